@@ -1,0 +1,131 @@
+/* include/mcr.h — C ABI of the MI355X-native MultiCarRacing-v0 batched step.
+ *
+ * The reference has no FFI of its own for this path: its native boundary is SWIG'd Box2D
+ * (`Box2D.b2World.Step`, multi_car_racing.py:428) plus ctypes OpenGL (`gl.glVertex3f`, :613-674).
+ * This header is the boundary a maintainer would bind instead (INTEGRATION.md shows the ctypes stub);
+ * each entry point names the reference interface it replaces.
+ *
+ * Conventions: plain pointers and sizes only, `int` status returns (0 = MCR_OK, <0 = error enum),
+ * nothing throws across the boundary, no exit().  `d_*` pointers are DEVICE pointers on the handle's
+ * HIP device; `stream` is a `hipStream_t` passed as `void*` (NULL = the null stream).  Kernels are only
+ * enqueued — no hidden device synchronisation in mcr_step / mcr_reset.
+ * One handle = one device = one env slice; handles are independent (thread-compatible).
+ */
+#ifndef MCR_H
+#define MCR_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCR_OK 0
+#define MCR_ERR_ARG (-1)      /* bad argument (NULL, range) */
+#define MCR_ERR_HIP (-2)      /* a HIP runtime call failed; see mcr_last_error() */
+#define MCR_ERR_STATE (-3)    /* call order violated (e.g. step before reset: AttributeError in the reference) */
+#define MCR_ERR_CAPACITY (-4) /* track larger than MCR_TILE_CAP / MCR_QUAD_CAP */
+
+#define MCR_MAX_AGENTS 8      /* CAR_COLORS has 8 entries (multi_car_racing.py:67-70) */
+#define MCR_TILE_CAP 512      /* tiles per track: observed 239..379 */
+#define MCR_QUAD_CAP 768      /* road_poly entries: observed 279..460 */
+#define MCR_OBS_H 96
+#define MCR_OBS_W 96
+#define MCR_MT_WORDS 625      /* MT19937 key[624] + pos — numpy RandomState layout */
+
+typedef struct mcr_env mcr_env; /* opaque */
+
+/* ctor kwargs of MultiCarRacing.__init__ (multi_car_racing.py:131-133) + batch/device knobs */
+typedef struct mcr_config {
+  int32_t num_envs;          /* B: environments in this slice */
+  int32_t num_agents;        /* N: 1..8 */
+  int32_t device;            /* HIP device ordinal */
+  int32_t obs_enabled;       /* 0: physics only ("obs=none"); 1: 96x96x3 state_pixels per agent */
+  int32_t auto_reset;        /* 1: finished envs are re-spawned inside mcr_step from their staged episode */
+  int32_t backwards_flag;    /* :158 */
+  int32_t use_ego_color;     /* :160 */
+  int32_t car_contacts;      /* 1: car<->car rigid contacts (Box2D default); 0: ghost cars (debug) */
+  int32_t max_episode_steps; /* gym TimeLimit from __init__.py:8 (1000); 0 disables */
+  int32_t reserved;
+  double h_ratio;            /* :159 */
+} mcr_config;
+
+const char* mcr_last_error(void);
+const char* mcr_version(void);
+
+/* ---- lifetime.  Replaces MultiCarRacing.__init__ (:131-166) / close (:606-611). */
+int mcr_create(const mcr_config* cfg, mcr_env** out);
+int mcr_destroy(mcr_env* h);
+
+/* ---- host-side episode setup (NO GPU needed).  Replaces reset()'s RNG draws + _create_track + spawn
+ * maths (:349-406, :183-338).  An "episode blob" is the host image of one env's device track slot. */
+size_t mcr_episode_bytes(void);
+/* numpy-compatible MT19937 helpers (RandomState.seed(int) / .seed(array), legacy stream). */
+void mcr_mt_seed(uint32_t* mt, uint32_t seed);
+void mcr_mt_seed_by_array(uint32_t* mt, const uint32_t* key, int key_len);
+double mcr_mt_random_sample(uint32_t* mt);
+/* np.random.choice(['CW','CCW']) (:352) -> 1 if 'CW';  np.random.choice(ids,size=N,replace=False) (:356) */
+int mcr_mt_choice_cw(uint32_t* mt);
+void mcr_mt_car_order(uint32_t* mt, int n, int32_t* order_out);
+/* One episode: retries _create_track until success (:359-364), builds tiles/quads/spawn poses.
+ * info_out[0..3] = T, P, retries, cw.  `mt_track` advances exactly as env.np_random does. */
+int mcr_episode_generate(uint32_t* mt_track, int num_agents, int cw, const int32_t* car_order,
+                         void* blob_out, int32_t* info_out);
+/* Batched + threaded: per env i draws direction (direction_mode 2) and car order from mt_global[i],
+ * then the track from mt_track[i].  direction_mode: 0 'CCW', 1 'CW', 2 random per episode. */
+int mcr_episodes_generate(uint32_t* mt_track, uint32_t* mt_global, int n, int num_agents,
+                          int direction_mode, void* blobs_out, int32_t* info_out, int num_threads);
+/* Read-only views into a blob (tests / facade attributes such as env.track). */
+int mcr_episode_unpack(const void* blob, int32_t* T, int32_t* P, int32_t* cw, double* track_xyb /*[T*3]*/,
+                       float* quads /*[P*8]*/, uint32_t* quad_meta /*[P]*/, double* spawn /*[8*3]*/,
+                       double* track_alpha /*[T]*/);
+
+/* ---- device side */
+/* Copy n host blobs into the STAGED slot of envs env_ids[0..n) (async on stream; blobs must stay valid
+ * until the stream reaches this point — use pinned memory for real overlap). */
+int mcr_stage_episodes(mcr_env* h, const int32_t* env_ids, int n, const void* blobs, void* stream);
+/* reset() (:340-408): installs the staged episode for every env whose d_env_mask byte != 0 (NULL = all),
+ * spawns the cars, runs the no-action step of :408 and writes the first observation.
+ * d_obs: [B,N,96,96,3] u8 or NULL. */
+int mcr_reset(mcr_env* h, const uint8_t* d_env_mask, uint8_t* d_obs, void* stream);
+/* step() (:410-509) for all B envs.
+ *   d_actions  [B,N,3] f32 (steer,gas,brake), NULL = the action-less step of :408
+ *   d_obs      [B,N,96,96,3] u8 or NULL (ignored when obs_enabled == 0)
+ *   d_reward   [B,N] f64 step_reward (:443,:507)
+ *   d_done     [B] u8   (:498-499, :503-506, TimeLimit)
+ *   d_trunc    [B] u8 or NULL: info['TimeLimit.truncated']
+ * With auto_reset, a finished env's obs row is the first observation of its next episode. */
+int mcr_step(mcr_env* h, const float* d_actions, uint8_t* d_obs, double* d_reward, uint8_t* d_done,
+             uint8_t* d_trunc, void* stream);
+/* Envs whose staged episode was consumed since the last poll (host must stage a fresh one).
+ * Synchronises `stream` only for a B-byte readback. Returns count (>=0) or error. */
+int mcr_poll_consumed(mcr_env* h, int32_t* env_ids_out, int cap, void* stream);
+
+/* ---- state access for differential tests / facade attributes (synchronous) */
+/* bodies [B,N,5,6] f32 (c.x c.y angle v.x v.y w; body 0 hull, 1..4 wheels FL FR RL RR)
+ * joints [B,N,4,4] f32 (impulse x y z, motorImpulse); wheels [B,N,4,5] f64 (gas brake steer phase omega)
+ * limit [B,N,4] i32; on_road [B,N,4] u8; sleep [B,N,5] f32.  Any pointer may be NULL. */
+int mcr_get_state(mcr_env* h, float* bodies, float* joints, double* wheels, int32_t* limit, uint8_t* on_road,
+                  float* sleep);
+int mcr_set_bodies(mcr_env* h, const float* bodies /*[B,N,5,6]*/);
+/* reward [B,N] f64 (self.reward), tile_visited_count [B,N] i32, backward/on_grass [B,N] u8,
+ * t [B] f64, tile_flags [B,MCR_TILE_CAP] u16 (bits 0..7 road_visited per agent, bit 8 recoloured) */
+int mcr_get_env_state(mcr_env* h, double* reward, int32_t* tile_visited_count, uint8_t* backward,
+                      uint8_t* on_grass, double* t, uint16_t* tile_flags, int32_t* num_tiles);
+/* hull.position per car [B,N,2] f32 */
+int mcr_get_positions(mcr_env* h, float* pos);
+/* mass KATs: hull invMass, invI, localCenter.x, .y, wheel invMass, invI (host computation) */
+void mcr_mass_props(float* out6);
+/* the build's sinf/cosf spec evaluated on the host (tests compare with the device kernel's) */
+void mcr_sincos_host(float a, float* s, float* c);
+int mcr_sincos_device(mcr_env* h, const float* d_in, float* d_sin, float* d_cos, int n, void* stream);
+
+/* ---- instrumentation for bench.py: HIP-event timing of the kernels enqueued by mcr_step.
+ * enable=1 records events around every kernel on the launch stream; mcr_timing_read drains
+ * accumulated milliseconds + launch counts per kernel id (0 collide, 1 dynamics, 2 view). */
+int mcr_timing_enable(mcr_env* h, int enable);
+int mcr_timing_read(mcr_env* h, double* ms_out /*[3]*/, int64_t* launches_out /*[3]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCR_H */

@@ -1,0 +1,104 @@
+"""ctypes binding of include/mcr.h.  Fails loudly if the HIP library is missing — there is no CPU fallback."""
+import ctypes, os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_lib", "libmcr_hip.so")
+
+MAX_AGENTS = 8
+TILE_CAP = 512
+QUAD_CAP = 768
+MT_WORDS = 625
+
+_vp, _i, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+
+
+class Config(ctypes.Structure):
+    _fields_ = [("num_envs", ctypes.c_int32), ("num_agents", ctypes.c_int32), ("device", ctypes.c_int32),
+                ("obs_enabled", ctypes.c_int32), ("auto_reset", ctypes.c_int32), ("backwards_flag", ctypes.c_int32),
+                ("use_ego_color", ctypes.c_int32), ("car_contacts", ctypes.c_int32), ("max_episode_steps", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("h_ratio", ctypes.c_double)]
+
+
+# every symbol include/mcr.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "mcr_last_error": (ctypes.c_char_p, []),
+    "mcr_version": (ctypes.c_char_p, []),
+    "mcr_create": (_i, [ctypes.POINTER(Config), ctypes.POINTER(_vp)]),
+    "mcr_destroy": (_i, [_vp]),
+    "mcr_episode_bytes": (ctypes.c_size_t, []),
+    "mcr_mt_seed": (None, [_vp, ctypes.c_uint32]),
+    "mcr_mt_seed_by_array": (None, [_vp, _vp, _i]),
+    "mcr_mt_random_sample": (_d, [_vp]),
+    "mcr_mt_choice_cw": (_i, [_vp]),
+    "mcr_mt_car_order": (None, [_vp, _i, _vp]),
+    "mcr_episode_generate": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "mcr_episodes_generate": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i]),
+    "mcr_episode_unpack": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mcr_stage_episodes": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "mcr_reset": (_i, [_vp, _vp, _vp, _vp]),
+    "mcr_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mcr_poll_consumed": (_i, [_vp, _vp, _i, _vp]),
+    "mcr_get_state": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mcr_set_bodies": (_i, [_vp, _vp]),
+    "mcr_get_env_state": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mcr_get_positions": (_i, [_vp, _vp]),
+    "mcr_mass_props": (None, [_vp]),
+    "mcr_sincos_host": (None, [ctypes.c_float, _vp, _vp]),
+    "mcr_sincos_device": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "mcr_timing_enable": (_i, [_vp, _i]),
+    "mcr_timing_read": (_i, [_vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class McrError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the in-tree library.  Import torch FIRST in GPU processes so both share one libamdhip64."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise McrError(f"{LIB_PATH} is missing: run `python -m multi_car_racing_amd.build` "
+                       "(hipcc --offload-arch=gfx950). There is no CPU fallback for the step path.")
+    L = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)           # AttributeError here == header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc, what=""):
+    if rc < 0:
+        raise McrError(f"{what} failed ({rc}): {load().mcr_last_error().decode()}")
+    return rc
+
+
+def ptr(a):
+    """host numpy array -> void*"""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def episode_bytes():
+    return int(load().mcr_episode_bytes())
+
+
+def unpack_episode(blob):
+    """host blob (uint8 array) -> dict(track (T,3) x,y,beta; quads (P,4,2) f32; quad_meta (P,) u32; spawn (8,3); cw)"""
+    L = load()
+    T, P, cw = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    L.mcr_episode_unpack(ptr(blob), ctypes.byref(T), ctypes.byref(P), ctypes.byref(cw), None, None, None, None, None)
+    track = np.zeros((T.value, 3)); quads = np.zeros((P.value, 8), np.float32); meta = np.zeros(P.value, np.uint32)
+    spawn = np.zeros((MAX_AGENTS, 3)); alpha = np.zeros(T.value)
+    L.mcr_episode_unpack(ptr(blob), None, None, None, ptr(track), ptr(quads), ptr(meta), ptr(spawn), ptr(alpha))
+    return dict(T=T.value, P=P.value, cw=bool(cw.value), track=track, alpha=alpha, quads=quads.reshape(-1, 4, 2),
+                quad_meta=meta, spawn=spawn)

@@ -1,0 +1,33 @@
+"""Build the in-tree HIP library (gfx950).  `python -m multi_car_racing_amd.build` or __graft_entry__.build()."""
+import os, subprocess, sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "_lib", "libmcr_hip.so")
+SOURCES = ["mcr_hip.hip", "mcr_host.cpp"]
+DEPS = SOURCES + ["mcr_common.h", "mcr_kernels.h", "k_dynamics.h", "k_collide.h", "k_view.h", os.path.join("..", "..", "include", "mcr.h")]
+# -ffp-contract=off: host (x86-64) and gfx950 must round identically (numerics)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-value"]
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

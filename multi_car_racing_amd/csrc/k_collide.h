@@ -1,0 +1,188 @@
+// k_collide.h — one wavefront per env: the sensor half of b2ContactManager::Collide plus the
+// FrictionDetector callbacks (multi_car_racing.py:80-123) at the poses ENTERING the step.
+//
+//  * lanes 0..8N-1 first build the env's car fixtures in world space (4 hull polygons + 4 wheels per
+//    car) into LDS, 8-lane groups reduce each car's AABB;
+//  * the wave then streams the track's tile AABBs from HBM (one float4 per lane per 64 tiles, fully
+//    coalesced); only tiles whose AABB meets a car's box load their hull and run the overlap test;
+//  * begin events are replayed in a defined order (tile ascending, car ascending) with wave ballots so
+//    that the f64 reward accumulation is order-exact (:113-120);
+//  * the per-wheel "touches any tile" mask (friction_limit, Car.step) is a wave-wide OR.
+//
+// Overlap predicate == result of b2TestOverlap (b2Distance with radii, touching iff
+// distance < 10*FLT_EPSILON): SAT for penetration / early-out, exact vertex-edge distance otherwise.
+#pragma once
+#include "mcr_kernels.h"
+
+namespace col {
+
+struct TilePoly { int n; float vx[4], vy[4], nx[4], ny[4]; };
+
+// max over A's edge normals of the min projection of B's vertices (A from LDS, B = tile)
+__device__ __forceinline__ float sat_fixture_tile(const float* avx, const float* avy, const float* anx, const float* any_, int an,
+                                                  const TilePoly& T) {
+  float best = -MCR_MAXFLT;
+  for (int i = 0; i < an; ++i) {
+    float mn = MCR_MAXFLT;
+    for (int j = 0; j < T.n; ++j) {
+      float d = anx[i] * (T.vx[j] - avx[i]) + any_[i] * (T.vy[j] - avy[i]);
+      mn = mcr_min(mn, d);
+    }
+    best = mcr_max(best, mn);
+  }
+  return best;
+}
+__device__ __forceinline__ float sat_tile_fixture(const TilePoly& T, const float* bvx, const float* bvy, int bn) {
+  float best = -MCR_MAXFLT;
+  for (int i = 0; i < T.n; ++i) {
+    float mn = MCR_MAXFLT;
+    for (int j = 0; j < bn; ++j) {
+      float d = T.nx[i] * (bvx[j] - T.vx[i]) + T.ny[i] * (bvy[j] - T.vy[i]);
+      mn = mcr_min(mn, d);
+    }
+    best = mcr_max(best, mn);
+  }
+  return best;
+}
+__device__ __forceinline__ float pt_seg_d2(float px, float py, float ax, float ay, float bx, float by) {
+  float abx = bx - ax, aby = by - ay, apx = px - ax, apy = py - ay;
+  float t = apx * abx + apy * aby;
+  float den = abx * abx + aby * aby;
+  if (t <= 0.0f) return apx * apx + apy * apy;
+  if (t >= den) { float bpx = px - bx, bpy = py - by; return bpx * bpx + bpy * bpy; }
+  float cr = abx * apy - aby * apx;
+  return (cr * cr) / den;
+}
+__device__ __forceinline__ bool overlap(const float* avx, const float* avy, const float* anx, const float* any_, int an, const TilePoly& T) {
+  const float R = 2.0f * B2_POLYGON_RADIUS;
+  const float TH = R + 10.0f * B2_EPSILON;
+  float s = mcr_max(sat_fixture_tile(avx, avy, anx, any_, an, T), sat_tile_fixture(T, avx, avy, an));
+  if (s > TH) return false;
+  if (s <= 0.0f) return true;
+  float d2 = MCR_MAXFLT;
+  for (int i = 0; i < an; ++i)
+    for (int j = 0; j < T.n; ++j) { int k = (j + 1) % T.n; d2 = mcr_min(d2, pt_seg_d2(avx[i], avy[i], T.vx[j], T.vy[j], T.vx[k], T.vy[k])); }
+  for (int i = 0; i < T.n; ++i)
+    for (int j = 0; j < an; ++j) { int k = (j + 1) % an; d2 = mcr_min(d2, pt_seg_d2(T.vx[i], T.vy[i], avx[j], avy[j], avx[k], avy[k])); }
+  return d2 < TH * TH;
+}
+
+}  // namespace col
+
+// pass 0: every active env.  pass 1: only envs with `resetting` set (their per-tile state is cleared first).
+__global__ __launch_bounds__(64) void k_collide(McrParams p, int pass) {
+  using namespace col;
+  const int env = blockIdx.x, lane = threadIdx.x;
+  const McrEnvState es = p.env[env];
+  if (!es.active) return;
+  if (pass == 1 && !es.resetting) return;
+  const int N = p.N, BN = p.BN;
+  const uint8_t* slot = p.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES;
+  const int T = ((const McrSlotHeader*)slot)->T;
+  uint32_t* touch = p.tile_touch + (size_t)env * MCR_TILE_CAP;
+  uint16_t* tflags = p.tile_flags + (size_t)env * MCR_TILE_CAP;
+  if (pass == 1) for (int t = lane; t < MCR_TILE_CAP; t += 64) { touch[t] = 0; tflags[t] = 0; }
+
+  __shared__ float fvx[64][8], fvy[64][8], fnx[64][8], fny[64][8];
+  __shared__ int fcnt[64];
+  __shared__ float cbox[MCR_MAX_AGENTS][4];
+  {
+    const int c = lane >> 3, fi = lane & 7;
+    float lox = MCR_MAXFLT, loy = MCR_MAXFLT, hix = -MCR_MAXFLT, hiy = -MCR_MAXFLT;
+    if (c < N) {
+      const int ci = env * N + c;
+      const int body = fi < 4 ? 0 : fi - 3;
+      const McrShapes& S = *p.shapes;
+      const McrPoly& P = fi < 4 ? S.hull[fi] : S.wheel;
+      V2 cc = v2(p.carf[(CF_CX + body) * BN + ci], p.carf[(CF_CY + body) * BN + ci]);
+      float a = p.carf[(CF_A + body) * BN + ci];
+      V2 lc = body == 0 ? v2(S.hull_lcx, S.hull_lcy) : v2(0.0f, 0.0f);
+      Xf xf = xf_of(cc, a, lc);
+      fcnt[lane] = P.n;
+      for (int i = 0; i < P.n; ++i) {
+        V2 w = xmul(xf, v2(P.vx[i], P.vy[i]));
+        V2 n = rmul(xf.q, v2(P.nx[i], P.ny[i]));
+        fvx[lane][i] = w.x; fvy[lane][i] = w.y; fnx[lane][i] = n.x; fny[lane][i] = n.y;
+        lox = mcr_min(lox, w.x); loy = mcr_min(loy, w.y); hix = mcr_max(hix, w.x); hiy = mcr_max(hiy, w.y);
+      }
+    } else fcnt[lane] = 0;
+    for (int o = 1; o < 8; o <<= 1) {
+      lox = mcr_min(lox, __shfl_xor(lox, o)); loy = mcr_min(loy, __shfl_xor(loy, o));
+      hix = mcr_max(hix, __shfl_xor(hix, o)); hiy = mcr_max(hiy, __shfl_xor(hiy, o));
+    }
+    if (fi == 0 && c < MCR_MAX_AGENTS) { cbox[c][0] = lox - 0.05f; cbox[c][1] = loy - 0.05f; cbox[c][2] = hix + 0.05f; cbox[c][3] = hiy + 0.05f; }
+  }
+  __syncthreads();
+
+  // uniform per-car accumulators (every lane keeps the same values)
+  double reward[MCR_MAX_AGENTS]; int tvc[MCR_MAX_AGENTS];
+#pragma unroll
+  for (int c = 0; c < MCR_MAX_AGENTS; ++c) { reward[c] = 0.0; tvc[c] = 0; }
+#pragma unroll
+  for (int c = 0; c < MCR_MAX_AGENTS; ++c) if (c < N) { reward[c] = p.card[CD_REWARD * BN + env * N + c]; tvc[c] = (int)p.caru[CU_TVC * BN + env * N + c]; }
+
+  const float4* TAABB = (const float4*)(slot + MCR_OFF_TAABB);
+  const float4* TVA = (const float4*)(slot + MCR_OFF_TVA); const float4* TVB = (const float4*)(slot + MCR_OFF_TVB);
+  const float4* TNA = (const float4*)(slot + MCR_OFF_TNA); const float4* TNB = (const float4*)(slot + MCR_OFF_TNB);
+  const uint32_t* TCNT = (const uint32_t*)(slot + MCR_OFF_TCNT);
+  uint32_t or_bits = 0;
+  for (int base = 0; base < T; base += 64) {
+    const int t = base + lane;
+    const bool valid = t < T;
+    uint32_t newbits = 0; bool touch_any = false;
+    uint32_t old = 0; uint32_t fl = 0;
+    if (valid) {
+      old = touch[t]; fl = tflags[t];
+      const float4 bb = TAABB[t];
+      bool loaded = false; TilePoly TP;
+      for (int c = 0; c < N; ++c) {
+        if (bb.x > cbox[c][2] || bb.z < cbox[c][0] || bb.y > cbox[c][3] || bb.w < cbox[c][1]) continue;
+        if (!loaded) {
+          float4 va = TVA[t], vb = TVB[t], na = TNA[t], nb = TNB[t];
+          TP.n = (int)TCNT[t];
+          TP.vx[0] = va.x; TP.vy[0] = va.y; TP.vx[1] = va.z; TP.vy[1] = va.w; TP.vx[2] = vb.x; TP.vy[2] = vb.y; TP.vx[3] = vb.z; TP.vy[3] = vb.w;
+          TP.nx[0] = na.x; TP.ny[0] = na.y; TP.nx[1] = na.z; TP.ny[1] = na.w; TP.nx[2] = nb.x; TP.ny[2] = nb.y; TP.nx[3] = nb.z; TP.ny[3] = nb.w;
+          loaded = true;
+        }
+        for (int fi = 0; fi < 8; ++fi) {
+          const int f = c * 8 + fi;
+          bool ov = overlap(fvx[f], fvy[f], fnx[f], fny[f], fcnt[f], TP);
+          if (ov) { touch_any = true; if (fi >= 4) newbits |= 1u << (c * 4 + (fi - 4)); }
+        }
+      }
+      if (touch_any || old != newbits) fl |= 0x100u;          // any Begin/End recolours the tile (:102-104)
+    }
+    const uint32_t begins = newbits & ~old;
+    unsigned long long m = __ballot(valid && begins != 0);
+    while (m) {
+      const int l = __ffsll((long long)m) - 1; m &= m - 1;
+      const uint32_t bg = (uint32_t)__shfl((int)begins, l);
+      uint32_t vis = (uint32_t)__shfl((int)(fl & 0xffu), l);
+#pragma unroll
+      for (int c = 0; c < MCR_MAX_AGENTS; ++c) {
+        if (c < N && ((bg >> (4 * c)) & 0xFu) && !(vis & (1u << c))) {
+          vis |= 1u << c;
+          tvc[c] += 1;
+          int past = __popc(vis) - 1;
+          double factor = 1 - ((double)past / (double)N);
+          reward[c] += factor * 1000.0 / (double)T;
+        }
+      }
+      if (lane == l) fl = (fl & ~0xffu) | vis;
+    }
+    if (valid) { touch[t] = newbits; tflags[t] = (uint16_t)fl; }
+    or_bits |= newbits;
+  }
+  for (int o = 1; o < 64; o <<= 1) or_bits |= (uint32_t)__shfl_xor((int)or_bits, o);
+  if (lane < N) {
+    const int ci = env * N + lane;
+    uint32_t prev = p.caru[CU_ONROAD * BN + ci] & 0xFu;
+    uint32_t cur = (or_bits >> (4 * lane)) & 0xFu;
+    p.caru[CU_ONROAD * BN + ci] = (prev << 4) | cur;
+    double r = 0.0; int tv = 0;
+#pragma unroll
+    for (int c = 0; c < MCR_MAX_AGENTS; ++c) if (c == lane) { r = reward[c]; tv = tvc[c]; }
+    p.card[CD_REWARD * BN + ci] = r;
+    p.caru[CU_TVC * BN + ci] = (uint32_t)tv;
+  }
+}

@@ -1,0 +1,473 @@
+// k_dynamics.h — one wavefront lane per car: Car.steer/gas/brake + Car.step (binary64, as CPython),
+// then the Box2D island solve for the car's 5 bodies and 4 revolute joints (binary32, as Box2D):
+// integrate velocities, warm start, 180 Gauss-Seidel velocity iterations, integrate positions,
+// <=60 position iterations with the early exit, sleep bookkeeping; then the env bookkeeping of
+// multi_car_racing.py:433-443,497-507 across the env's lane group, TimeLimit, and the auto-reset install.
+//
+// Reference: multi_car_racing.py:418-429; gym car_dynamics.py Car.{steer,gas,brake,step};
+// Box2D 2.3 b2Island::Solve, b2RevoluteJoint::{Init,Solve}VelocityConstraints/SolvePositionConstraints.
+//
+// State lives in registers for the whole step (~110 VGPRs): the 180x4 joint iterations are a serial
+// dependency chain, so the kernel is VALU-latency bound, not HBM bound; loads/stores are one coalesced
+// 4- or 8-byte access per SoA field per lane.
+#pragma once
+#include "mcr_kernels.h"
+
+namespace dyn {
+
+struct Joint {
+  float ix, iy, iz, im;          // accumulated impulse (x,y,z) + motor impulse (warm start state)
+  float motorSpeed;
+  int limit;                     // 0 inactive, 1 at lower, 2 at upper
+  // per-step temporaries
+  float rAx, rAy, rBx, rBy;
+  float exx, eyx, ezx, eyy, ezy, ezz;   // symmetric K (b2Mat33 m_mass): ex=(exx,eyx,ezx) ey=(eyx,eyy,ezy) ez=(ezx,ezy,ezz)
+  float motorMass;
+};
+
+__device__ __forceinline__ float d3(float ax, float ay, float az, float bx, float by, float bz) { return ax * bx + ay * by + az * bz; }
+
+// b2Mat33::Solve33 (det recomputed exactly as Box2D does; loop-invariant pieces are CSE'd by the compiler)
+__device__ __forceinline__ void solve33(const Joint& J, float bx, float by, float bz, float& x, float& y, float& z) {
+  // ex=(exx,eyx,ezx)  ey=(eyx,eyy,ezy)  ez=(ezx,ezy,ezz)
+  float ex0 = J.exx, ex1 = J.eyx, ex2 = J.ezx;
+  float ey0 = J.eyx, ey1 = J.eyy, ey2 = J.ezy;
+  float ez0 = J.ezx, ez1 = J.ezy, ez2 = J.ezz;
+  // cross(ey, ez)
+  float c0 = ey1 * ez2 - ey2 * ez1, c1 = ey2 * ez0 - ey0 * ez2, c2 = ey0 * ez1 - ey1 * ez0;
+  float det = d3(ex0, ex1, ex2, c0, c1, c2);
+  if (det != 0.0f) det = 1.0f / det;
+  x = det * d3(bx, by, bz, c0, c1, c2);
+  // cross(b, ez)
+  float p0 = by * ez2 - bz * ez1, p1 = bz * ez0 - bx * ez2, p2 = bx * ez1 - by * ez0;
+  y = det * d3(ex0, ex1, ex2, p0, p1, p2);
+  // cross(ey, b)
+  float r0 = ey1 * bz - ey2 * by, r1 = ey2 * bx - ey0 * bz, r2 = ey0 * by - ey1 * bx;
+  z = det * d3(ex0, ex1, ex2, r0, r1, r2);
+}
+// b2Mat33::Solve22
+__device__ __forceinline__ void solve22(const Joint& J, float bx, float by, float& x, float& y) {
+  float a11 = J.exx, a12 = J.eyx, a21 = J.eyx, a22 = J.eyy;
+  float det = a11 * a22 - a12 * a21;
+  if (det != 0.0f) det = 1.0f / det;
+  x = det * (a22 * bx - a12 * by);
+  y = det * (a11 * by - a21 * bx);
+}
+
+struct Body { float cx, cy, a, vx, vy, w; };
+
+// b2RevoluteJoint::InitVelocityConstraints (enableMotor, enableLimit, limits +-0.4, dtRatio 1)
+__device__ __forceinline__ void joint_init(Joint& J, Body& A, Body& B, float anchx, float anchy, float lcx, float lcy,
+                                           float mA, float iA, float mB, float iB) {
+  Rot qA = rot_of(A.a), qB = rot_of(B.a);
+  V2 rA = rmul(qA, v2(anchx, anchy) - v2(lcx, lcy));
+  V2 rB = rmul(qB, v2(0.0f, 0.0f) - v2(0.0f, 0.0f));
+  J.rAx = rA.x; J.rAy = rA.y; J.rBx = rB.x; J.rBy = rB.y;
+  J.exx = mA + mB + J.rAy * J.rAy * iA + J.rBy * J.rBy * iB;
+  J.eyx = -J.rAy * J.rAx * iA - J.rBy * J.rBx * iB;
+  J.ezx = -J.rAy * iA - J.rBy * iB;
+  J.eyy = mA + mB + J.rAx * J.rAx * iA + J.rBx * J.rBx * iB;
+  J.ezy = J.rAx * iA + J.rBx * iB;
+  J.ezz = iA + iB;
+  J.motorMass = iA + iB;
+  if (J.motorMass > 0.0f) J.motorMass = 1.0f / J.motorMass;
+  float jointAngle = B.a - A.a;
+  if (jointAngle <= -0.4f) { if (J.limit != 1) J.iz = 0.0f; J.limit = 1; }
+  else if (jointAngle >= 0.4f) { if (J.limit != 2) J.iz = 0.0f; J.limit = 2; }
+  else { J.limit = 0; J.iz = 0.0f; }
+  // warm start
+  float Px = J.ix, Py = J.iy;
+  A.vx = A.vx - mA * Px; A.vy = A.vy - mA * Py;
+  A.w -= iA * ((J.rAx * Py - J.rAy * Px) + J.im + J.iz);
+  B.vx = B.vx + mB * Px; B.vy = B.vy + mB * Py;
+  B.w += iB * ((J.rBx * Py - J.rBy * Px) + J.im + J.iz);
+}
+
+// b2RevoluteJoint::SolveVelocityConstraints
+__device__ __forceinline__ void joint_velocity(Joint& J, Body& A, Body& B, float mA, float iA, float mB, float iB, float maxImpulse) {
+  float vAx = A.vx, vAy = A.vy, wA = A.w, vBx = B.vx, vBy = B.vy, wB = B.w;
+  {
+    float Cdot = wB - wA - J.motorSpeed;
+    float impulse = -J.motorMass * Cdot;
+    float old = J.im;
+    J.im = mcr_clamp(J.im + impulse, -maxImpulse, maxImpulse);
+    impulse = J.im - old;
+    wA -= iA * impulse; wB += iB * impulse;
+  }
+  if (J.limit != 0) {
+    // Cdot1 = vB + cross(wB, rB) - vA - cross(wA, rA)
+    float c1x = ((vBx + (-wB * J.rBy)) - vAx) - (-wA * J.rAy);
+    float c1y = ((vBy + (wB * J.rBx)) - vAy) - (wA * J.rAx);
+    float c2 = wB - wA;
+    float sx, sy, sz; solve33(J, c1x, c1y, c2, sx, sy, sz);
+    float impx = -sx, impy = -sy, impz = -sz;
+    float newImpulse = J.iz + impz;
+    bool reduce = (J.limit == 1) ? (newImpulse < 0.0f) : (newImpulse > 0.0f);
+    if (reduce) {
+      float rhsx = -c1x + J.iz * J.ezx, rhsy = -c1y + J.iz * J.ezy;
+      float rx, ry; solve22(J, rhsx, rhsy, rx, ry);
+      impx = rx; impy = ry; impz = -J.iz;
+      J.ix += rx; J.iy += ry; J.iz = 0.0f;
+    } else { J.ix += impx; J.iy += impy; J.iz += impz; }
+    vAx = vAx - mA * impx; vAy = vAy - mA * impy;
+    wA -= iA * ((J.rAx * impy - J.rAy * impx) + impz);
+    vBx = vBx + mB * impx; vBy = vBy + mB * impy;
+    wB += iB * ((J.rBx * impy - J.rBy * impx) + impz);
+  } else {
+    float cx = ((vBx + (-wB * J.rBy)) - vAx) - (-wA * J.rAy);
+    float cy = ((vBy + (wB * J.rBx)) - vAy) - (wA * J.rAx);
+    float ix, iy; solve22(J, -cx, -cy, ix, iy);
+    J.ix += ix; J.iy += iy;
+    vAx = vAx - mA * ix; vAy = vAy - mA * iy;
+    wA -= iA * (J.rAx * iy - J.rAy * ix);
+    vBx = vBx + mB * ix; vBy = vBy + mB * iy;
+    wB += iB * (J.rBx * iy - J.rBy * ix);
+  }
+  A.vx = vAx; A.vy = vAy; A.w = wA; B.vx = vBx; B.vy = vBy; B.w = wB;
+}
+
+// b2RevoluteJoint::SolvePositionConstraints
+__device__ __forceinline__ bool joint_position(const Joint& J, Body& A, Body& B, float anchx, float anchy, float lcx, float lcy,
+                                               float mA, float iA, float mB, float iB) {
+  float cAx = A.cx, cAy = A.cy, aA = A.a, cBx = B.cx, cBy = B.cy, aB = B.a;
+  float angularError = 0.0f, positionError = 0.0f;
+  if (J.limit != 0) {
+    float angle = aB - aA;
+    float limitImpulse = 0.0f;
+    if (J.limit == 1) {
+      float C = angle - (-0.4f); angularError = -C;
+      C = mcr_clamp(C + B2_ANGULAR_SLOP, -B2_MAX_ANGULAR_CORRECTION, 0.0f);
+      limitImpulse = -J.motorMass * C;
+    } else {
+      float C = angle - 0.4f; angularError = C;
+      C = mcr_clamp(C - B2_ANGULAR_SLOP, 0.0f, B2_MAX_ANGULAR_CORRECTION);
+      limitImpulse = -J.motorMass * C;
+    }
+    aA -= iA * limitImpulse; aB += iB * limitImpulse;
+  }
+  {
+    Rot qA = rot_of(aA), qB = rot_of(aB);
+    V2 rA = rmul(qA, v2(anchx, anchy) - v2(lcx, lcy));
+    V2 rB = rmul(qB, v2(0.0f, 0.0f) - v2(0.0f, 0.0f));
+    float Cx = ((cBx + rB.x) - cAx) - rA.x, Cy = ((cBy + rB.y) - cAy) - rA.y;
+    positionError = sqrtf(Cx * Cx + Cy * Cy);
+    float k11 = mA + mB + iA * rA.y * rA.y + iB * rB.y * rB.y;
+    float k12 = -iA * rA.x * rA.y - iB * rB.x * rB.y;
+    float k22 = mA + mB + iA * rA.x * rA.x + iB * rB.x * rB.x;
+    float det = k11 * k22 - k12 * k12;
+    if (det != 0.0f) det = 1.0f / det;
+    float ix = -(det * (k22 * Cx - k12 * Cy)), iy = -(det * (k11 * Cy - k12 * Cx));
+    cAx = cAx - mA * ix; cAy = cAy - mA * iy; aA -= iA * (rA.x * iy - rA.y * ix);
+    cBx = cBx + mB * ix; cBy = cBy + mB * iy; aB += iB * (rB.x * iy - rB.y * ix);
+  }
+  A.cx = cAx; A.cy = cAy; A.a = aA; B.cx = cBx; B.cy = cBy; B.a = aB;
+  return positionError <= B2_LINEAR_SLOP && angularError <= B2_ANGULAR_SLOP;
+}
+
+__device__ __forceinline__ double np_sign(double x) { return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : 0.0); }
+
+}  // namespace dyn
+
+// mode 0: regular step (bookkeeping, TimeLimit, auto-reset install)
+// mode 1: the action-less step of reset() (:408) for envs whose `resetting` flag is set
+__global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
+  using namespace dyn;
+  const int g = blockIdx.x * 64 + threadIdx.x;
+  const int env = g / p.G, agent = g % p.G;
+  const bool lane_ok = env < p.B && agent < p.N;
+  const int ci = lane_ok ? env * p.N + agent : 0;
+  const int BN = p.BN;
+  McrEnvState es;
+  if (env < p.B) es = p.env[env]; else { es.active = 0; es.resetting = 0; }
+  bool run = lane_ok && es.active;
+  if (mode == 1) run = run && es.resetting;
+
+  const McrShapes& S = *p.shapes;
+  const float mH = S.hull_invMass, iH = S.hull_invI, mW = S.wheel_invMass, iW = S.wheel_invI;
+  const float lcx = S.hull_lcx, lcy = S.hull_lcy;
+  const float h = (float)(1.0 / MCR_FPS);
+  const double dt = 1.0 / MCR_FPS;
+
+  Body b[5]; Joint J[4];
+  double gas[2] = {0, 0}, steer = 0, brake = 0, omega[4] = {0, 0, 0, 0}, phase[4] = {0, 0, 0, 0};
+  float sleepT[5] = {0, 0, 0, 0, 0};
+  uint32_t onroad = 0;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { b[k].cx = b[k].cy = b[k].a = b[k].vx = b[k].vy = b[k].w = 0.0f; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { J[k].ix = J[k].iy = J[k].iz = J[k].im = 0.0f; J[k].limit = 0; J[k].motorSpeed = 0.0f; }
+
+  if (run) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      b[k].cx = p.carf[(CF_CX + k) * BN + ci]; b[k].cy = p.carf[(CF_CY + k) * BN + ci]; b[k].a = p.carf[(CF_A + k) * BN + ci];
+      b[k].vx = p.carf[(CF_VX + k) * BN + ci]; b[k].vy = p.carf[(CF_VY + k) * BN + ci]; b[k].w = p.carf[(CF_W + k) * BN + ci];
+      sleepT[k] = p.carf[(CF_SLEEP + k) * BN + ci];
+    }
+    uint32_t lim = p.caru[CU_LIMIT * BN + ci];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      J[k].ix = p.carf[(CF_JIX + k) * BN + ci]; J[k].iy = p.carf[(CF_JIY + k) * BN + ci];
+      J[k].iz = p.carf[(CF_JIZ + k) * BN + ci]; J[k].im = p.carf[(CF_JM + k) * BN + ci];
+      J[k].limit = (lim >> (2 * k)) & 3;
+      omega[k] = p.card[(CD_OMEGA + k) * BN + ci]; phase[k] = p.card[(CD_PHASE + k) * BN + ci];
+    }
+    gas[0] = p.card[(CD_GAS + 0) * BN + ci]; gas[1] = p.card[(CD_GAS + 1) * BN + ci];
+    steer = p.card[CD_STEER * BN + ci]; brake = p.card[CD_BRAKE * BN + ci];
+    onroad = p.caru[CU_ONROAD * BN + ci];
+
+    // ---- controls (:418-424) — the reference negates the steering input
+    if (mode == 0 && p.actions) {
+      double a0 = (double)p.actions[ci * 3 + 0], a1 = (double)p.actions[ci * 3 + 1], a2 = (double)p.actions[ci * 3 + 2];
+      steer = -a0;
+      double gg = fmin(fmax(a1, 0.0), 1.0);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) { double diff = gg - gas[k]; if (diff > 0.1) diff = 0.1; gas[k] += diff; }
+      brake = a2;
+    }
+
+    // ---- Car.step(dt): tyre model, f64.  Friction uses the PREVIOUS Collide's contact set (bits 4..7).
+    const double ENGINE_POWER = 100000000 * MCR_SIZE * MCR_SIZE;
+    const double WHEEL_MOI = 4000 * MCR_SIZE * MCR_SIZE;
+    const double FRICTION_LIMIT = 1000000 * MCR_SIZE * MCR_SIZE;
+    const double WHEEL_RAD = MCR_WHEEL_R * MCR_SIZE;
+    const double KF = 205000 * MCR_SIZE * MCR_SIZE;
+    float fx[4], fy[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double wsteer = (k < 2) ? steer : 0.0;
+      double wgas = (k >= 2) ? gas[k - 2] : 0.0;
+      double jangle = (double)(b[k + 1].a - b[0].a);
+      double dir = np_sign(wsteer - jangle);
+      double val = fabs(wsteer - jangle);
+      J[k].motorSpeed = (float)(dir * fmin(50.0 * val, 3.0));
+      double friction_limit = FRICTION_LIMIT * 0.6;
+      if ((onroad >> (4 + k)) & 1u) friction_limit = fmax(friction_limit, FRICTION_LIMIT * 1.0);
+      Rot q = rot_of(b[k + 1].a);
+      double forw0 = (double)(-q.s), forw1 = (double)q.c, side0 = (double)q.c, side1 = (double)q.s;
+      double vx = (double)b[k + 1].vx, vy = (double)b[k + 1].vy;
+      double vf = forw0 * vx + forw1 * vy;
+      double vs = side0 * vx + side1 * vy;
+      double om = omega[k];
+      om += dt * ENGINE_POWER * wgas / WHEEL_MOI / (fabs(om) + 5.0);
+      if (brake >= 0.9) om = 0;
+      else if (brake > 0) {
+        double d = -np_sign(om);
+        double v = 15 * brake;
+        if (fabs(v) > fabs(om)) v = fabs(om);
+        om += d * v;
+      }
+      phase[k] += om * dt;
+      double vr = om * WHEEL_RAD;
+      double f_force = -vf + vr;
+      double p_force = -vs;
+      f_force *= KF; p_force *= KF;
+      double force = sqrt(f_force * f_force + p_force * p_force);
+      if (fabs(force) > friction_limit) {
+        f_force /= force; p_force /= force;
+        force = friction_limit;
+        f_force *= force; p_force *= force;
+      }
+      om -= dt * f_force * WHEEL_RAD / WHEEL_MOI;
+      omega[k] = om;
+      fx[k] = (float)(p_force * side0 + f_force * forw0);
+      fy[k] = (float)(p_force * side1 + f_force * forw1);
+    }
+
+    // ---- b2Island::Solve: integrate velocities
+    b[0].vx = b[0].vx + h * (mH * 0.0f); b[0].vy = b[0].vy + h * (mH * 0.0f); b[0].w += h * iH * 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      b[k + 1].vx = b[k + 1].vx + h * (mW * (0.0f + fx[k])); b[k + 1].vy = b[k + 1].vy + h * (mW * (0.0f + fy[k]));
+      b[k + 1].w += h * iW * 0.0f;
+    }
+    // joints, island order 3,2,1,0
+#pragma unroll
+    for (int q = 3; q >= 0; --q) joint_init(J[q], b[0], b[q + 1], S.anchor_x[q], S.anchor_y[q], lcx, lcy, mH, iH, mW, iW);
+    const float maxImpulse = h * (float)(180 * 900 * MCR_SIZE * MCR_SIZE);
+    for (int it = 0; it < 180; ++it) {
+#pragma unroll
+      for (int q = 3; q >= 0; --q) joint_velocity(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);
+    }
+    // integrate positions
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      float tx = h * b[k].vx, ty = h * b[k].vy;
+      if (tx * tx + ty * ty > B2_MAX_TRANSLATION * B2_MAX_TRANSLATION) {
+        float ratio = B2_MAX_TRANSLATION / sqrtf(tx * tx + ty * ty);
+        b[k].vx = ratio * b[k].vx; b[k].vy = ratio * b[k].vy;
+      }
+      float rot = h * b[k].w;
+      if (rot * rot > B2_MAX_ROTATION * B2_MAX_ROTATION) { float ratio = B2_MAX_ROTATION / fabsf(rot); b[k].w *= ratio; }
+      b[k].cx = b[k].cx + h * b[k].vx; b[k].cy = b[k].cy + h * b[k].vy; b[k].a += h * b[k].w;
+    }
+    // position iterations with early exit
+    bool positionSolved = false;
+    for (int it = 0; it < 60; ++it) {
+      bool ok = true;
+#pragma unroll
+      for (int q = 3; q >= 0; --q) {
+        bool jo = joint_position(J[q], b[0], b[q + 1], S.anchor_x[q], S.anchor_y[q], lcx, lcy, mH, iH, mW, iW);
+        ok = ok && jo;
+      }
+      if (ok) { positionSolved = true; break; }
+    }
+    // sleep (b2Island::Solve tail).  Car.step re-wakes every body next step, so "asleep" reduces to:
+    // zero the velocities and restart the timers.
+    float minSleep = MCR_MAXFLT;
+    const float linTol2 = B2_LINEAR_SLEEP_TOL * B2_LINEAR_SLEEP_TOL, angTol2 = B2_ANGULAR_SLEEP_TOL * B2_ANGULAR_SLEEP_TOL;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      if (b[k].w * b[k].w > angTol2 || (b[k].vx * b[k].vx + b[k].vy * b[k].vy) > linTol2) { sleepT[k] = 0.0f; minSleep = 0.0f; }
+      else { sleepT[k] += h; minSleep = mcr_min(minSleep, sleepT[k]); }
+    }
+    if (minSleep >= B2_TIME_TO_SLEEP && positionSolved) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) { sleepT[k] = 0.0f; b[k].vx = 0.0f; b[k].vy = 0.0f; b[k].w = 0.0f; }
+    }
+  }
+
+  // ---- env bookkeeping (:433-443, :497-507) + TimeLimit, across the env's lane group
+  bool done = false, trunc = false, respawn = false;
+  double step_reward = 0.0, reward = 0.0, prev_reward = 0.0;
+  uint32_t tvc = 0, flags = 0;
+  if (run) { reward = p.card[CD_REWARD * BN + ci]; prev_reward = p.card[CD_PREV_REWARD * BN + ci]; tvc = p.caru[CU_TVC * BN + ci]; flags = p.caru[CU_FLAGS * BN + ci]; }
+  int T = 0;
+  if (env < p.B && es.active) T = ((const McrSlotHeader*)(p.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES))->T;
+  if (mode == 0) {
+    const bool has_action = p.actions != nullptr;
+    int d = 0;
+    if (run && has_action) {
+      reward -= 0.1;
+      step_reward = reward - prev_reward;
+      prev_reward = reward;
+      if ((int)tvc == T) d = 1;
+      // hull.position = xf.p
+      Xf xh = xf_of(v2(b[0].cx, b[0].cy), b[0].a, v2(lcx, lcy));
+      double px = (double)xh.p.x, py = (double)xh.p.y;
+      if (fabs(px) > MCR_PLAYFIELD || fabs(py) > MCR_PLAYFIELD) { d = 1; step_reward = -100; }
+    }
+    for (int o = 1; o < p.G; o <<= 1) d |= __shfl_xor(d, o);
+    done = d != 0;
+    if (run && has_action) {
+      int steps = es.steps + 1;
+      if (p.max_steps > 0 && steps >= p.max_steps) { trunc = !done; done = true; }
+    }
+    if (lane_ok && es.active) {
+      p.reward_out[ci] = step_reward;
+      if (agent == 0) { p.done_out[env] = done ? 1 : 0; if (p.trunc_out) p.trunc_out[env] = trunc ? 1 : 0; }
+    } else if (lane_ok) {
+      p.reward_out[ci] = 0.0;
+      if (agent == 0) { p.done_out[env] = 0; if (p.trunc_out) p.trunc_out[env] = 0; }
+    }
+    respawn = run && done && p.auto_reset && es.staged_ready;
+  }
+
+  // ---- env state update by the group leader
+  if (lane_ok && agent == 0 && es.active && (mode == 0 || es.resetting)) {
+    McrEnvState* E = &p.env[env];
+    if (mode == 0) {
+      if (respawn) {
+        E->slot = es.slot ^ 1; E->staged_ready = 0; E->consumed = es.consumed + 1; E->resetting = 1; E->just_reset = 1;
+        E->t = 0.0; E->steps = 0;
+        p.consumed_host[env] = es.consumed + 1;
+      } else {
+        E->t = es.t + 1.0 / MCR_FPS;
+        if (p.actions) E->steps = es.steps + 1;
+        E->just_reset = 0;
+        if (done && p.auto_reset) E->active = 0;      // no staged episode: freeze until mcr_reset
+      }
+    } else {
+      E->t = es.t + 1.0 / MCR_FPS;
+      E->resetting = 0;
+    }
+  }
+
+  if (!run) return;
+  if (respawn) {
+    // Car(world, angle, x, y): hull at the pose, wheels at UNROTATED offsets with the same angle
+    const McrSlotHeader* H = (const McrSlotHeader*)(p.slots + ((size_t)env * 2 + (es.slot ^ 1)) * MCR_SLOT_BYTES);
+    double sa = H->spawn[agent][0], sx = H->spawn[agent][1], sy = H->spawn[agent][2];
+    float fa = (float)sa;
+    Rot q = rot_of(fa);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      float px = (k == 0) ? (float)sx : (float)(sx + (k == 1 || k == 3 ? -55 : 55) * MCR_SIZE);
+      float py = (k == 0) ? (float)sy : (float)(sy + (k <= 2 ? 80 : -82) * MCR_SIZE);
+      Xf xf; xf.p = v2(px, py); xf.q = q;
+      V2 lc = (k == 0) ? v2(lcx, lcy) : v2(0.0f, 0.0f);
+      V2 c = xmul(xf, lc);
+      b[k].cx = c.x; b[k].cy = c.y; b[k].a = fa; b[k].vx = b[k].vy = b[k].w = 0.0f; sleepT[k] = 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { J[k].ix = J[k].iy = J[k].iz = J[k].im = 0.0f; J[k].limit = 0; omega[k] = 0; phase[k] = 0; }
+    gas[0] = gas[1] = 0; steer = 0; brake = 0; onroad = 0;
+    reward = 0; prev_reward = 0; tvc = 0; flags = 0;
+    p.caru[CU_ONROAD * BN + ci] = 0;
+    p.caru[CU_TVC * BN + ci] = 0;
+  }
+  // ---- write back
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    p.carf[(CF_CX + k) * BN + ci] = b[k].cx; p.carf[(CF_CY + k) * BN + ci] = b[k].cy; p.carf[(CF_A + k) * BN + ci] = b[k].a;
+    p.carf[(CF_VX + k) * BN + ci] = b[k].vx; p.carf[(CF_VY + k) * BN + ci] = b[k].vy; p.carf[(CF_W + k) * BN + ci] = b[k].w;
+    p.carf[(CF_SLEEP + k) * BN + ci] = sleepT[k];
+  }
+  uint32_t lim = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    p.carf[(CF_JIX + k) * BN + ci] = J[k].ix; p.carf[(CF_JIY + k) * BN + ci] = J[k].iy;
+    p.carf[(CF_JIZ + k) * BN + ci] = J[k].iz; p.carf[(CF_JM + k) * BN + ci] = J[k].im;
+    lim |= (uint32_t)J[k].limit << (2 * k);
+    p.card[(CD_OMEGA + k) * BN + ci] = omega[k]; p.card[(CD_PHASE + k) * BN + ci] = phase[k];
+  }
+  p.caru[CU_LIMIT * BN + ci] = lim;
+  p.card[(CD_GAS + 0) * BN + ci] = gas[0]; p.card[(CD_GAS + 1) * BN + ci] = gas[1];
+  p.card[CD_STEER * BN + ci] = steer; p.card[CD_BRAKE * BN + ci] = brake;
+  if (mode == 0) {
+    p.card[CD_REWARD * BN + ci] = reward; p.card[CD_PREV_REWARD * BN + ci] = prev_reward;
+    if (respawn) p.caru[CU_FLAGS * BN + ci] = 0;
+  }
+}
+
+// Explicit reset(): install the staged episode for masked envs and spawn the cars; the caller then
+// runs collide(pass 1) -> dynamics(mode 1) -> view to complete `return self.step(None)[0]` (:408).
+__global__ __launch_bounds__(64) void k_install(McrParams p) {
+  const int g = blockIdx.x * 64 + threadIdx.x;
+  const int env = g / p.G, agent = g % p.G;
+  if (env >= p.B || agent >= p.N) return;
+  if (p.reset_mask && !p.reset_mask[env]) return;
+  McrEnvState es = p.env[env];
+  if (!es.staged_ready) return;
+  const int ci = env * p.N + agent, BN = p.BN;
+  const McrShapes& S = *p.shapes;
+  const McrSlotHeader* H = (const McrSlotHeader*)(p.slots + ((size_t)env * 2 + (es.slot ^ 1)) * MCR_SLOT_BYTES);
+  double sa = H->spawn[agent][0], sx = H->spawn[agent][1], sy = H->spawn[agent][2];
+  float fa = (float)sa;
+  Rot q = rot_of(fa);
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    float px = (k == 0) ? (float)sx : (float)(sx + (k == 1 || k == 3 ? -55 : 55) * MCR_SIZE);
+    float py = (k == 0) ? (float)sy : (float)(sy + (k <= 2 ? 80 : -82) * MCR_SIZE);
+    Xf xf; xf.p = v2(px, py); xf.q = q;
+    V2 lc = (k == 0) ? v2(S.hull_lcx, S.hull_lcy) : v2(0.0f, 0.0f);
+    V2 c = xmul(xf, lc);
+    p.carf[(CF_CX + k) * BN + ci] = c.x; p.carf[(CF_CY + k) * BN + ci] = c.y; p.carf[(CF_A + k) * BN + ci] = fa;
+    p.carf[(CF_VX + k) * BN + ci] = 0.0f; p.carf[(CF_VY + k) * BN + ci] = 0.0f; p.carf[(CF_W + k) * BN + ci] = 0.0f;
+    p.carf[(CF_SLEEP + k) * BN + ci] = 0.0f;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    p.carf[(CF_JIX + k) * BN + ci] = 0.0f; p.carf[(CF_JIY + k) * BN + ci] = 0.0f; p.carf[(CF_JIZ + k) * BN + ci] = 0.0f; p.carf[(CF_JM + k) * BN + ci] = 0.0f;
+    p.card[(CD_OMEGA + k) * BN + ci] = 0.0; p.card[(CD_PHASE + k) * BN + ci] = 0.0;
+  }
+  p.card[(CD_GAS + 0) * BN + ci] = 0.0; p.card[(CD_GAS + 1) * BN + ci] = 0.0; p.card[CD_STEER * BN + ci] = 0.0; p.card[CD_BRAKE * BN + ci] = 0.0;
+  p.card[CD_REWARD * BN + ci] = 0.0; p.card[CD_PREV_REWARD * BN + ci] = 0.0;
+  p.caru[CU_LIMIT * BN + ci] = 0; p.caru[CU_ONROAD * BN + ci] = 0; p.caru[CU_TVC * BN + ci] = 0; p.caru[CU_FLAGS * BN + ci] = 0;
+  if (agent == 0) {
+    McrEnvState* E = &p.env[env];
+    E->slot = es.slot ^ 1; E->staged_ready = 0; E->consumed = es.consumed + 1; E->resetting = 1; E->just_reset = 1; E->active = 1;
+    E->t = 0.0; E->steps = 0;
+    p.consumed_host[env] = es.consumed + 1;
+  }
+}

@@ -1,0 +1,174 @@
+// mcr_common.h — constants, HBM layouts and small math shared by host code and gfx950 kernels.
+//
+// Numeric contract: physics state is IEEE binary32 exactly as Box2D keeps it,
+// Car.step arithmetic is binary64 exactly as CPython evaluates it; every translation unit is built with
+// -ffp-contract=off so that host and device round identically.  sinf/cosf are DEFINED by mcr_sincosf
+// below (f64 Cody-Waite reduction + fdlibm minimax kernels, rounded once to f32).
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MCR_HD __host__ __device__ __forceinline__
+#else
+#define MCR_HD inline
+#endif
+
+#define MCR_MAX_AGENTS 8
+#define MCR_TILE_CAP 512
+#define MCR_QUAD_CAP 768
+
+// ------------------------------------------------------------------ reference constants
+// multi_car_racing.py:43-78
+#define MCR_SCALE 6.0
+#define MCR_PLAYFIELD (2000 / 6.0)
+#define MCR_FPS 50
+#define MCR_ZOOM 2.7
+#define MCR_WINDOW_W 1000
+#define MCR_WINDOW_H 800
+// gym car_dynamics.py
+#define MCR_SIZE 0.02
+#define MCR_WHEEL_R 27
+#define MCR_WHEEL_W 14
+// Box2D b2Settings.h
+#define B2_PI 3.14159265359f
+#define B2_EPSILON 1.1920928955078125e-07f
+#define B2_LINEAR_SLOP 0.005f
+#define B2_ANGULAR_SLOP (2.0f / 180.0f * B2_PI)
+#define B2_POLYGON_RADIUS (2.0f * B2_LINEAR_SLOP)
+#define B2_MAX_LINEAR_CORRECTION 0.2f
+#define B2_MAX_ANGULAR_CORRECTION (8.0f / 180.0f * B2_PI)
+#define B2_MAX_TRANSLATION 2.0f
+#define B2_MAX_ROTATION (0.5f * B2_PI)
+#define B2_BAUMGARTE 0.2f
+#define B2_TIME_TO_SLEEP 0.5f
+#define B2_LINEAR_SLEEP_TOL 0.01f
+#define B2_ANGULAR_SLEEP_TOL (2.0f / 180.0f * B2_PI)
+#define MCR_MAXFLT 3.402823466e+38f
+
+// ------------------------------------------------------------------ episode slot (host blob == device image)
+// One env owns two slots (current / staged).  Arrays are capacity-strided so that a wave reading
+// consecutive tiles/quads issues fully coalesced 16-byte-per-lane loads.
+struct McrSlotHeader {
+  int32_t T, P, cw, pad0;
+  double spawn[MCR_MAX_AGENTS][3];   // (angle, x, y) per car id, as handed to Car(...)
+  int32_t pad1[12];
+};
+#define MCR_OFF_HDR 0
+#define MCR_OFF_TRACK_X 256                                   // f64 [TILE_CAP]
+#define MCR_OFF_TRACK_Y (MCR_OFF_TRACK_X + 8 * MCR_TILE_CAP)
+#define MCR_OFF_TRACK_B (MCR_OFF_TRACK_Y + 8 * MCR_TILE_CAP)
+#define MCR_OFF_TRACK_A (MCR_OFF_TRACK_B + 8 * MCR_TILE_CAP)  // f64 [TILE_CAP] alpha (facade attribute env.track only)
+#define MCR_OFF_QA (MCR_OFF_TRACK_A + 8 * MCR_TILE_CAP)       // float4 [QUAD_CAP]  x0 y0 x1 y1
+#define MCR_OFF_QB (MCR_OFF_QA + 16 * MCR_QUAD_CAP)           // float4 [QUAD_CAP]  x2 y2 x3 y3
+#define MCR_OFF_QMETA (MCR_OFF_QB + 16 * MCR_QUAD_CAP)        // u32    [QUAD_CAP]  (tile+1)<<8 | colour id
+#define MCR_OFF_TAABB (MCR_OFF_QMETA + 4 * MCR_QUAD_CAP)      // float4 [TILE_CAP]  lo.xy hi.xy
+#define MCR_OFF_TVA (MCR_OFF_TAABB + 16 * MCR_TILE_CAP)       // float4 [TILE_CAP]  hull v0 v1 (CCW)
+#define MCR_OFF_TVB (MCR_OFF_TVA + 16 * MCR_TILE_CAP)         // float4             v2 v3
+#define MCR_OFF_TNA (MCR_OFF_TVB + 16 * MCR_TILE_CAP)         // float4             n0 n1
+#define MCR_OFF_TNB (MCR_OFF_TNA + 16 * MCR_TILE_CAP)         // float4             n2 n3
+#define MCR_OFF_TCNT (MCR_OFF_TNB + 16 * MCR_TILE_CAP)        // u32    [TILE_CAP]  hull vertex count (3|4)
+#define MCR_SLOT_BYTES (MCR_OFF_TCNT + 4 * MCR_TILE_CAP)
+
+// quad colour ids (u8 RGB after the GL float->unorm8 conversion)
+enum { MCR_COL_ROAD0 = 0, MCR_COL_ROAD1 = 1, MCR_COL_ROAD2 = 2, MCR_COL_KERB_WHITE = 3, MCR_COL_KERB_RED = 4 };
+
+// ------------------------------------------------------------------ per-car SoA field indices
+// f32 fields  carf[field][B*N]
+enum {
+  CF_CX = 0,   // +body (0 hull, 1..4 wheels)
+  CF_CY = 5, CF_A = 10, CF_VX = 15, CF_VY = 20, CF_W = 25,
+  CF_JIX = 30, // +joint
+  CF_JIY = 34, CF_JIZ = 38, CF_JM = 42,
+  CF_SLEEP = 46,  // +body
+  CF_COUNT = 51
+};
+// f64 fields  card[field][B*N]
+enum {
+  CD_GAS = 0,    // +0,1 rear-left, rear-right (wheels 2,3)
+  CD_STEER = 2,  // front wheels share the target
+  CD_BRAKE = 3,
+  CD_OMEGA = 4,  // +wheel
+  CD_PHASE = 8,  // +wheel
+  CD_REWARD = 12, CD_PREV_REWARD = 13,
+  CD_COUNT = 14
+};
+// u32 fields  caru[field][B*N]
+enum {
+  CU_LIMIT = 0,       // 2 bits per joint
+  CU_ONROAD = 1,      // bits 0..3 current Collide, bits 4..7 previous Collide (what Car.step reads)
+  CU_TVC = 2,         // tile_visited_count
+  CU_FLAGS = 3,       // bit0 driving_backward, bit1 driving_on_grass
+  CU_COUNT = 4
+};
+// per-env state
+struct McrEnvState {
+  double t;                // self.t
+  int32_t steps;           // TimeLimit counter
+  int32_t slot;            // current episode slot (0/1); the other one is the staged slot
+  int32_t staged_ready;    // staged slot holds a fresh episode
+  int32_t consumed;        // staged episode was installed since the last poll
+  int32_t active;          // 0 until the first reset
+  int32_t resetting;       // episode installed; the action-less step of reset() (:408) is still pending
+  int32_t just_reset;      // the obs being produced is a first observation (a7 bookkeeping is skipped, :435)
+  int32_t pad[1];
+};
+
+// fixtures of one car in body-local coordinates (host builds them with its b2PolygonShape::Set
+// restatement; kernels receive a pointer)
+struct McrPoly { int32_t n; int32_t pad; float vx[8], vy[8], nx[8], ny[8]; };
+struct McrShapes {
+  McrPoly hull[4];
+  McrPoly wheel;
+  float hull_invMass, hull_invI, hull_lcx, hull_lcy;
+  float wheel_invMass, wheel_invI;
+  float anchor_x[4], anchor_y[4];     // revolute joint localAnchorA
+  float pad[2];
+};
+
+// ------------------------------------------------------------------ math
+struct V2 { float x, y; };
+MCR_HD V2 v2(float x, float y) { V2 r; r.x = x; r.y = y; return r; }
+MCR_HD V2 operator+(V2 a, V2 b) { return v2(a.x + b.x, a.y + b.y); }
+MCR_HD V2 operator-(V2 a, V2 b) { return v2(a.x - b.x, a.y - b.y); }
+MCR_HD V2 operator-(V2 a) { return v2(-a.x, -a.y); }
+MCR_HD V2 operator*(float s, V2 a) { return v2(s * a.x, s * a.y); }
+MCR_HD float dot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
+MCR_HD float cross(V2 a, V2 b) { return a.x * b.y - a.y * b.x; }
+MCR_HD V2 cross(V2 a, float s) { return v2(s * a.y, -s * a.x); }
+MCR_HD V2 cross(float s, V2 a) { return v2(-s * a.y, s * a.x); }
+MCR_HD float mcr_min(float a, float b) { return a < b ? a : b; }   // std::min semantics
+MCR_HD float mcr_max(float a, float b) { return a < b ? b : a; }   // std::max semantics
+MCR_HD float mcr_clamp(float a, float lo, float hi) { return mcr_max(lo, mcr_min(a, hi)); }
+MCR_HD float length(V2 a) { return sqrtf(a.x * a.x + a.y * a.y); }
+
+// sinf/cosf spec of the build: bit-identical on host (x86-64) and gfx950.
+MCR_HD void mcr_sincosf(float a, float* s, float* c) {
+  double x = (double)a;
+  double fn = rint(x * 6.36619772367581382433e-01);
+  int n = (int)fn;
+  double r = (x - fn * 1.57079632673412561417e+00) - fn * 6.07710050650619224932e-11;
+  double z = r * r;
+  double ps = r + r * z * (-1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+              z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)))));
+  double pc = 1.0 - 0.5 * z + z * z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+              z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  double ss, cc;
+  switch (n & 3) {
+    case 0: ss = ps; cc = pc; break;
+    case 1: ss = pc; cc = -ps; break;
+    case 2: ss = -ps; cc = -pc; break;
+    default: ss = -pc; cc = ps; break;
+  }
+  *s = (float)ss; *c = (float)cc;
+}
+struct Rot { float s, c; };
+MCR_HD Rot rot_of(float a) { Rot q; mcr_sincosf(a, &q.s, &q.c); return q; }
+MCR_HD V2 rmul(Rot q, V2 v) { return v2(q.c * v.x - q.s * v.y, q.s * v.x + q.c * v.y); }
+MCR_HD V2 rmulT(Rot q, V2 v) { return v2(q.c * v.x + q.s * v.y, -q.s * v.x + q.c * v.y); }
+struct Xf { V2 p; Rot q; };
+MCR_HD V2 xmul(const Xf& t, V2 v) { return v2((t.q.c * v.x - t.q.s * v.y) + t.p.x, (t.q.s * v.x + t.q.c * v.y) + t.p.y); }
+MCR_HD V2 xmulT(const Xf& t, V2 v) { float px = v.x - t.p.x, py = v.y - t.p.y; return v2(t.q.c * px + t.q.s * py, -t.q.s * px + t.q.c * py); }
+// b2Body::SynchronizeTransform from (sweep.c, sweep.a, localCenter)
+MCR_HD Xf xf_of(V2 c, float a, V2 lc) { Xf t; t.q = rot_of(a); t.p = c - rmul(t.q, lc); return t; }

@@ -1,0 +1,30 @@
+// mcr_kernels.h — kernel parameter block shared by the three step kernels (gfx950 only).
+#pragma once
+#include "mcr_common.h"
+
+struct McrParams {
+  int32_t B, N, G;              // envs, agents, lanes per env in the dynamics kernel (pow2 >= N)
+  int32_t BN;                   // B*N: stride of every per-car SoA field
+  float* carf;                  // [CF_COUNT][BN]
+  double* card;                 // [CD_COUNT][BN]
+  uint32_t* caru;               // [CU_COUNT][BN]
+  McrEnvState* env;             // [B]
+  uint8_t* slots;               // [B][2][MCR_SLOT_BYTES]
+  uint32_t* tile_touch;         // [B][TILE_CAP]  bit (car*4+wheel): wheel currently in contact with the tile
+  uint16_t* tile_flags;         // [B][TILE_CAP]  bits 0..7 road_visited[car], bit 8 recoloured
+  uint32_t* cc_store;           // [B][...] car<->car manifold store (warm starting)
+  const McrShapes* shapes;
+  int32_t* consumed_host;       // [B] mapped host memory: episode counter of the last install
+  // step I/O
+  const float* actions;         // [B,N,3] or null
+  uint8_t* obs;                 // [B,N,96,96,3] or null
+  double* reward_out;           // [B,N]
+  uint8_t* done_out;            // [B]
+  uint8_t* trunc_out;           // [B] or null
+  const uint8_t* reset_mask;    // [B] or null (k_install)
+  int32_t auto_reset, max_steps, car_contacts, backwards_flag, use_ego_color;
+  double h_ratio;
+};
+
+#define MCR_CC_MAX 24           // touching car<->car fixture pairs kept per env (warm start)
+#define MCR_CC_WORDS 20         // u32 words per stored manifold

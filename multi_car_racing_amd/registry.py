@@ -1,0 +1,66 @@
+"""`make("MultiCarRacing-v0", **kwargs)` — the registration of gym_multi_car_racing/__init__.py:5-10
+(id, max_episode_steps=1000, reward_threshold=900).  If a real `gym` is importable the env is registered
+there and `gym.make` is used; otherwise a minimal registry + TimeLimit (gym 0.17.2 semantics) is used."""
+from .env import MultiCarRacing
+
+ENV_ID = "MultiCarRacing-v0"
+MAX_EPISODE_STEPS = 1000
+REWARD_THRESHOLD = 900
+
+
+class TimeLimit:
+    """gym.wrappers.TimeLimit (0.17.2): after max_episode_steps steps done=True and
+    info['TimeLimit.truncated'] = not done_before; reset() zeroes the counter."""
+
+    def __init__(self, env, max_episode_steps):
+        self.env = env
+        self._max_episode_steps = max_episode_steps
+        self._elapsed_steps = None
+
+    def __getattr__(self, name):
+        return getattr(self.env, name)
+
+    def step(self, action):
+        assert self._elapsed_steps is not None, "Cannot call env.step() before calling reset()"
+        observation, reward, done, info = self.env.step(action)
+        self._elapsed_steps += 1
+        if self._elapsed_steps >= self._max_episode_steps:
+            info["TimeLimit.truncated"] = not done
+            done = True
+        return observation, reward, done, info
+
+    def reset(self, **kwargs):
+        self._elapsed_steps = 0
+        return self.env.reset(**kwargs)
+
+    @property
+    def unwrapped(self):
+        return self.env
+
+
+_registered_with_gym = False
+
+
+def register():
+    global _registered_with_gym
+    try:
+        from gym.envs.registration import register as gym_register
+    except Exception:
+        return False
+    if not _registered_with_gym:
+        try:
+            gym_register(id=ENV_ID, entry_point="multi_car_racing_amd:MultiCarRacing",
+                         max_episode_steps=MAX_EPISODE_STEPS, reward_threshold=REWARD_THRESHOLD)
+        except Exception:
+            pass
+        _registered_with_gym = True
+    return True
+
+
+def make(env_id=ENV_ID, **kwargs):
+    if env_id != ENV_ID:
+        raise ValueError(f"unknown environment id {env_id!r}; this package provides {ENV_ID!r}")
+    if register():
+        import gym
+        return gym.make(env_id, **kwargs)
+    return TimeLimit(MultiCarRacing(**kwargs), MAX_EPISODE_STEPS)

@@ -1,0 +1,229 @@
+"""Batched MultiCarRacing-v0 on one MI355X: B independent envs advanced by the HIP kernels behind
+include/mcr.h.  torch is plumbing only (device memory, streams); every step is the C-ABI `mcr_step`.
+
+Semantics per env follow the reference's `reset()`/`step()` (multi_car_racing.py:340-509) with the
+TimeLimit(1000) of gym_multi_car_racing/__init__.py:8.  With `auto_reset=True` a finished env is re-spawned
+on the device inside the same `step` call (its `obs` row is the first observation of the next episode,
+its `done` row is 1) — the convention of baselines-style VecEnvs.
+
+Determinism: env with global index g uses two numpy-compatible MT19937 streams,
+  track stream  RandomState(seed + g)                (the reference's `env.np_random`)
+  draw stream   RandomState((seed + g + 2**31) % 2**32)   (stands in for the reference's *global* np.random:
+                direction choice then car order, multi_car_racing.py:351-357)
+so results do not depend on B, on the GPU count, or on scheduling.
+"""
+import ctypes
+import os
+import queue
+import threading
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_DIRECTION_MODE = {"CCW": 0, "CW": 1}
+
+
+class VecMultiCarRacing:
+    def __init__(self, num_envs, num_agents=2, device=None, seed=0, env_offset=0, direction="CCW",
+                 use_random_direction=True, backwards_flag=True, h_ratio=0.25, use_ego_color=False,
+                 obs=True, auto_reset=True, max_episode_steps=1000, car_contacts=True,
+                 gen_threads=None, async_refill=True):
+        if not torch.cuda.is_available():
+            raise _lib.McrError("VecMultiCarRacing needs a HIP device: the step path has no CPU fallback")
+        self.L = _lib.load()
+        self.B, self.N = int(num_envs), int(num_agents)
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        torch.cuda.set_device(self.device)
+        self.obs_enabled = bool(obs)
+        self.auto_reset = bool(auto_reset)
+        self.direction_mode = 2 if use_random_direction else _DIRECTION_MODE[direction]
+        self.gen_threads = gen_threads or max(1, (os.cpu_count() or 2) - 1)
+        cfg = _lib.Config(self.B, self.N, self.device.index or 0, int(self.obs_enabled), int(self.auto_reset),
+                          int(backwards_flag), int(use_ego_color), int(car_contacts), int(max_episode_steps), 0,
+                          float(h_ratio))
+        self.h = ctypes.c_void_p()
+        _lib.check(self.L.mcr_create(ctypes.byref(cfg), ctypes.byref(self.h)), "mcr_create")
+        # persistent outputs (overwritten by every step)
+        self.obs = torch.zeros((self.B, self.N, 96, 96, 3), dtype=torch.uint8, device=self.device) if self.obs_enabled else None
+        self.reward = torch.zeros((self.B, self.N), dtype=torch.float64, device=self.device)
+        self.done = torch.zeros((self.B,), dtype=torch.uint8, device=self.device)
+        self.truncated = torch.zeros((self.B,), dtype=torch.uint8, device=self.device)
+        # RNG streams
+        self.mt_track = np.zeros((self.B, _lib.MT_WORDS), np.uint32)
+        self.mt_draw = np.zeros((self.B, _lib.MT_WORDS), np.uint32)
+        for e in range(self.B):
+            g = (int(seed) + int(env_offset) + e) % 2 ** 32
+            self.L.mcr_mt_seed(_lib.ptr(self.mt_track[e]), ctypes.c_uint32(g))
+            self.L.mcr_mt_seed(_lib.ptr(self.mt_draw[e]), ctypes.c_uint32((g + 2 ** 31) % 2 ** 32))
+        self.slot_bytes = _lib.episode_bytes()
+        self._blobs = torch.empty((self.B, self.slot_bytes), dtype=torch.uint8, pin_memory=True)
+        self._blobs_np = self._blobs.numpy()
+        self.episode_info = np.zeros((self.B, 12), np.int32)      # T, P, retries, cw, car_order[8] of the newest generated episode
+        self._ids = np.zeros(self.B, np.int32)
+        self.episodes_generated = 0
+        self._copy_stream = torch.cuda.Stream(device=self.device)
+        self._async = bool(async_refill)
+        self._q = None
+        self._worker = None
+        self._closed = False
+        self._has_reset = False
+
+    # ------------------------------------------------------------------ episode generation / staging
+    def _generate(self, ids):
+        """Fill self._blobs rows `ids` with each env's next episode (advances the env's RNG streams)."""
+        ids = np.ascontiguousarray(ids, np.int32)
+        n = len(ids)
+        if n == 0:
+            return
+        mt_t = np.ascontiguousarray(self.mt_track[ids]); mt_d = np.ascontiguousarray(self.mt_draw[ids])
+        blobs = np.empty((n, self.slot_bytes), np.uint8) if n != self.B else self._blobs_np
+        info = np.zeros((n, 12), np.int32)
+        _lib.check(self.L.mcr_episodes_generate(_lib.ptr(mt_t), _lib.ptr(mt_d), n, self.N, self.direction_mode,
+                                                _lib.ptr(blobs), _lib.ptr(info), min(self.gen_threads, n)), "mcr_episodes_generate")
+        self.mt_track[ids] = mt_t; self.mt_draw[ids] = mt_d
+        self.episode_info[ids] = info
+        if n != self.B:
+            self._blobs_np[ids] = blobs
+        self.episodes_generated += n
+
+    def _stage(self, ids, stream):
+        ids = np.ascontiguousarray(ids, np.int32)
+        if len(ids) == 0:
+            return
+        rows = self._blobs_np if len(ids) == self.B and np.array_equal(ids, np.arange(self.B)) else None
+        if rows is not None:
+            _lib.check(self.L.mcr_stage_episodes(self.h, _lib.ptr(ids), len(ids), _lib.ptr(rows), ctypes.c_void_p(stream.cuda_stream)), "mcr_stage_episodes")
+        else:
+            for e in ids:     # rows of the pinned pool are not contiguous for a subset: one call per env
+                one = np.array([e], np.int32)
+                _lib.check(self.L.mcr_stage_episodes(self.h, _lib.ptr(one), 1, _lib.ptr(self._blobs_np[e]), ctypes.c_void_p(stream.cuda_stream)), "mcr_stage_episodes")
+
+    def _refill(self, ids):
+        self._generate(ids)
+        self._stage(ids, self._copy_stream)
+        self._copy_stream.synchronize()      # blobs may be regenerated as soon as this returns
+
+    def _worker_main(self):
+        torch.cuda.set_device(self.device)
+        while True:
+            ids = self._q.get()
+            if ids is None:
+                return
+            self._refill(ids)
+            self._q.task_done()
+
+    def _poll_and_refill(self):
+        n = self.L.mcr_poll_consumed(self.h, _lib.ptr(self._ids), self.B, None)
+        if n <= 0:
+            return 0
+        ids = self._ids[:n].copy()
+        if self._async:
+            if self._worker is None:
+                self._q = queue.Queue()
+                self._worker = threading.Thread(target=self._worker_main, daemon=True)
+                self._worker.start()
+            self._q.put(ids)
+        else:
+            self._refill(ids)
+        return n
+
+    def wait_refills(self):
+        if self._q is not None:
+            self._q.join()
+
+    # ------------------------------------------------------------------ API
+    def reset(self):
+        """Reset every env; returns obs [B,N,96,96,3] uint8 (device tensor, overwritten by later steps)."""
+        st = torch.cuda.current_stream(self.device)
+        self.wait_refills()
+        if not self._has_reset:
+            self._generate(np.arange(self.B, dtype=np.int32))
+            self._stage(np.arange(self.B, dtype=np.int32), st)
+        else:
+            # a staged episode already waits on the device for every env that consumed one; envs whose staged
+            # slot is still full simply install it
+            pass
+        _lib.check(self.L.mcr_reset(self.h, None, ctypes.c_void_p(self.obs.data_ptr()) if self.obs_enabled else None,
+                                    ctypes.c_void_p(st.cuda_stream)), "mcr_reset")
+        st.synchronize()
+        self._has_reset = True
+        self._poll_and_refill()
+        return self.obs
+
+    def step(self, actions):
+        """actions: float32 device tensor [B,N,3] (steer, gas, brake) or None. Returns (obs, reward, done, info)."""
+        st = torch.cuda.current_stream(self.device)
+        a_ptr = None
+        if actions is not None:
+            if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self.device:
+                actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+            if actions.numel() != self.B * self.N * 3:
+                raise ValueError(f"actions must have {self.B * self.N * 3} elements, got {actions.numel()}")
+            a_ptr = ctypes.c_void_p(actions.data_ptr())
+        _lib.check(self.L.mcr_step(self.h, a_ptr, ctypes.c_void_p(self.obs.data_ptr()) if self.obs_enabled else None,
+                                   ctypes.c_void_p(self.reward.data_ptr()), ctypes.c_void_p(self.done.data_ptr()),
+                                   ctypes.c_void_p(self.truncated.data_ptr()), ctypes.c_void_p(st.cuda_stream)), "mcr_step")
+        if self.auto_reset:
+            self._poll_and_refill()
+        return self.obs, self.reward, self.done, {"TimeLimit.truncated": self.truncated}
+
+    # ------------------------------------------------------------------ introspection (synchronous; tests / debugging)
+    def get_state(self):
+        B, N = self.B, self.N
+        bodies = np.zeros((B, N, 5, 6), np.float32); joints = np.zeros((B, N, 4, 4), np.float32)
+        wheels = np.zeros((B, N, 4, 5), np.float64); limit = np.zeros((B, N, 4), np.int32)
+        on_road = np.zeros((B, N, 4), np.uint8); sleep = np.zeros((B, N, 5), np.float32)
+        _lib.check(self.L.mcr_get_state(self.h, _lib.ptr(bodies), _lib.ptr(joints), _lib.ptr(wheels), _lib.ptr(limit),
+                                        _lib.ptr(on_road), _lib.ptr(sleep)), "mcr_get_state")
+        return dict(bodies=bodies, joints=joints, wheels=wheels, limit=limit, on_road=on_road, sleep=sleep)
+
+    def set_bodies(self, bodies):
+        b = np.ascontiguousarray(bodies, np.float32)
+        assert b.shape == (self.B, self.N, 5, 6)
+        _lib.check(self.L.mcr_set_bodies(self.h, _lib.ptr(b)), "mcr_set_bodies")
+
+    def get_env_state(self):
+        B, N = self.B, self.N
+        reward = np.zeros((B, N)); tvc = np.zeros((B, N), np.int32)
+        bw = np.zeros((B, N), np.uint8); og = np.zeros((B, N), np.uint8); t = np.zeros(B)
+        flags = np.zeros((B, _lib.TILE_CAP), np.uint16); nt = np.zeros(B, np.int32)
+        _lib.check(self.L.mcr_get_env_state(self.h, _lib.ptr(reward), _lib.ptr(tvc), _lib.ptr(bw), _lib.ptr(og), _lib.ptr(t),
+                                            _lib.ptr(flags), _lib.ptr(nt)), "mcr_get_env_state")
+        return dict(reward=reward, tile_visited_count=tvc, driving_backward=bw, driving_on_grass=og, t=t,
+                    tile_flags=flags, num_tiles=nt)
+
+    def positions(self):
+        pos = np.zeros((self.B, self.N, 2), np.float32)
+        _lib.check(self.L.mcr_get_positions(self.h, _lib.ptr(pos)), "mcr_get_positions")
+        return pos
+
+    def current_episode(self, e):
+        """Host copy of the NEWEST generated episode of env e (the staged one once the env has reset)."""
+        return _lib.unpack_episode(np.ascontiguousarray(self._blobs_np[e]))
+
+    def timing(self, enable):
+        _lib.check(self.L.mcr_timing_enable(self.h, int(enable)))
+
+    def timing_read(self):
+        ms = np.zeros(3); n = np.zeros(3, np.int64)
+        _lib.check(self.L.mcr_timing_read(self.h, _lib.ptr(ms), _lib.ptr(n)))
+        return ms, n
+
+    def close(self):
+        if self._closed:
+            return
+        self._closed = True
+        if self._worker is not None:
+            self._q.put(None)
+            self._worker.join()
+        if self.h:
+            self.L.mcr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
