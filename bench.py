@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the batched MultiCarRacing-v0 step on N MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path (collide -> dynamics -> view raster, incl. device-side auto-reset and
+host-side episode generation for finished envs) over one batch of 4096 envs per GPU with synthetic random
+actions already resident in HBM.  Workload at N=1 = BASELINE.json configs[1]: num_agents=2, batch=4096,
+96x96 RGB obs.  Multi-GPU: independent env slices (weak scaling), one scalar all-reduce at the end.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (view/raster kernel vs HBM) and `cpu_baseline`
+(the oracle = CPU restatement, timed on this host's cores on a bounded sample; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def cpu_baseline(num_agents, obs, n_envs=None, steps=100):
+    """Oracle (C++ CPU restatement of the same step) on a bounded sample: n_envs envs x steps steps with the
+    same action distribution, one thread per core.  Returns the cpu_baseline JSON object."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    from tests.util import oracle_episode
+    cores = os.cpu_count() or 1
+    n_envs = n_envs or max(cores, 8)
+    envs = []
+    for e in range(n_envs):
+        o = O.OracleEnv(num_agents)
+        o.reset(oracle_episode(O, num_agents, 12345, e, use_random_direction=True), render=obs)
+        envs.append(o)
+    rng = np.random.RandomState(1)
+    acts = np.stack([rng.uniform(-1, 1, (steps, n_envs, num_agents)), rng.uniform(0, 1, (steps, n_envs, num_agents)),
+                     rng.uniform(0, 1, (steps, n_envs, num_agents))], -1).astype(np.float32)
+
+    def run(e):
+        o = envs[e]
+        for k in range(steps):
+            o.step(acts[k, e], render=obs)       # ctypes releases the GIL: threads scale across cores
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(run, range(n_envs)))
+    dt = time.perf_counter() - t0
+    for o in envs:
+        o.close()
+    return {"value": n_envs * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n_envs} envs x {steps} steps, num_agents={num_agents}, obs={'96x96x3' if obs else 'none'}, "
+                      f"oracle/mcr_oracle.cpp (CPU restatement; the reference's Box2D+pyglet path is not installable here), "
+                      f"{dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--agents", type=int, default=2)
+    ap.add_argument("--obs", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event time all three kernels (adds overhead)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from multi_car_racing_amd.sharded import ShardedVecEnv, reduce_metrics
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    B, N, K, W = args.envs, args.agents, args.steps, args.warmup
+    env = ShardedVecEnv(B * world, N, seed=0, rank=rank, world_size=world, device=dev, obs=bool(args.obs),
+                        auto_reset=True, use_random_direction=True)
+    env.reset()
+    # synthetic actions resident in HBM: a pool of i.i.d. (steer~U(-1,1), gas~U(0,1), brake~U(0,1)) batches
+    g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
+    pool = torch.rand((64, B, N, 3), device=dev, generator=g)
+    pool[..., 0] = pool[..., 0] * 2 - 1
+    for k in range(W):
+        env.step(pool[k % 64])
+    env.wait_refills()
+    env.timing(7 if args.time_all_kernels else 4)
+    gen0 = env.env.episodes_generated
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(K):
+        env.step(pool[(W + k) % 64])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms, nl = env.timing_read()
+    env.timing(0)
+    env.wait_refills()
+    episodes = env.env.episodes_generated - gen0
+    m = reduce_metrics(B * K, elapsed, episodes=episodes)
+
+    # roofline of the dominant kernel (view raster): algorithmic bytes per env-step:
+    #   N*27648 (obs write) + 36*P (road quads read once per env) + 76*N (car transforms+phases) + 48*N (camera+HUD)
+    P_mean = float(env.env.episode_info[:, 1].mean())
+    bytes_per_env_step = N * 27648 + 36 * P_mean + 124 * N
+    roofline = None
+    if args.obs and nl[2] > 0:
+        avg_ms = ms[2] / nl[2]
+        achieved = bytes_per_env_step * B / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "view_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "k_view", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                    "frac": achieved / 8000.0, "traffic": traffic, "avg_launch_ms": avg_ms, "launches": int(nl[2]),
+                    "algorithmic_bytes_per_launch": bytes_per_env_step * B}
+    if rank == 0:
+        out = {
+            "metric": "env-steps/sec (num_agents=%d, 96x96 RGB obs) at batch=%d; %d GPU" % (N, B, world),
+            "value": m["env_steps"] / m["elapsed_s"], "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": m["elapsed_s"] / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 rigid-body state / f64 tyre model / u8 pixels", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: num_agents=%d, batch=%d envs/GPU, %s, random-action rollout, "
+                                   "TimeLimit 1000 auto-reset incl. host track generation" % (N, B, "96x96 RGB obs" if args.obs else "obs=none"),
+                       "global_batch": B * world, "parallelism": "env-sharded dp%d (no data-path collective)" % world,
+                       "episodes_reset_in_timed_region": m["episodes"]},
+            "roofline": roofline,
+        }
+        if args.time_all_kernels:
+            out["kernel_ms"] = {"collide": ms[0] / max(nl[0], 1), "dynamics": ms[1] / max(nl[1], 1), "view": ms[2] / max(nl[2], 1)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N, bool(args.obs))
+        print(json.dumps(out))
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -119,10 +119,10 @@ void mcr_mass_props(float* out6);
 void mcr_sincos_host(float a, float* s, float* c);
 int mcr_sincos_device(mcr_env* h, const float* d_in, float* d_sin, float* d_cos, int n, void* stream);
 
-/* ---- instrumentation for bench.py: HIP-event timing of the kernels enqueued by mcr_step.
- * enable=1 records events around every kernel on the launch stream; mcr_timing_read drains
- * accumulated milliseconds + launch counts per kernel id (0 collide, 1 dynamics, 2 view). */
-int mcr_timing_enable(mcr_env* h, int enable);
+/* ---- instrumentation for bench.py: HIP-event timing of the kernels enqueued by mcr_step, recorded on the
+ * launch stream.  `mask` bit k enables kernel id k (0 collide, 1 dynamics, 2 view; 7 = all, 0 = off).
+ * mcr_timing_read synchronises the device and drains accumulated milliseconds + launch counts. */
+int mcr_timing_enable(mcr_env* h, int mask);
 int mcr_timing_read(mcr_env* h, double* ms_out /*[3]*/, int64_t* launches_out /*[3]*/);
 
 #ifdef __cplusplus

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(64) void k_collide(McrParams p, int pass) {
         if (bb.x > cbox[c][2] || bb.z < cbox[c][0] || bb.y > cbox[c][3] || bb.w < cbox[c][1]) continue;
         if (!loaded) {
           float4 va = TVA[t], vb = TVB[t], na = TNA[t], nb = TNB[t];
-          TP.n = (int)TCNT[t];
+          TP.n = (int)(TCNT[t] & 0xffu);
           TP.vx[0] = va.x; TP.vy[0] = va.y; TP.vx[1] = va.z; TP.vy[1] = va.w; TP.vx[2] = vb.x; TP.vy[2] = vb.y; TP.vx[3] = vb.z; TP.vy[3] = vb.w;
           TP.nx[0] = na.x; TP.ny[0] = na.y; TP.nx[1] = na.z; TP.ny[1] = na.w; TP.nx[2] = nb.x; TP.ny[2] = nb.y; TP.nx[3] = nb.z; TP.ny[3] = nb.w;
           loaded = true;

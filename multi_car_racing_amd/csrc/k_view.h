@@ -292,21 +292,37 @@ __global__ __launch_bounds__(VIEW_THREADS) void k_view(McrParams p, int flags_mo
       if (d < bd) { bd = d; bi = t; }
     }
     red_d[tid] = bd; red_i[tid] = bi;
-    // strict-interior point-in-quad over all road_poly (shapely `within`)
-    const float4* QA = (const float4*)(slot + MCR_OFF_QA); const float4* QB = (const float4*)(slot + MCR_OFF_QB);
+    // strict-interior point-in-quad over all road_poly (shapely `within`), on the f64 polygons the reference
+    // hands to shapely: tile quad (:313-317) and kerb quad (:329-333) rebuilt from the host's f64 cos/sin(beta)
+    const double* TC = (const double*)(slot + MCR_OFF_TRACK_C); const double* TS = (const double*)(slot + MCR_OFF_TRACK_S);
+    const uint32_t* TCNT = (const uint32_t*)(slot + MCR_OFF_TCNT);
+    const double TW = 40 / MCR_SCALE, TBW = 8 / MCR_SCALE;
     bool inside = false;
-    for (int q = tid; q < P; q += VIEW_THREADS) {
-      const float4 a = QA[q], b = QB[q];
-      const double X[4] = {a.x, a.z, b.x, b.z}, Y[4] = {a.y, a.w, b.y, b.w};
-      bool pos = true, neg = true;
+    for (int t = tid; t < T; t += VIEW_THREADS) {
+      const int u = t == 0 ? T - 1 : t - 1;
+      const double x1 = TX[t], y1 = TY[t], c1 = TC[t], s1 = TS[t], x2 = TX[u], y2 = TY[u], c2 = TC[u], s2 = TS[u];
+      const int nq = (TCNT[t] & 0x100u) ? 2 : 1;
+      for (int k = 0; k < nq; ++k) {
+        double X[4], Y[4];
+        if (k == 0) {
+          X[0] = x1 - TW * c1; Y[0] = y1 - TW * s1; X[1] = x1 + TW * c1; Y[1] = y1 + TW * s1;
+          X[2] = x2 + TW * c2; Y[2] = y2 + TW * s2; X[3] = x2 - TW * c2; Y[3] = y2 - TW * s2;
+        } else {
+          const double side = dyn::np_sign(TB[u] - TB[t]);
+          const double w0 = side * TW, w1 = side * (TW + TBW);
+          X[0] = x1 + w0 * c1; Y[0] = y1 + w0 * s1; X[1] = x1 + w1 * c1; Y[1] = y1 + w1 * s1;
+          X[2] = x2 + w1 * c2; Y[2] = y2 + w1 * s2; X[3] = x2 + w0 * c2; Y[3] = y2 + w0 * s2;
+        }
+        bool pos = true, neg = true;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int j = (i + 1) & 3;
-        const double cr = (X[j] - X[i]) * (py - Y[i]) - (Y[j] - Y[i]) * (px - X[i]);
-        if (!(cr > 0)) pos = false;
-        if (!(cr < 0)) neg = false;
+        for (int i = 0; i < 4; ++i) {
+          const int j = (i + 1) & 3;
+          const double cr = (X[j] - X[i]) * (py - Y[i]) - (Y[j] - Y[i]) * (px - X[i]);
+          if (!(cr > 0)) pos = false;
+          if (!(cr < 0)) neg = false;
+        }
+        inside = inside || pos || neg;
       }
-      inside = inside || pos || neg;
     }
     if (inside) atomicOr(&any_inside, 1);
     __syncthreads();

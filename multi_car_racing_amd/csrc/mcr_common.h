@@ -60,7 +60,9 @@ struct McrSlotHeader {
 #define MCR_OFF_TRACK_Y (MCR_OFF_TRACK_X + 8 * MCR_TILE_CAP)
 #define MCR_OFF_TRACK_B (MCR_OFF_TRACK_Y + 8 * MCR_TILE_CAP)
 #define MCR_OFF_TRACK_A (MCR_OFF_TRACK_B + 8 * MCR_TILE_CAP)  // f64 [TILE_CAP] alpha (facade attribute env.track only)
-#define MCR_OFF_QA (MCR_OFF_TRACK_A + 8 * MCR_TILE_CAP)       // float4 [QUAD_CAP]  x0 y0 x1 y1
+#define MCR_OFF_TRACK_C (MCR_OFF_TRACK_A + 8 * MCR_TILE_CAP)  // f64 [TILE_CAP] cos(beta) as libm computed it on the host
+#define MCR_OFF_TRACK_S (MCR_OFF_TRACK_C + 8 * MCR_TILE_CAP)  // f64 [TILE_CAP] sin(beta)  (on-grass test in f64, :470-472)
+#define MCR_OFF_QA (MCR_OFF_TRACK_S + 8 * MCR_TILE_CAP)       // float4 [QUAD_CAP]  x0 y0 x1 y1
 #define MCR_OFF_QB (MCR_OFF_QA + 16 * MCR_QUAD_CAP)           // float4 [QUAD_CAP]  x2 y2 x3 y3
 #define MCR_OFF_QMETA (MCR_OFF_QB + 16 * MCR_QUAD_CAP)        // u32    [QUAD_CAP]  (tile+1)<<8 | colour id
 #define MCR_OFF_TAABB (MCR_OFF_QMETA + 4 * MCR_QUAD_CAP)      // float4 [TILE_CAP]  lo.xy hi.xy
@@ -68,7 +70,7 @@ struct McrSlotHeader {
 #define MCR_OFF_TVB (MCR_OFF_TVA + 16 * MCR_TILE_CAP)         // float4             v2 v3
 #define MCR_OFF_TNA (MCR_OFF_TVB + 16 * MCR_TILE_CAP)         // float4             n0 n1
 #define MCR_OFF_TNB (MCR_OFF_TNA + 16 * MCR_TILE_CAP)         // float4             n2 n3
-#define MCR_OFF_TCNT (MCR_OFF_TNB + 16 * MCR_TILE_CAP)        // u32    [TILE_CAP]  hull vertex count (3|4)
+#define MCR_OFF_TCNT (MCR_OFF_TNB + 16 * MCR_TILE_CAP)        // u32    [TILE_CAP]  hull vertex count (3|4) | kerb<<8
 #define MCR_SLOT_BYTES (MCR_OFF_TCNT + 4 * MCR_TILE_CAP)
 
 // quad colour ids (u8 RGB after the GL float->unorm8 conversion)

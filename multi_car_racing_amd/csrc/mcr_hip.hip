@@ -35,7 +35,7 @@ struct mcr_env {
   size_t slab_bytes;
   int32_t* consumed_host;     // mapped host memory
   int32_t* consumed_seen;     // host copy of the last polled counters
-  bool timing;
+  int timing;                 // bit mask of kernel ids to time with HIP events
   std::vector<TimedLaunch> pending;
   std::vector<hipEvent_t> free_events;
   double t_ms[3]; int64_t t_n[3];
@@ -49,7 +49,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   if (cfg->num_envs < 1 || cfg->num_agents < 1 || cfg->num_agents > MCR_MAX_AGENTS) { g_err = "num_envs/num_agents out of range"; return MCR_ERR_ARG; }
   HIPCHK(hipSetDevice(cfg->device));
   mcr_env* h = new mcr_env();
-  h->cfg = *cfg; h->timing = false; h->any_reset = false;
+  h->cfg = *cfg; h->timing = 0; h->any_reset = false;
   for (int i = 0; i < 3; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
   const int B = cfg->num_envs, N = cfg->num_agents;
   int G = 1; while (G < N) G <<= 1;
@@ -128,7 +128,7 @@ static hipEvent_t get_event(mcr_env* h) {
 }
 #define LAUNCH(kid_, kernel, grid, block, st, ...)                                         \
   do {                                                                                   \
-    TimedLaunch tl_; bool tm_ = h->timing;                                               \
+    TimedLaunch tl_; bool tm_ = (h->timing >> (kid_)) & 1;                                              \
     if (tm_) { tl_.id = (kid_); tl_.a = get_event(h); tl_.b = get_event(h); (void)hipEventRecord(tl_.a, st); } \
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, st, __VA_ARGS__);             \
     if (tm_) { (void)hipEventRecord(tl_.b, st); h->pending.push_back(tl_); }                   \
@@ -288,7 +288,7 @@ extern "C" int mcr_sincos_device(mcr_env* h, const float* d_in, float* d_sin, fl
   return MCR_OK;
 }
 
-extern "C" int mcr_timing_enable(mcr_env* h, int enable) { if (!h) return MCR_ERR_ARG; h->timing = enable != 0; return MCR_OK; }
+extern "C" int mcr_timing_enable(mcr_env* h, int enable) { if (!h) return MCR_ERR_ARG; h->timing = enable; return MCR_OK; }
 extern "C" int mcr_timing_read(mcr_env* h, double* ms_out, int64_t* launches_out) {
   if (!h) return MCR_ERR_ARG;
   HIPCHK(hipDeviceSynchronize());

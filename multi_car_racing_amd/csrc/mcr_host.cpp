@@ -345,7 +345,7 @@ extern "C" int mcr_episode_generate(uint32_t* mt_track, int num_agents, int cw, 
   McrSlotHeader* H = (McrSlotHeader*)(blob + MCR_OFF_HDR);
   H->T = T; H->P = P; H->cw = cw ? 1 : 0;
   double* TX = (double*)(blob + MCR_OFF_TRACK_X); double* TY = (double*)(blob + MCR_OFF_TRACK_Y); double* TB = (double*)(blob + MCR_OFF_TRACK_B);
-  double* TAl = (double*)(blob + MCR_OFF_TRACK_A);
+  double* TAl = (double*)(blob + MCR_OFF_TRACK_A); double* TCs = (double*)(blob + MCR_OFF_TRACK_C); double* TSn = (double*)(blob + MCR_OFF_TRACK_S);
   float* QA = (float*)(blob + MCR_OFF_QA); float* QB = (float*)(blob + MCR_OFF_QB); uint32_t* QM = (uint32_t*)(blob + MCR_OFF_QMETA);
   float* TA = (float*)(blob + MCR_OFF_TAABB); float* VA = (float*)(blob + MCR_OFF_TVA); float* VB = (float*)(blob + MCR_OFF_TVB);
   float* NA = (float*)(blob + MCR_OFF_TNA); float* NB = (float*)(blob + MCR_OFF_TNB); uint32_t* TC = (uint32_t*)(blob + MCR_OFF_TCNT);
@@ -354,6 +354,7 @@ extern "C" int mcr_episode_generate(uint32_t* mt_track, int num_agents, int cw, 
     const TrackPt& a = lap[i]; const TrackPt& b = lap[wrap(i - 1, T)];
     TX[i] = a.x; TY[i] = a.y; TB[i] = a.beta; TAl[i] = a.alpha;
     double c1 = cos(a.beta), s1 = sin(a.beta), c2 = cos(b.beta), s2 = sin(b.beta);
+    TCs[i] = c1; TSn[i] = s1;
     double vx[4] = {a.x - kTrackWidth * c1, a.x + kTrackWidth * c1, b.x + kTrackWidth * c2, b.x - kTrackWidth * c2};
     double vy[4] = {a.y - kTrackWidth * s1, a.y + kTrackWidth * s1, b.y + kTrackWidth * s2, b.y - kTrackWidth * s2};
     float fx[4], fy[4];
@@ -373,7 +374,7 @@ extern "C" int mcr_episode_generate(uint32_t* mt_track, int num_agents, int cw, 
     VB[i * 4 + 0] = hp.x[2]; VB[i * 4 + 1] = hp.y[2]; VB[i * 4 + 2] = hp.x[3]; VB[i * 4 + 3] = hp.y[3];
     NA[i * 4 + 0] = hp.nx[0]; NA[i * 4 + 1] = hp.ny[0]; NA[i * 4 + 2] = hp.nx[1]; NA[i * 4 + 3] = hp.ny[1];
     NB[i * 4 + 0] = hp.nx[2]; NB[i * 4 + 1] = hp.ny[2]; NB[i * 4 + 2] = hp.nx[3]; NB[i * 4 + 3] = hp.ny[3];
-    TC[i] = (uint32_t)hp.n;
+    TC[i] = (uint32_t)hp.n | (kerb[i] ? 0x100u : 0u);
     if (kerb[i]) {
       double side = sgn(b.beta - a.beta);
       double w0 = side * kTrackWidth, w1 = side * (kTrackWidth + kBorder);

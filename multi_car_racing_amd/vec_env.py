@@ -203,8 +203,9 @@ class VecMultiCarRacing:
         """Host copy of the NEWEST generated episode of env e (the staged one once the env has reset)."""
         return _lib.unpack_episode(np.ascontiguousarray(self._blobs_np[e]))
 
-    def timing(self, enable):
-        _lib.check(self.L.mcr_timing_enable(self.h, int(enable)))
+    def timing(self, mask):
+        """HIP-event kernel timing; mask bit 0 collide, 1 dynamics, 2 view (7 = all, 0 = off)."""
+        _lib.check(self.L.mcr_timing_enable(self.h, int(mask)))
 
     def timing_read(self):
         ms = np.zeros(3); n = np.zeros(3, np.int64)

@@ -213,7 +213,8 @@ def lib():
         L.orc_create.restype = ctypes.c_void_p
         L.orc_create.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         for name in ("orc_destroy", "orc_set_track", "orc_reset", "orc_step", "orc_render", "orc_get_state",
-                     "orc_set_body", "orc_get_env", "orc_positions"):
+                     "orc_set_body", "orc_get_env", "orc_positions", "orc_contact_event", "orc_set_hull_pose",
+                     "orc_bookkeeping", "orc_wheel_tile_counts", "orc_reset_nostep"):
             getattr(L, name).restype = None
         L.orc_num_car_contacts.restype = ctypes.c_int
         L.orc_num_car_contacts.argtypes = [ctypes.c_void_p]
@@ -320,6 +321,28 @@ class OracleEnv:
     def positions(self):
         out = np.zeros((self.N, 2), np.float32)
         self.L.orc_positions(self.h, _p(out))
+        return out
+
+    # ---- scripted hooks (tests/golden/bookkeeping.json)
+    def reset_nostep(self, ep):
+        self.set_episode(ep)
+        self.L.orc_reset_nostep(self.h, _p(self._poses))
+
+    def contact_event(self, begin, car, wheel, tile):
+        self.L.orc_contact_event(self.h, ctypes.c_int(int(begin)), ctypes.c_int(car), ctypes.c_int(wheel), ctypes.c_int(tile))
+
+    def set_hull_pose(self, car, px, py, vx, vy, angle):
+        f = ctypes.c_float
+        self.L.orc_set_hull_pose(self.h, ctypes.c_int(car), f(px), f(py), f(vx), f(vy), f(angle))
+
+    def bookkeeping(self, has_action=True):
+        rew = np.zeros(self.N, np.float64); done = np.zeros(1, np.uint8)
+        self.L.orc_bookkeeping(self.h, ctypes.c_int(int(has_action)), _p(rew), _p(done))
+        return rew, bool(done[0])
+
+    def wheel_tile_counts(self):
+        out = np.zeros((self.N, 4), np.int32)
+        self.L.orc_wheel_tile_counts(self.h, _p(out))
         return out
 
     def num_car_contacts(self):

@@ -1,0 +1,53 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol include/mcr.h declares."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "mcr.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mcr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(lib):
+    L = lib.load()
+    names = _declared()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/mcr.h but not exported by libmcr_hip.so"
+    assert set(names) == set(lib.SYMBOLS), "multi_car_racing_amd/_lib.py binds a different symbol set than the header declares"
+
+
+def test_version_and_sizes(lib):
+    L = lib.load()
+    assert b"gfx950" in L.mcr_version()
+    assert lib.episode_bytes() % 16 == 0 and lib.episode_bytes() > 80000
+    assert ctypes.sizeof(lib.Config) == 48
+
+
+def test_library_contains_gfx950_code_object():
+    so = os.path.join(ROOT, "multi_car_racing_amd", "_lib", "libmcr_hip.so")
+    data = open(so, "rb").read()
+    assert b"gfx950" in data and b"k_dynamics" in data and b"k_view" in data and b"k_collide" in data
+
+
+def test_missing_library_fails_loudly(lib, monkeypatch):
+    from multi_car_racing_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmcr_hip.so")
+    import pytest
+    with pytest.raises(_lib.McrError):
+        _lib.load()
+
+
+def test_step_path_refuses_cpu(lib):
+    import pytest, torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from multi_car_racing_amd import McrError
+    from multi_car_racing_amd.vec_env import VecMultiCarRacing
+    with pytest.raises(McrError):
+        VecMultiCarRacing(4, 2)

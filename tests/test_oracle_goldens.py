@@ -1,0 +1,145 @@
+"""CPU: the oracle (oracle/) against the fixtures generated FROM THE REFERENCE MODULE (oracle/make_goldens.py)
+and against analytic known answers.  This is what pins the checker before it is trusted on the GPU."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_tracks_bit_exact(oracle):
+    g = np.load(os.path.join(G, "tracks.npz"))
+    for s in g["seeds"]:
+        rng = np.random.RandomState(int(s)); retries = 0
+        while True:
+            tr = oracle.make_track(rng)
+            if tr is not None:
+                break
+            retries += 1
+        assert retries == int(g[f"s{s}_retries"])
+        assert np.array_equal(tr["track"], g[f"s{s}_track"])
+        assert np.array_equal(tr["poly"], g[f"s{s}_poly"])
+        assert np.array_equal(tr["color"], g[f"s{s}_color"])
+        assert np.array_equal(tr["tile_of_quad"] >= 0, g[f"s{s}_is_tile"].astype(bool))
+        assert tr["start_alpha"] == float(g[f"s{s}_start_alpha"])
+
+
+def test_survey_probe_tile_counts(oracle):
+    # RandomState(s) -> 286 (after 1 retry), 275, 263, 275 tiles
+    g = np.load(os.path.join(G, "tracks.npz"))
+    assert [len(g[f"s{s}_track"]) for s in range(4)] == [286, 275, 263, 275]
+    assert int(g["s0_retries"]) == 1
+
+
+def test_spawn_and_global_draws(oracle):
+    sp = json.load(open(os.path.join(G, "spawn.json")))
+    for c in sp["cases"]:
+        np.random.seed(c["global_seed"])
+        if c.get("random_direction"):
+            assert str(np.random.choice(["CW", "CCW"])) == c["ctor_direction"]      # ctor draw (:157)
+            trng = np.random.RandomState(c["track_seed"])
+            for ep in range(3):
+                e = oracle.new_episode(2, trng, np.random, use_random_direction=True)
+                assert e["direction"] == c["episode_directions"][ep]
+                assert e["car_order"] == c["car_orders"][ep]
+            assert np.array_equal(e["poses"], np.array(c["poses"]))
+        else:
+            e = oracle.new_episode(c["N"], np.random.RandomState(c["track_seed"]), np.random,
+                                   direction=c["direction"], use_random_direction=False)
+            assert e["car_order"] == c["car_order"]
+            assert len(e["track"]) == c["T"]
+            assert np.array_equal(e["poses"], np.array(c["poses"]))
+
+
+def test_constants_match_reference():
+    k = json.load(open(os.path.join(G, "spawn.json")))["constants"]
+    from oracle import oracle as O
+    assert (k["SCALE"], k["FPS"], k["ZOOM"], k["STATE_W"], k["STATE_H"]) == (6.0, 50, 2.7, 96, 96)
+    assert k["PLAYFIELD"] == O.PLAYFIELD and k["TRACK_RAD"] == O.TRACK_RAD
+    assert k["TRACK_DETAIL_STEP"] == O.TRACK_DETAIL_STEP and k["TRACK_WIDTH"] == O.TRACK_WIDTH and k["BORDER"] == O.BORDER
+    assert k["K_BACKWARD"] == 0 and abs(k["BACKWARD_THRESHOLD"] - np.pi / 2) == 0
+    assert k["LINE_SPACING"] == 5 and k["LATERAL_SPACING"] == 3 and len(k["CAR_COLORS"]) == 8
+
+
+def test_contact_and_step_bookkeeping_traces(oracle):
+    """FrictionDetector._contact (:88-123) + step bookkeeping (:433-507) of the C++ oracle replayed on the
+    scripted contact/pose traces the reference module produced."""
+    eps = json.load(open(os.path.join(G, "bookkeeping.json")))
+    for ep in eps:
+        N = ep["N"]
+        np.random.seed(11)
+        e = oracle.new_episode(N, np.random.RandomState(ep["track_seed"]), np.random, direction=ep["direction"],
+                               use_random_direction=False)
+        assert len(e["track"]) == ep["T"]
+        env = oracle.OracleEnv(N)
+        env.reset_nostep(e)
+        for k, (st, tr) in enumerate(zip(ep["script"], ep["trace"])):
+            for begin, c, w, tidx in st["events"]:
+                env.contact_event(begin, c, w, tidx)
+            for c, (px, py, vx, vy, ang) in enumerate(st["poses"]):
+                env.set_hull_pose(c, px, py, vx, vy, ang)
+            r, done = env.bookkeeping(True)
+            es = env.env_state()
+            assert done == tr["done"], (ep["N"], k)
+            # f64 reward sums: same addends, the reference adds them in its contact-callback order
+            np.testing.assert_allclose(r, tr["step_reward"], rtol=0, atol=1e-9)
+            np.testing.assert_allclose(es["reward"], tr["reward"], rtol=0, atol=1e-9)
+            assert es["tile_visited_count"].tolist() == tr["tile_visited_count"]
+            assert es["driving_backward"].astype(bool).tolist() == tr["driving_backward"], (ep["N"], k)
+            assert es["driving_on_grass"].astype(bool).tolist() == tr["driving_on_grass"], (ep["N"], k)
+            assert env.wheel_tile_counts().tolist() == tr["n_wheel_tiles"]
+            # golden lists tiles whose colour equals ROAD_COLOR: recoloured ones plus the i%3==0 shade (:321-322)
+            shown = np.flatnonzero(es["touched"].astype(bool) | (np.arange(len(es["touched"])) % 3 == 0)).tolist()
+            assert shown == tr["touched"]
+        env.close()
+
+
+def test_reward_formula_readme(oracle):
+    # README:5 — first visitor +1000/T, second +500/T (N=2), -0.1 per frame
+    e = oracle.new_episode(2, np.random.RandomState(0), np.random.RandomState(0), use_random_direction=False)
+    T = len(e["track"])
+    env = oracle.OracleEnv(2); env.reset_nostep(e)
+    env.contact_event(1, 0, 0, 5); env.contact_event(1, 1, 2, 5)
+    r, _ = env.bookkeeping(True)
+    assert r[0] == 1000.0 / T - 0.1 and r[1] == 0.5 * 1000.0 / T - 0.1
+    env.contact_event(1, 0, 1, 5)          # same car, another wheel: no second reward
+    r, _ = env.bookkeeping(True)
+    assert np.allclose(r, -0.1)
+
+
+def test_mass_kats(oracle):
+    # hull mass 7.06, COM (0,-0.0825307), I 18.2122788; wheel mass 0.06048, I 0.0074592
+    m = oracle.mass_props()
+    assert abs(1 / m[0] - 7.06) < 1e-5 and abs(1 / m[1] - 18.2122788) < 2e-5
+    assert abs(m[2]) < 1e-7 and abs(m[3] + 0.0825307) < 1e-6
+    assert abs(1 / m[4] - 0.06048) < 1e-7 and abs(1 / m[5] - 0.0074592) < 1e-8
+
+
+def test_portable_sincos_vs_libm(oracle):
+    """The build's sinf/cosf spec is the correctly rounded value (f64 evaluation rounded once); glibc's
+    sinf/cosf (what Box2D calls) is within 1 ulp of it (it is itself only ~0.56-ulp accurate)."""
+    rng = np.random.RandomState(0)
+    angles = np.concatenate([rng.uniform(-50, 50, 3000), rng.uniform(-0.5, 0.5, 1000), [0.0, np.pi / 2, -np.pi, 1e-8]]).astype(np.float32)
+    ndiff = 0
+    for a in angles:
+        s0, c0 = oracle.sincos(float(a), 0); s1, c1 = oracle.sincos(float(a), 1)
+        assert np.float32(s0) == np.float32(np.sin(np.float64(a))) and np.float32(c0) == np.float32(np.cos(np.float64(a)))
+        assert abs(s0 - s1) <= 6e-8 and abs(c0 - c1) <= 6e-8
+        ndiff += (s0 != s1) + (c0 != c1)
+    assert ndiff < 0.03 * 2 * len(angles)
+    assert oracle.sincos(0.0, 0) == (0.0, 1.0)
+
+
+def test_trig_mode_deviation_is_small(oracle):
+    """The build's sinf/cosf spec vs libm: poses agree to fp32 roundoff over a short horizon."""
+    e = oracle.new_episode(2, np.random.RandomState(3), np.random.RandomState(3), use_random_direction=False)
+    a = oracle.OracleEnv(2, trig_mode=0); b = oracle.OracleEnv(2, trig_mode=1)
+    a.reset(e, render=False); b.reset(e, render=False)
+    rng = np.random.RandomState(0)
+    for k in range(60):
+        act = np.stack([rng.uniform(-1, 1, 2), rng.uniform(0, 1, 2), rng.uniform(0, 0.2, 2)], 1).astype(np.float32)
+        a.step(act, render=False); b.step(act, render=False)
+    assert np.abs(a.state()["bodies"] - b.state()["bodies"]).max() < 5e-3
+    assert a.env_state()["tile_visited_count"].tolist() == b.env_state()["tile_visited_count"].tolist()

@@ -55,7 +55,7 @@ for obs_on in (True, False):
     act = torch.rand((4096, 2, 3), device="cuda"); act[..., 0] = act[..., 0] * 2 - 1
     for _ in range(20): env.step(act)
     torch.cuda.synchronize()
-    env.timing(True)
+    env.timing(7)
     t0 = time.time()
     for _ in range(200): env.step(act)
     torch.cuda.synchronize(); dt = time.time() - t0
