@@ -65,6 +65,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise McrError(f"{LIB_PATH} is missing: run `python -m multi_car_racing_amd.build` "
                        "(hipcc --offload-arch=gfx950). There is no CPU fallback for the step path.")
+    try:
+        # PyTorch-ROCm bundles its own libamdhip64.so.7; load it FIRST so that this library (same soname)
+        # binds to the same HIP runtime instance that owns torch's device memory and streams.
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(L, name)           # AttributeError here == header/library mismatch

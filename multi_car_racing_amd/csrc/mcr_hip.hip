@@ -40,6 +40,7 @@ struct mcr_env {
   std::vector<hipEvent_t> free_events;
   double t_ms[3]; int64_t t_n[3];
   bool any_reset;
+  float* view_scratch;        // per-view spill area of the rasteriser (zoomed-out frames only)
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -64,10 +65,11 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   const size_t o_tflags = carve(sizeof(uint16_t) * MCR_TILE_CAP * (size_t)B);
   const size_t o_cc = carve(sizeof(uint32_t) * (size_t)B * (MCR_CC_MAX * MCR_CC_WORDS + 4));
   const size_t o_shapes = carve(sizeof(McrShapes));
+  const size_t o_vscratch = carve(sizeof(float) * (size_t)VIEW_SCRATCH_FLOATS * BN);
   const size_t o_slots = carve((size_t)B * 2 * MCR_SLOT_BYTES);
   h->slab_bytes = off;
   if (hipMalloc(&h->slab, off) != hipSuccess) { g_err = "hipMalloc failed"; delete h; return MCR_ERR_HIP; }
-  (void)hipMemset(h->slab, 0, off - (size_t)B * 2 * MCR_SLOT_BYTES);
+  (void)hipMemset(h->slab, 0, o_vscratch);
   uint8_t* base = (uint8_t*)h->slab;
   McrParams& P = h->P;
   memset(&P, 0, sizeof(P));
@@ -75,6 +77,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   P.carf = (float*)(base + o_carf); P.card = (double*)(base + o_card); P.caru = (uint32_t*)(base + o_caru);
   P.env = (McrEnvState*)(base + o_env); P.tile_touch = (uint32_t*)(base + o_touch); P.tile_flags = (uint16_t*)(base + o_tflags);
   P.cc_store = (uint32_t*)(base + o_cc); P.shapes = (const McrShapes*)(base + o_shapes); P.slots = base + o_slots;
+  h->view_scratch = (float*)(base + o_vscratch);
   P.auto_reset = cfg->auto_reset; P.max_steps = cfg->max_episode_steps; P.car_contacts = cfg->car_contacts;
   P.backwards_flag = cfg->backwards_flag; P.use_ego_color = cfg->use_ego_color; P.h_ratio = cfg->h_ratio;
   McrShapes S; mcr_build_shapes(&S);
@@ -139,7 +142,7 @@ static int run_reset_tail(mcr_env* h, McrParams& P, hipStream_t st, bool only_ju
   const int dyn_blocks = (B * P.G + 63) / 64;
   LAUNCH(0, k_collide, B, 64, st, P, 1);
   LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 1);
-  if (P.obs) LAUNCH(2, k_view, B * N, VIEW_THREADS, st, P, 0, only_just_reset ? 1 : 0);
+  if (P.obs) LAUNCH(2, k_view, B * N, VIEW_THREADS, st, P, h->view_scratch, 0, only_just_reset ? 1 : 0);
   return MCR_OK;
 }
 
@@ -171,7 +174,7 @@ extern "C" int mcr_step(mcr_env* h, const float* d_actions, uint8_t* d_obs, doub
     LAUNCH(0, k_collide, B, 64, st, P, 1);
     LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 1);
   }
-  LAUNCH(2, k_view, B * N, VIEW_THREADS, st, P, d_actions ? 1 : 0, 0);
+  LAUNCH(2, k_view, B * N, VIEW_THREADS, st, P, h->view_scratch, d_actions ? 1 : 0, 0);
   HIPCHK(hipGetLastError());
   return MCR_OK;
 }
