@@ -123,6 +123,9 @@ int mcr_sincos_device(mcr_env* h, const float* d_in, float* d_sin, float* d_cos,
  * launch stream.  `mask` bit k enables kernel id k (0 collide, 1 dynamics, 2 view; 7 = all, 0 = off).
  * mcr_timing_read synchronises the device and drains accumulated milliseconds + launch counts. */
 int mcr_timing_enable(mcr_env* h, int mask);
+/* profiling ablations of the raster kernel (bit 0 skip flags block, 1 skip road shading, 2 skip cars, 3 skip
+ * write-out, 4 skip binning/cull); 0 in production.  Results are WRONG when non-zero. */
+int mcr_debug_set(mcr_env* h, int value);
 int mcr_timing_read(mcr_env* h, double* ms_out /*[3]*/, int64_t* launches_out /*[3]*/);
 
 #ifdef __cplusplus

@@ -47,6 +47,7 @@ SYMBOLS = {
     "mcr_sincos_host": (None, [ctypes.c_float, _vp, _vp]),
     "mcr_sincos_device": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "mcr_timing_enable": (_i, [_vp, _i]),
+    "mcr_debug_set": (_i, [_vp, _i]),
     "mcr_timing_read": (_i, [_vp, _vp, _vp]),
 }
 

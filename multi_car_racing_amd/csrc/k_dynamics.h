@@ -428,6 +428,54 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
     p.card[CD_REWARD * BN + ci] = reward; p.card[CD_PREV_REWARD * BN + ci] = prev_reward;
     if (respawn) p.caru[CU_FLAGS * BN + ci] = 0;
   }
+  // ---- per-car view parameters for the rasteriser: one lane per agent view here instead of one redundant
+  // evaluation per raster thread there.  Camera (:540-556): f64 exactly as CPython evaluates it, then the f32
+  // values gym's Transform hands to glTranslatef/glRotatef/glScalef; HUD rectangles (:634-674).
+  if (p.obs != nullptr && !respawn) {
+    float* vp = p.viewp + (size_t)ci * MCR_VIEWP_FLOATS;
+    const Xf hxf = xf_of(v2(b[0].cx, b[0].cy), b[0].a, v2(lcx, lcy));
+    const double t = es.t + 1.0 / MCR_FPS;
+    const double zoom = 0.1 * MCR_SCALE * fmax(1 - t, 0.0) + MCR_ZOOM * MCR_SCALE * fmin(t, 1.0);
+    const double sx = (double)hxf.p.x, sy = (double)hxf.p.y;
+    double angle = -(double)b[0].a;
+    const double vx = (double)b[0].vx, vy = (double)b[0].vy;
+    const double speed = sqrt(vx * vx + vy * vy);
+    if (speed > 0.5) angle = atan2(vx, vy);
+    const double ttx = MCR_WINDOW_W / 2 - (sx * zoom * cos(angle) - sy * zoom * sin(angle));
+    const double tty = MCR_WINDOW_H * p.h_ratio - (sx * zoom * sin(angle) + sy * zoom * cos(angle));
+    const float ftx = (float)ttx, fty = (float)tty, fz = (float)zoom;
+    const float fdeg = (float)(57.29577951308232 * angle);
+    const double rad = (double)fdeg * (3.14159265358979323846 / 180.0);
+    const float fcs = (float)cos(rad), fsn = (float)sin(rad);
+    const float kx = 96.0f / 1000.0f, ky = 96.0f / 800.0f;
+    vp[VP_CAM + 0] = fcs * fz * kx; vp[VP_CAM + 1] = -fsn * fz * kx; vp[VP_CAM + 2] = fsn * fz * ky; vp[VP_CAM + 3] = fcs * fz * ky;
+    vp[VP_CAM + 4] = ftx * kx; vp[VP_CAM + 5] = fty * ky;
+    // pixel centre -> world:  world = R^T (W - t) / zoom,  W = centre * (1000/96, 800/96)
+    const float inv_z = 1.0f / fz;
+    vp[VP_INV + 0] = fcs * (1000.0f / 96.0f) * inv_z; vp[VP_INV + 1] = fsn * (800.0f / 96.0f) * inv_z; vp[VP_INV + 2] = -(fcs * ftx + fsn * fty) * inv_z;
+    vp[VP_INV + 3] = -fsn * (1000.0f / 96.0f) * inv_z; vp[VP_INV + 4] = fcs * (800.0f / 96.0f) * inv_z; vp[VP_INV + 5] = (fsn * ftx - fcs * fty) * inv_z;
+    const double sW = MCR_WINDOW_W / 40.0, hH = MCR_WINDOW_H / 40.0;
+    const double vals[5] = {0.02 * speed, 0.01 * omega[0], 0.01 * omega[1], 0.01 * omega[2], 0.01 * omega[3]};
+    const double places[5] = {5, 7, 8, 9, 10};
+    float hud_top = 12.0f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {                                   // vertical_ind (:643-648)
+      const float ya = (float)(hH + hH * vals[i]) * ky, yb = (float)hH * ky;
+      vp[VP_IND + i * 4 + 0] = (float)((places[i] + 0) * sW) * kx; vp[VP_IND + i * 4 + 1] = (float)((places[i] + 1) * sW) * kx;
+      vp[VP_IND + i * 4 + 2] = fminf(ya, yb); vp[VP_IND + i * 4 + 3] = fmaxf(ya, yb);
+      hud_top = fmaxf(hud_top, fmaxf(ya, yb) + 1.0f);
+    }
+    const double jang = (double)(b[1].a - b[0].a);
+    const double hv[2] = {-10.0 * jang, -0.8 * (double)b[0].w};
+    const double hp[2] = {20, 30};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                                   // horiz_ind (:649-654)
+      const float xa = (float)((hp[i] + 0) * sW) * kx, xb = (float)((hp[i] + hv[i]) * sW) * kx;
+      vp[VP_IND + (5 + i) * 4 + 0] = fminf(xa, xb); vp[VP_IND + (5 + i) * 4 + 1] = fmaxf(xa, xb);
+      vp[VP_IND + (5 + i) * 4 + 2] = (float)(2 * hH) * ky; vp[VP_IND + (5 + i) * 4 + 3] = (float)(4 * hH) * ky;
+    }
+    vp[VP_HUDTOP] = hud_top;
+  }
 }
 
 // Explicit reset(): install the staged episode for masked envs and spawn the cars; the caller then

@@ -9,7 +9,8 @@
 //   2. cull + setup: threads stride over quads, transform, reject by pixel bbox (incl. "contains no pixel
 //      centre"), store oriented edge equations of the survivors (LDS; rare overflow spills to a per-view HBM
 //      scratch) and the car polygons (12 per car);
-//   3. bin: one thread per 8x8-pixel bin builds that bin's survivor list (box-vs-convex test);
+//   3. bin: the thread that set a polygon up appends it to the lists of the 8x8-pixel bins it can touch
+//      (box-vs-convex test, LDS atomics; order is irrelevant because the highest draw index wins);
 //   4. shade: one wave per bin, lane = pixel; list walking is wave-uniform (LDS broadcast reads).  Background
 //      (playfield + checker) is analytic in world space; road/kerb: highest road_poly index wins (== painter's
 //      order); then cars; then the HUD in window space.  Result: one palette index per pixel (u8 framebuffer);
@@ -21,11 +22,12 @@
 namespace view {
 
 #define VIEW_THREADS 256
-#define VIS_LDS 160                  // survivors kept in LDS; more spill to HBM scratch (zoomed-out frames)
-#define BIN_CAP 24                   // entries per 8x8 bin list; overflow -> the bin walks every survivor
+#define VIS_LDS 112                  // road survivors kept in LDS; more spill to HBM scratch (zoomed-out frames)
+#define BIN_CAP 14                   // entries per 8x8 bin list; overflow -> the bin walks every survivor
+#define CAR_KEY 1024                 // bin-list ids >= CAR_KEY are car polygons (drawn after every road quad)
 #define NBINS 144
 #define CARPOLY_CAP (MCR_MAX_AGENTS * 12)
-#define VIEW_SCRATCH_FLOATS (MCR_QUAD_CAP * 13)   // per-view spill area (edge eq + info)
+#define VIEW_SCRATCH_FLOATS (MCR_QUAD_CAP * 16)   // per-view spill area (3 x float4 edge eq + info)
 
 // palette
 enum { PAL_BLACK = 0, PAL_GRASS0, PAL_GRASS1, PAL_ROAD0, PAL_ROAD1, PAL_ROAD2, PAL_WHITE, PAL_RED255, PAL_WHEELWHITE,
@@ -87,182 +89,67 @@ __device__ __forceinline__ bool centre_range(float lo, float hi, int c0, int c1,
 
 }  // namespace view
 
+// One 4-edge record vs one pixel centre: all oriented edge functions >= 0 (no short-circuit: one LDS burst).
+__device__ __forceinline__ bool inside4(const float4 a, const float4 b, const float4 c, float cx, float cy) {
+  const float e0 = a.x * cx + a.y * cy + a.z, e1 = a.w * cx + b.x * cy + b.y, e2 = b.z * cx + b.w * cy + c.x, e3 = c.y * cx + c.z * cy + c.w;
+  return fminf(fminf(e0, e1), fminf(e2, e3)) >= 0.0f;
+}
+// conservative convex-vs-box test: false if some edge function is negative on the whole pixel-centre box
+__device__ __forceinline__ bool box_may_touch(const float* e, int n, float X0, float X1, float Y0, float Y1) {
+  bool out = false;
+  for (int k = 0; k < n; ++k) {
+    const float A = e[k * 3], B = e[k * 3 + 1], C = e[k * 3 + 2];
+    const float m = A * (A >= 0.0f ? X1 : X0) + B * (B >= 0.0f ? Y1 : Y0) + C;
+    out = out || (m < 0.0f);
+  }
+  return !out;
+}
+
 // flags_mode: 1 = evaluate the backward/on-grass block (:446-495) for this agent.
-__global__ __launch_bounds__(VIEW_THREADS) void k_view(McrParams p, float* scratch, int flags_mode, int only_just_reset) {
+// dynamic LDS: car polygon records, N*12 x 6 float4 (8 edges each, padded with always-true edges)
+__global__ __launch_bounds__(VIEW_THREADS) void k_view(McrParams p, float* __restrict__ scratch, int flags_mode, int only_just_reset) {
   using namespace view;
   const int vw = blockIdx.x, tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
   const int N = p.N, BN = p.BN;
   const int env = vw / N, agent = vw % N;
   const McrEnvState es = p.env[env];
   if (!es.active) return;
   if (only_just_reset && !es.just_reset) return;
-  const uint8_t* slot = p.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES;
+  const uint8_t* __restrict__ slot = p.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES;
   const McrSlotHeader* H = (const McrSlotHeader*)slot;
   const int T = H->T, P = H->P;
   const int ci = env * N + agent;
   const McrShapes& S = *p.shapes;
+  const int dbg = p.debug;
 
+  extern __shared__ __attribute__((aligned(16))) float4 car8[];             // [N*12][6]
   __shared__ __attribute__((aligned(16))) uint8_t fb[96 * 96];
-  __shared__ __attribute__((aligned(16))) float qe[VIS_LDS][12];          // also reused as reduction scratch by the flags block
+  __shared__ __attribute__((aligned(16))) float4 qe[VIS_LDS][3];          // 4 oriented edges (A,B,C) of each surviving quad
   __shared__ uint32_t qinfo[VIS_LDS];                                       // bins(16) | quad index(10) << 3 | colour(3)
   __shared__ uint16_t bins[NBINS][BIN_CAP];
   __shared__ int bcnt[NBINS];
-  __shared__ float ce[CARPOLY_CAP][24];                                     // up to 8 edges per car polygon
-  __shared__ float cbb[CARPOLY_CAP][4];
-  __shared__ uint32_t cinfo[CARPOLY_CAP];                                   // 0x10000 | (nedges << 8) | palette ; 0 = skip
-  __shared__ float carbox[MCR_MAX_AGENTS][4];
+  __shared__ uint32_t cinfo[CARPOLY_CAP];                                   // 0x100 | palette ; 0 = not drawn
   __shared__ uint32_t pal[32];
-  __shared__ int nvis;
-  __shared__ int any_inside;
+  __shared__ double red_d[4]; __shared__ int red_i[4];
+  __shared__ int nvis, any_inside, next_bin;
 
-  if (tid == 0) { nvis = 0; any_inside = 0; }
+  if (tid == 0) { nvis = 0; any_inside = 0; next_bin = 4; }
   if (tid < 32) pal[tid] = palette_rgb(tid);
-  if (tid < MCR_MAX_AGENTS) { carbox[tid][0] = MCR_MAXFLT; carbox[tid][1] = 0.0f; carbox[tid][2] = MCR_MAXFLT; carbox[tid][3] = 0.0f; }
+  if (tid < NBINS) bcnt[tid] = 0;
   const uint32_t old_flags = p.caru[CU_FLAGS * BN + ci];
-
-  // ---- camera (:540-556).  f64 exactly as CPython, then the f32 values GL receives.
-  const float hcx = p.carf[(CF_CX + 0) * BN + ci], hcy = p.carf[(CF_CY + 0) * BN + ci], ha = p.carf[(CF_A + 0) * BN + ci];
-  const float hvx = p.carf[(CF_VX + 0) * BN + ci], hvy = p.carf[(CF_VY + 0) * BN + ci], hw = p.carf[(CF_W + 0) * BN + ci];
-  const Xf hxf = xf_of(v2(hcx, hcy), ha, v2(S.hull_lcx, S.hull_lcy));
-  Cam cam; float fz, fcs, fsn, ftx, fty;
-  {
-    const double t = es.t;
-    const double zoom = 0.1 * MCR_SCALE * fmax(1 - t, 0.0) + MCR_ZOOM * MCR_SCALE * fmin(t, 1.0);
-    const double sx = (double)hxf.p.x, sy = (double)hxf.p.y;
-    double angle = -(double)ha;
-    const double vx = (double)hvx, vy = (double)hvy;
-    if (sqrt(vx * vx + vy * vy) > 0.5) angle = atan2(vx, vy);
-    const double ttx = MCR_WINDOW_W / 2 - (sx * zoom * cos(angle) - sy * zoom * sin(angle));
-    const double tty = MCR_WINDOW_H * p.h_ratio - (sx * zoom * sin(angle) + sy * zoom * cos(angle));
-    ftx = (float)ttx; fty = (float)tty; fz = (float)zoom;
-    const float fdeg = (float)(57.29577951308232 * angle);
-    const double rad = (double)fdeg * (3.14159265358979323846 / 180.0);
-    fcs = (float)cos(rad); fsn = (float)sin(rad);
-    const float kx = 96.0f / 1000.0f, ky = 96.0f / 800.0f;
-    cam.m00 = fcs * fz * kx; cam.m01 = -fsn * fz * kx; cam.tx = ftx * kx;
-    cam.m10 = fsn * fz * ky; cam.m11 = fcs * fz * ky; cam.ty = fty * ky;
-  }
+  const float hvx = p.carf[(CF_VX + 0) * BN + ci], hvy = p.carf[(CF_VY + 0) * BN + ci], ha = p.carf[(CF_A + 0) * BN + ci];
+  const bool draw = p.obs != nullptr;
+  const float* __restrict__ vp = p.viewp + (size_t)ci * MCR_VIEWP_FLOATS;
+  float m00 = 0, m01 = 0, m10 = 0, m11 = 0, ctx = 0, cty = 0;
+  if (draw) { m00 = vp[VP_CAM + 0]; m01 = vp[VP_CAM + 1]; m10 = vp[VP_CAM + 2]; m11 = vp[VP_CAM + 3]; ctx = vp[VP_CAM + 4]; cty = vp[VP_CAM + 5]; }
+  float* __restrict__ spill = scratch + (size_t)vw * VIEW_SCRATCH_FLOATS;
   __syncthreads();
 
-  // ---- backward / on-grass flags (:446-495) from the post-solve pose; they reach pixels one step later
-  uint32_t new_flags = old_flags; bool write_flags = false;
-  if (flags_mode) {
-    const double px = (double)hxf.p.x, py = (double)hxf.p.y;
-    const double* TX = (const double*)(slot + MCR_OFF_TRACK_X); const double* TY = (const double*)(slot + MCR_OFF_TRACK_Y); const double* TB = (const double*)(slot + MCR_OFF_TRACK_B);
-    const double* TC = (const double*)(slot + MCR_OFF_TRACK_C); const double* TS = (const double*)(slot + MCR_OFF_TRACK_S);
-    const uint32_t* TCNT = (const uint32_t*)(slot + MCR_OFF_TCNT);
-    const float4* TAABB = (const float4*)(slot + MCR_OFF_TAABB);
-    const double TW = 40 / MCR_SCALE, TBW = 8 / MCR_SCALE;
-    const float fpx = hxf.p.x, fpy = hxf.p.y, margin = (float)(8 / MCR_SCALE) + 0.01f;
-    double bd = 1e300; int bi = 0x7fffffff;
-    bool inside = false;
-    for (int t = tid; t < T; t += VIEW_THREADS) {
-      const double x1 = TX[t], y1 = TY[t];
-      const double dx = px - x1, dy = py - y1;
-      const double d = sqrt(dx * dx + dy * dy);            // np.linalg.norm(..., axis=1) then argmin (:465-467)
-      if (d < bd) { bd = d; bi = t; }
-      // strict-interior point-in-quad over road_poly (shapely `within`, :470-472) on the f64 polygons the
-      // reference builds (:313-317 tile, :329-333 kerb); a f32 AABB (+kerb width) prefilter skips far tiles
-      const float4 bb = TAABB[t];
-      if (fpx < bb.x - margin || fpx > bb.z + margin || fpy < bb.y - margin || fpy > bb.w + margin) continue;
-      const int u = t == 0 ? T - 1 : t - 1;
-      const double c1 = TC[t], s1 = TS[t], x2 = TX[u], y2 = TY[u], c2 = TC[u], s2 = TS[u];
-      const int nq = (TCNT[t] & 0x100u) ? 2 : 1;
-      for (int k = 0; k < nq; ++k) {
-        double X[4], Y[4];
-        if (k == 0) {
-          X[0] = x1 - TW * c1; Y[0] = y1 - TW * s1; X[1] = x1 + TW * c1; Y[1] = y1 + TW * s1;
-          X[2] = x2 + TW * c2; Y[2] = y2 + TW * s2; X[3] = x2 - TW * c2; Y[3] = y2 - TW * s2;
-        } else {
-          const double side = dyn::np_sign(TB[u] - TB[t]);
-          const double w0 = side * TW, w1 = side * (TW + TBW);
-          X[0] = x1 + w0 * c1; Y[0] = y1 + w0 * s1; X[1] = x1 + w1 * c1; Y[1] = y1 + w1 * s1;
-          X[2] = x2 + w1 * c2; Y[2] = y2 + w1 * s2; X[3] = x2 + w0 * c2; Y[3] = y2 + w0 * s2;
-        }
-        bool pos = true, neg = true;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int j = (i + 1) & 3;
-          const double cr = (X[j] - X[i]) * (py - Y[i]) - (Y[j] - Y[i]) * (px - X[i]);
-          if (!(cr > 0)) pos = false;
-          if (!(cr < 0)) neg = false;
-        }
-        inside = inside || pos || neg;
-      }
-    }
-    if (inside) atomicOr(&any_inside, 1);
-    double* red_d = (double*)&qe[0][0]; int* red_i = (int*)(red_d + VIEW_THREADS);
-    red_d[tid] = bd; red_i[tid] = bi;
-    __syncthreads();
-    for (int s = VIEW_THREADS / 2; s > 0; s >>= 1) {
-      if (tid < s) {
-        const double d2 = red_d[tid + s]; const int i2 = red_i[tid + s];
-        if (d2 < red_d[tid] || (d2 == red_d[tid] && i2 < red_i[tid])) { red_d[tid] = d2; red_i[tid] = i2; }
-      }
-      __syncthreads();
-    }
-    if (tid == 0) {
-      const double TWO_PI = 2 * 3.141592653589793, PI = 3.141592653589793;
-      double car_angle;
-      const double vx = (double)hvx, vy = (double)hvy;
-      if (sqrt(vx * vx + vy * vy) > 0.5) car_angle = -atan2(vx, vy); else car_angle = (double)ha;
-      car_angle = fmod(car_angle + TWO_PI, TWO_PI); if (car_angle < 0) car_angle += TWO_PI;
-      double desired = TB[red_i[0]];
-      if (H->cw) desired += PI;
-      desired = fmod(desired + TWO_PI, TWO_PI); if (desired < 0) desired += TWO_PI;
-      double diff = fabs(desired - car_angle);
-      if (diff > PI) diff = fabs(diff - TWO_PI);
-      new_flags = 0;
-      if (diff > PI / 2) new_flags |= 1u;
-      if (!any_inside) new_flags |= 2u;
-      write_flags = true;
-    }
-    __syncthreads();
-  }
-  if (write_flags) p.caru[CU_FLAGS * BN + ci] = new_flags;
-  if (p.obs == nullptr) return;
-
-  // ---- road quads: cull + edge setup
-  float* spill = scratch + (size_t)vw * VIEW_SCRATCH_FLOATS;
-  {
-    const float4* QA = (const float4*)(slot + MCR_OFF_QA); const float4* QB = (const float4*)(slot + MCR_OFF_QB);
-    const uint32_t* QM = (const uint32_t*)(slot + MCR_OFF_QMETA);
-    const uint16_t* tflags = p.tile_flags + (size_t)env * MCR_TILE_CAP;
-    for (int q = tid; q < P; q += VIEW_THREADS) {
-      const float4 a = QA[q], b = QB[q];
-      const float wx[4] = {a.x, a.z, b.x, b.z}, wy[4] = {a.y, a.w, b.y, b.w};
-      float px[4], py[4];
-      float x0 = MCR_MAXFLT, x1 = -MCR_MAXFLT, y0 = MCR_MAXFLT, y1 = -MCR_MAXFLT;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        px[i] = cam.m00 * wx[i] + cam.m01 * wy[i] + cam.tx; py[i] = cam.m10 * wx[i] + cam.m11 * wy[i] + cam.ty;
-        x0 = fminf(x0, px[i]); x1 = fmaxf(x1, px[i]); y0 = fminf(y0, py[i]); y1 = fmaxf(y1, py[i]);
-      }
-      int ix0, ix1, iy0, iy1;
-      if (!centre_range(x0, x1, 0, 95, ix0, ix1) || !centre_range(y0, y1, 12, 95, iy0, iy1)) continue;   // rows < 12: HUD bar
-      float e[12];
-      if (!edge_setup(px, py, 4, e)) continue;
-      const uint32_t meta = QM[q];
-      uint32_t col = meta & 0xffu; const uint32_t tile1 = meta >> 8;
-      if (tile1 && (tflags[tile1 - 1] & 0x100u)) col = MCR_COL_ROAD0;           // touched tile -> ROAD_COLOR (:102-104)
-      const uint32_t info = ((uint32_t)(ix0 >> 3) << 28) | ((uint32_t)(ix1 >> 3) << 24) | ((uint32_t)(iy0 >> 3) << 20) | ((uint32_t)(iy1 >> 3) << 16) |
-                            ((uint32_t)q << 3) | col;
-      const int s = atomicAdd(&nvis, 1);
-      if (s < VIS_LDS) {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) qe[s][i] = e[i];
-        qinfo[s] = info;
-      } else {
-        float* d = spill + (size_t)(s - VIS_LDS) * 13;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) d[i] = e[i];
-        d[12] = __uint_as_float(info);
-      }
-    }
-  }
-  // ---- car polygons (Car.draw): per car 4x(wheel box, white stripe) then 4 hull polys, cars in id order
-  for (int k = tid; k < N * 12; k += VIEW_THREADS) {
-    const int c = k / 12, j = k % 12;
+  // ---- car polygons (Car.draw): per car 4x(wheel box, white stripe) then 4 hull polys, cars in id order.
+  // Threads 0..12N-1 set one polygon up each, then join the road loop.
+  if (draw && tid < N * 12) {
+    const int k = tid, c = k / 12, j = k % 12;
     const int cj = env * N + c;
     uint32_t info = 0;
     float lx[8], ly[8]; int n = 0; uint32_t colr = 0; Xf xf;
@@ -294,173 +181,254 @@ __global__ __launch_bounds__(VIEW_THREADS) void k_view(McrParams p, float* scrat
       colr = PAL_CAR0 + (c & 7);                                              // CAR_COLORS[c % 8] (:402)
       if (p.use_ego_color) colr = (c == agent) ? PAL_CAR0 + 0 : PAL_CAR0 + 1; // (:560-563)
     }
-    if (n > 0) {
+    if (n > 0 && !(dbg & 4)) {
       float px[8], py[8];
       float x0 = MCR_MAXFLT, x1 = -MCR_MAXFLT, y0 = MCR_MAXFLT, y1 = -MCR_MAXFLT;
       for (int i = 0; i < n; ++i) {
         const V2 w = xmul(xf, v2(lx[i], ly[i]));                 // trans*v in f32, as pybox2d returns it
-        px[i] = cam.m00 * w.x + cam.m01 * w.y + cam.tx; py[i] = cam.m10 * w.x + cam.m11 * w.y + cam.ty;
+        px[i] = m00 * w.x + m01 * w.y + ctx; py[i] = m10 * w.x + m11 * w.y + cty;
         x0 = fminf(x0, px[i]); x1 = fmaxf(x1, px[i]); y0 = fminf(y0, py[i]); y1 = fmaxf(y1, py[i]);
       }
       float e[24];
-      int a0, a1, b0, b1;
-      if (centre_range(x0, x1, 0, 95, a0, a1) && centre_range(y0, y1, 12, 95, b0, b1) && edge_setup(px, py, n, e)) {
-        for (int i = 0; i < n * 3; ++i) ce[k][i] = e[i];
-        cbb[k][0] = x0; cbb[k][1] = x1; cbb[k][2] = y0; cbb[k][3] = y1;
-        info = 0x10000u | ((uint32_t)n << 8) | colr;
-        // per-car pixel bbox via integer atomics on positive floats (on-screen boxes, offset by +1000 px)
-        const float ox0 = fmaxf(x0, -900.0f) + 1000.0f, ox1 = fminf(x1, 900.0f) + 1000.0f, oy0 = fmaxf(y0, -900.0f) + 1000.0f, oy1 = fminf(y1, 900.0f) + 1000.0f;
-        atomicMin((int*)&carbox[c][0], __float_as_int(ox0)); atomicMax((int*)&carbox[c][1], __float_as_int(ox1));
-        atomicMin((int*)&carbox[c][2], __float_as_int(oy0)); atomicMax((int*)&carbox[c][3], __float_as_int(oy1));
+      int ix0, ix1, iy0, iy1;
+      if (centre_range(x0, x1, 0, 95, ix0, ix1) && centre_range(y0, y1, 12, 95, iy0, iy1) && edge_setup(px, py, n, e)) {
+        for (int i = n * 3; i < 24; i += 3) { e[i] = 0.0f; e[i + 1] = 0.0f; e[i + 2] = 1.0f; }     // always-true padding edges
+#pragma unroll
+        for (int i = 0; i < 6; ++i) car8[k * 6 + i] = make_float4(e[i * 4], e[i * 4 + 1], e[i * 4 + 2], e[i * 4 + 3]);
+        info = 0x100u | colr;
+        for (int by = iy0 >> 3; by <= (iy1 >> 3); ++by)
+          for (int bx = ix0 >> 3; bx <= (ix1 >> 3); ++bx) {
+            const float X0 = (float)(bx * 8) + 0.5f, Y0 = (float)(by * 8) + 0.5f;
+            if (!box_may_touch(e, n, X0, X0 + 7.0f, Y0, Y0 + 7.0f)) continue;
+            const int b = by * 12 + bx;
+            const int at = atomicAdd(&bcnt[b], 1);
+            if (at < BIN_CAP) bins[b][at] = (uint16_t)(CAR_KEY + k);
+          }
       }
     }
     cinfo[k] = info;
   }
+
+  // ---- road quads: cull + edge setup + bin
+  if (draw && !(dbg & 16)) {
+    const float4* QA = (const float4*)(slot + MCR_OFF_QA); const float4* QB = (const float4*)(slot + MCR_OFF_QB);
+    const uint32_t* QM = (const uint32_t*)(slot + MCR_OFF_QMETA);
+    const uint16_t* tflags = p.tile_flags + (size_t)env * MCR_TILE_CAP;
+    for (int q = tid; q < P; q += VIEW_THREADS) {
+      const float4 a = QA[q], b = QB[q];
+      const float wx[4] = {a.x, a.z, b.x, b.z}, wy[4] = {a.y, a.w, b.y, b.w};
+      float px[4], py[4];
+      float x0 = MCR_MAXFLT, x1 = -MCR_MAXFLT, y0 = MCR_MAXFLT, y1 = -MCR_MAXFLT;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        px[i] = m00 * wx[i] + m01 * wy[i] + ctx; py[i] = m10 * wx[i] + m11 * wy[i] + cty;
+        x0 = fminf(x0, px[i]); x1 = fmaxf(x1, px[i]); y0 = fminf(y0, py[i]); y1 = fmaxf(y1, py[i]);
+      }
+      int ix0, ix1, iy0, iy1;
+      if (!centre_range(x0, x1, 0, 95, ix0, ix1) || !centre_range(y0, y1, 12, 95, iy0, iy1)) continue;   // rows < 12: HUD bar
+      float e[12];
+      if (!edge_setup(px, py, 4, e)) continue;
+      const uint32_t meta = QM[q];
+      uint32_t col = meta & 0xffu; const uint32_t tile1 = meta >> 8;
+      if (tile1 && (tflags[tile1 - 1] & 0x100u)) col = MCR_COL_ROAD0;           // touched tile -> ROAD_COLOR (:102-104)
+      const uint32_t info = ((uint32_t)q << 3) | col;
+      const int s = atomicAdd(&nvis, 1);
+      if (s < VIS_LDS) {
+        qe[s][0] = make_float4(e[0], e[1], e[2], e[3]); qe[s][1] = make_float4(e[4], e[5], e[6], e[7]); qe[s][2] = make_float4(e[8], e[9], e[10], e[11]);
+        qinfo[s] = info;
+      } else {
+        float4* d = (float4*)(spill + (size_t)(s - VIS_LDS) * 16);
+        d[0] = make_float4(e[0], e[1], e[2], e[3]); d[1] = make_float4(e[4], e[5], e[6], e[7]); d[2] = make_float4(e[8], e[9], e[10], e[11]);
+        d[3] = make_float4(__uint_as_float(info), 0.0f, 0.0f, 0.0f);
+      }
+      for (int by = iy0 >> 3; by <= (iy1 >> 3); ++by)
+        for (int bx = ix0 >> 3; bx <= (ix1 >> 3); ++bx) {
+          const float X0 = (float)(bx * 8) + 0.5f, Y0 = (float)(by * 8) + 0.5f;
+          if (!box_may_touch(e, 4, X0, X0 + 7.0f, Y0, Y0 + 7.0f)) continue;
+          const int bb = by * 12 + bx;
+          const int at = atomicAdd(&bcnt[bb], 1);
+          if (at < BIN_CAP) bins[bb][at] = (uint16_t)s;
+        }
+    }
+  }
+
+  // ---- backward / on-grass flags (:446-495) from the post-solve pose; they reach pixels one step later
+  const bool do_flags = flags_mode && !(dbg & 1);
+  if (do_flags) {
+    const Xf hxf = xf_of(v2(p.carf[(CF_CX + 0) * BN + ci], p.carf[(CF_CY + 0) * BN + ci]), ha, v2(S.hull_lcx, S.hull_lcy));
+    const double px = (double)hxf.p.x, py = (double)hxf.p.y;
+    const double* TX = (const double*)(slot + MCR_OFF_TRACK_X); const double* TY = (const double*)(slot + MCR_OFF_TRACK_Y); const double* TB = (const double*)(slot + MCR_OFF_TRACK_B);
+    const double* TC = (const double*)(slot + MCR_OFF_TRACK_C); const double* TS = (const double*)(slot + MCR_OFF_TRACK_S);
+    const uint32_t* TCNT = (const uint32_t*)(slot + MCR_OFF_TCNT);
+    const float4* TAABB = (const float4*)(slot + MCR_OFF_TAABB);
+    const double TW = 40 / MCR_SCALE, TBW = 8 / MCR_SCALE;
+    const float fpx = hxf.p.x, fpy = hxf.p.y, margin = (float)(8 / MCR_SCALE) + 0.01f;
+    double bd = 1e300; int bi = 0x7fffffff;
+    bool inside = false;
+    for (int t = tid; t < T; t += VIEW_THREADS) {
+      const double x1 = TX[t], y1 = TY[t];
+      const double dx = px - x1, dy = py - y1;
+      const double d = sqrt(dx * dx + dy * dy);            // np.linalg.norm(..., axis=1) then argmin (:465-467)
+      if (d < bd) { bd = d; bi = t; }
+      // strict-interior point-in-quad over road_poly (shapely `within`, :470-472) on the f64 polygons the
+      // reference builds (:313-317 tile, :329-333 kerb); a f32 AABB (+kerb width) prefilter skips far tiles
+      const float4 bb = TAABB[t];
+      if (fpx < bb.x - margin || fpx > bb.z + margin || fpy < bb.y - margin || fpy > bb.w + margin) continue;
+      const int u = t == 0 ? T - 1 : t - 1;
+      const double c1 = TC[t], s1 = TS[t], x2 = TX[u], y2 = TY[u], c2 = TC[u], s2 = TS[u];
+      const int nqd = (TCNT[t] & 0x100u) ? 2 : 1;
+      for (int k = 0; k < nqd; ++k) {
+        double X[4], Y[4];
+        if (k == 0) {
+          X[0] = x1 - TW * c1; Y[0] = y1 - TW * s1; X[1] = x1 + TW * c1; Y[1] = y1 + TW * s1;
+          X[2] = x2 + TW * c2; Y[2] = y2 + TW * s2; X[3] = x2 - TW * c2; Y[3] = y2 - TW * s2;
+        } else {
+          const double side = dyn::np_sign(TB[u] - TB[t]);
+          const double w0 = side * TW, w1 = side * (TW + TBW);
+          X[0] = x1 + w0 * c1; Y[0] = y1 + w0 * s1; X[1] = x1 + w1 * c1; Y[1] = y1 + w1 * s1;
+          X[2] = x2 + w1 * c2; Y[2] = y2 + w1 * s2; X[3] = x2 + w0 * c2; Y[3] = y2 + w0 * s2;
+        }
+        bool pos = true, neg = true;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int j = (i + 1) & 3;
+          const double cr = (X[j] - X[i]) * (py - Y[i]) - (Y[j] - Y[i]) * (px - X[i]);
+          if (!(cr > 0)) pos = false;
+          if (!(cr < 0)) neg = false;
+        }
+        inside = inside || pos || neg;
+      }
+    }
+    if (__any(inside) && lane == 0) atomicOr(&any_inside, 1);
+    // wave argmin (first index on ties), partials combined after the barrier
+    for (int o = 32; o > 0; o >>= 1) {
+      const double d2 = __shfl_xor(bd, o); const int i2 = __shfl_xor(bi, o);
+      if (d2 < bd || (d2 == bd && i2 < bi)) { bd = d2; bi = i2; }
+    }
+    if (lane == 0) { red_d[wave] = bd; red_i[wave] = bi; }
+  }
   __syncthreads();
   const int nq = nvis;
+  const int nq_lds = nq < VIS_LDS ? nq : VIS_LDS;
 
-  // ---- bin: thread b owns the 8x8 bin b and collects the survivors whose quad can touch it
-  if (tid < NBINS) {
-    const int bx = tid % 12, by = tid / 12;
-    const float X0 = (float)(bx * 8) + 0.5f, X1 = X0 + 7.0f, Y0 = (float)(by * 8) + 0.5f, Y1 = Y0 + 7.0f;   // pixel-centre box
-    int cnt = 0;
-    for (int s = 0; s < nq; ++s) {
-      const uint32_t inf = s < VIS_LDS ? qinfo[s] : __float_as_uint(spill[(size_t)(s - VIS_LDS) * 13 + 12]);
-      const int bx0 = inf >> 28, bx1 = (inf >> 24) & 15, by0 = (inf >> 20) & 15, by1 = (inf >> 16) & 15;
-      if (bx < bx0 || bx > bx1 || by < by0 || by > by1) continue;
-      const float* e = s < VIS_LDS ? qe[s] : spill + (size_t)(s - VIS_LDS) * 13;
-      bool out = false;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float A = e[k * 3], B = e[k * 3 + 1], C = e[k * 3 + 2];
-        const float m = A * (A >= 0.0f ? X1 : X0) + B * (B >= 0.0f ? Y1 : Y0) + C;     // max of the edge function over the box
-        out = out || (m < 0.0f);
-      }
-      if (out) continue;
-      if (cnt < BIN_CAP) bins[tid][cnt] = (uint16_t)s;
-      ++cnt;
-    }
-    bcnt[tid] = cnt;
+  // ---- finish the flags on one lane of the last wave while the other waves start shading
+  if (do_flags && tid == VIEW_THREADS - 1) {
+    const double* TB = (const double*)(slot + MCR_OFF_TRACK_B);
+    double bd = red_d[0]; int bi = red_i[0];
+    for (int w = 1; w < 4; ++w) if (red_d[w] < bd || (red_d[w] == bd && red_i[w] < bi)) { bd = red_d[w]; bi = red_i[w]; }
+    const double TWO_PI = 2 * 3.141592653589793, PI = 3.141592653589793;
+    double car_angle;
+    const double vx = (double)hvx, vy = (double)hvy;
+    if (sqrt(vx * vx + vy * vy) > 0.5) car_angle = -atan2(vx, vy); else car_angle = (double)ha;
+    car_angle = fmod(car_angle + TWO_PI, TWO_PI); if (car_angle < 0) car_angle += TWO_PI;
+    double desired = TB[bi];
+    if (H->cw) desired += PI;
+    desired = fmod(desired + TWO_PI, TWO_PI); if (desired < 0) desired += TWO_PI;
+    double diff = fabs(desired - car_angle);
+    if (diff > PI) diff = fabs(diff - TWO_PI);
+    uint32_t f = 0;
+    if (diff > PI / 2) f |= 1u;
+    if (!any_inside) f |= 2u;
+    p.caru[CU_FLAGS * BN + ci] = f;
   }
-  __syncthreads();
+  if (!draw) return;
 
-  // ---- HUD values (:634-674) in pixel units (window x*0.096, y*0.12)
-  const float kx = 96.0f / 1000.0f, ky = 96.0f / 800.0f;
-  const double sW = MCR_WINDOW_W / 40.0, hH = MCR_WINDOW_H / 40.0;
-  float ind_x0[7], ind_x1[7], ind_y0[7], ind_y1[7];
+  // ---- shade: one wave per 8x8 bin (lane = pixel), bins handed out dynamically
   {
-    const double speed = sqrt((double)hvx * (double)hvx + (double)hvy * (double)hvy);
-    const double vals[5] = {0.02 * speed, 0.01 * p.card[(CD_OMEGA + 0) * BN + ci], 0.01 * p.card[(CD_OMEGA + 1) * BN + ci],
-                            0.01 * p.card[(CD_OMEGA + 2) * BN + ci], 0.01 * p.card[(CD_OMEGA + 3) * BN + ci]};
-    const double places[5] = {5, 7, 8, 9, 10};
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      ind_x0[i] = (float)((places[i] + 0) * sW) * kx; ind_x1[i] = (float)((places[i] + 1) * sW) * kx;
-      const float ya = (float)(hH + hH * vals[i]) * ky, yb = (float)hH * ky;
-      ind_y0[i] = fminf(ya, yb); ind_y1[i] = fmaxf(ya, yb);
-    }
-    const double jang = (double)(p.carf[(CF_A + 1) * BN + ci] - ha);
-    const double hv[2] = {-10.0 * jang, -0.8 * (double)hw};
-    const double hp[2] = {20, 30};
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float xa = (float)((hp[i] + 0) * sW) * kx, xb = (float)((hp[i] + hv[i]) * sW) * kx;
-      ind_x0[5 + i] = fminf(xa, xb); ind_x1[5 + i] = fmaxf(xa, xb);
-      ind_y0[5 + i] = (float)(2 * hH) * ky; ind_y1[5 + i] = (float)(4 * hH) * ky;
-    }
-  }
-  const uint32_t ind_col[7] = {PAL_WHITE, PAL_BLUE255, PAL_BLUE255, PAL_PURPLE, PAL_PURPLE, PAL_GREEN255, PAL_RED255};
-  const bool show_flag = (old_flags & 1u) && p.backwards_flag;
-  float fe[9];
-  { const float fx[3] = {900.0f * kx, 925.0f * kx, 950.0f * kx}, fy[3] = {30.0f * ky, 70.0f * ky, 30.0f * ky}; edge_setup(fx, fy, 3, fe); }
-  float hud_top = 12.0f;
-#pragma unroll
-  for (int i = 0; i < 7; ++i) hud_top = fmaxf(hud_top, ind_y1[i] + 1.0f);
-
-  // ---- shade: one wave per bin, lane = pixel of the 8x8 bin
-  {
-    const int wave = tid >> 6, lane = tid & 63;
+    const bool show_flag = (old_flags & 1u) && p.backwards_flag;
+    const float kx = 96.0f / 1000.0f, ky = 96.0f / 800.0f;
+    float fe[9];
+    { const float fx[3] = {900.0f * kx, 925.0f * kx, 950.0f * kx}, fy[3] = {30.0f * ky, 70.0f * ky, 30.0f * ky}; edge_setup(fx, fy, 3, fe); }
+    const float hud_top = vp[VP_HUDTOP];
     const int lx = lane & 7, ly = lane >> 3;
-    const float inv_z = 1.0f / fz;
-    const float kgrid = (float)(MCR_PLAYFIELD / 20.0), PF = (float)MCR_PLAYFIELD;
-    // world = R^T (W - t) / zoom, W = pixel centre * (1000/96, 800/96)
-    const float ax = fcs * (1000.0f / 96.0f) * inv_z, bx_ = fsn * (800.0f / 96.0f) * inv_z, cx0 = -(fcs * ftx + fsn * fty) * inv_z;
-    const float ay = -fsn * (1000.0f / 96.0f) * inv_z, by_ = fcs * (800.0f / 96.0f) * inv_z, cy0 = (fsn * ftx - fcs * fty) * inv_z;
-    for (int b = wave; b < NBINS; b += 4) {
+    const float inv_kgrid = 1.0f / (float)(MCR_PLAYFIELD / 20.0), PF = (float)MCR_PLAYFIELD;
+    const float ax = vp[VP_INV + 0], bx_ = vp[VP_INV + 1], cx0 = vp[VP_INV + 2], ay = vp[VP_INV + 3], by_ = vp[VP_INV + 4], cy0 = vp[VP_INV + 5];
+    const int ncar = N * 12;
+    int b = wave;
+    while (b < NBINS) {
       const int bxi = b % 12, byi = b / 12;
       const int ix = bxi * 8 + lx, iy = byi * 8 + ly;                 // GL pixel coords (origin bottom-left)
       const float cx = (float)ix + 0.5f, cy = (float)iy + 0.5f;
       uint32_t col = PAL_BLACK;
       if (byi >= 1) {                                                   // bin row 0 (y < 8) is entirely under the HUD bar
-        if (iy >= 12) {
-          const float wx = ax * cx + bx_ * cy + cx0, wy = ay * cx + by_ * cy + cy0;
-          if (fabsf(wx) <= PF && fabsf(wy) <= PF) {
-            const int gx = (int)floorf(wx / kgrid), gy = (int)floorf(wy / kgrid);
-            col = (((gx | gy) & 1) == 0) ? PAL_GRASS1 : PAL_GRASS0;
-          }
+        const float wx = ax * cx + bx_ * cy + cx0, wy = ay * cx + by_ * cy + cy0;
+        if (fabsf(wx) <= PF && fabsf(wy) <= PF) {
+          const int gx = (int)floorf(wx * inv_kgrid), gy = (int)floorf(wy * inv_kgrid);
+          col = (((gx | gy) & 1) == 0) ? PAL_GRASS1 : PAL_GRASS0;
         }
-        // road / kerbs: highest road_poly index covering the pixel wins (painter's order)
+        // highest draw index covering the pixel wins (painter's order): road_poly index, then car polygons
         const int cnt = bcnt[b];
         int best = -1;
         if (cnt <= BIN_CAP) {
           for (int k = 0; k < cnt; ++k) {
             const int s = bins[b][k];
-            const float* e = s < VIS_LDS ? qe[s] : spill + (size_t)(s - VIS_LDS) * 13;
-            const uint32_t inf = s < VIS_LDS ? qinfo[s] : __float_as_uint(e[12]);
-            const bool in = (e[0] * cx + e[1] * cy + e[2] >= 0.0f) && (e[3] * cx + e[4] * cy + e[5] >= 0.0f) &&
-                            (e[6] * cx + e[7] * cy + e[8] >= 0.0f) && (e[9] * cx + e[10] * cy + e[11] >= 0.0f);
-            const int key = (int)(inf & 0xffffu);
-            if (in && key > best) best = key;
+            if (s >= CAR_KEY) {
+              const float4* r = &car8[(s - CAR_KEY) * 6];
+              const bool in = inside4(r[0], r[1], r[2], cx, cy) && inside4(r[3], r[4], r[5], cx, cy);
+              const int key = (s << 5) | (int)(cinfo[s - CAR_KEY] & 31u);
+              if (in && key > best) best = key;
+            } else if (s < VIS_LDS) {
+              const int key = (int)qinfo[s] << 2;                        // (q << 5) | colour << 2
+              if (inside4(qe[s][0], qe[s][1], qe[s][2], cx, cy) && key > best && !(dbg & 2)) best = key;
+            } else {
+              const float4* d = (const float4*)(spill + (size_t)(s - VIS_LDS) * 16);
+              const int key = (int)__float_as_uint(d[3].x) << 2;
+              if (inside4(d[0], d[1], d[2], cx, cy) && key > best) best = key;
+            }
           }
         } else {
-          for (int s = 0; s < nq; ++s) {
-            const float* e = s < VIS_LDS ? qe[s] : spill + (size_t)(s - VIS_LDS) * 13;
-            const uint32_t inf = s < VIS_LDS ? qinfo[s] : __float_as_uint(e[12]);
-            const bool in = (e[0] * cx + e[1] * cy + e[2] >= 0.0f) && (e[3] * cx + e[4] * cy + e[5] >= 0.0f) &&
-                            (e[6] * cx + e[7] * cy + e[8] >= 0.0f) && (e[9] * cx + e[10] * cy + e[11] >= 0.0f);
-            const int key = (int)(inf & 0xffffu);
-            if (in && key > best) best = key;
+          for (int s = 0; s < nq_lds; ++s) {
+            const int key = (int)qinfo[s] << 2;
+            if (inside4(qe[s][0], qe[s][1], qe[s][2], cx, cy) && key > best) best = key;
+          }
+          for (int s = VIS_LDS; s < nq; ++s) {
+            const float4* d = (const float4*)(spill + (size_t)(s - VIS_LDS) * 16);
+            const int key = (int)__float_as_uint(d[3].x) << 2;
+            if (inside4(d[0], d[1], d[2], cx, cy) && key > best) best = key;
+          }
+          for (int k = 0; k < ncar; ++k) {
+            const uint32_t ci2 = cinfo[k];
+            if (!ci2) continue;
+            const float4* r = &car8[k * 6];
+            const int key = ((CAR_KEY + k) << 5) | (int)(ci2 & 31u);
+            if (inside4(r[0], r[1], r[2], cx, cy) && inside4(r[3], r[4], r[5], cx, cy) && key > best) best = key;
           }
         }
-        if (best >= 0 && iy >= 12) {
-          const uint32_t bc = (uint32_t)best & 7u;
-          col = bc == MCR_COL_ROAD0 ? PAL_ROAD0 : bc == MCR_COL_ROAD1 ? PAL_ROAD1 : bc == MCR_COL_ROAD2 ? PAL_ROAD2 : bc == MCR_COL_KERB_WHITE ? PAL_WHITE : PAL_RED255;
-        }
-        // cars
-        const float BX0 = (float)(bxi * 8) + 1000.0f, BX1 = BX0 + 8.0f, BY0 = (float)(byi * 8) + 1000.0f, BY1 = BY0 + 8.0f;
-        for (int c = 0; c < N; ++c) {
-          if (carbox[c][0] > BX1 || carbox[c][1] < BX0 || carbox[c][2] > BY1 || carbox[c][3] < BY0) continue;
-          for (int k = c * 12; k < c * 12 + 12; ++k) {
-            const uint32_t inf = cinfo[k];
-            if (!inf) continue;
-            if (cx < cbb[k][0] || cx > cbb[k][1] || cy < cbb[k][2] || cy > cbb[k][3]) continue;
-            const int n = (int)((inf >> 8) & 0xffu);
-            bool in = true;
-            for (int i = 0; i < n; ++i) in = in && (ce[k][i * 3] * cx + ce[k][i * 3 + 1] * cy + ce[k][i * 3 + 2] >= 0.0f);
-            if (in && iy >= 12) col = inf & 0xffu;
+        if (best >= 0) {
+          if (best >= (CAR_KEY << 5)) col = (uint32_t)best & 31u;
+          else {
+            const uint32_t bc = ((uint32_t)best >> 2) & 7u;
+            col = bc == MCR_COL_ROAD0 ? PAL_ROAD0 : bc == MCR_COL_ROAD1 ? PAL_ROAD1 : bc == MCR_COL_ROAD2 ? PAL_ROAD2 : bc == MCR_COL_KERB_WHITE ? PAL_WHITE : PAL_RED255;
           }
         }
+        if (iy < 12) col = PAL_BLACK;                                   // the HUD bar (window y < 100) covers the scene
       }
-      if (cy < hud_top) {
-        // HUD (window space, drawn last): bar rows are already black; gauges in draw order (a tall gauge may
-        // poke above the bar), then the backwards flag
+      if ((float)(byi * 8) < hud_top && cy < hud_top) {
+        // HUD (window space, drawn last): gauges in draw order (a tall gauge may poke above the bar), then the flag
+        const uint32_t ind_col[7] = {PAL_WHITE, PAL_BLUE255, PAL_BLUE255, PAL_PURPLE, PAL_PURPLE, PAL_GREEN255, PAL_RED255};
 #pragma unroll
-        for (int i = 0; i < 7; ++i)
-          if (ind_x1[i] > ind_x0[i] && ind_y1[i] > ind_y0[i] && cx >= ind_x0[i] && cx <= ind_x1[i] && cy >= ind_y0[i] && cy <= ind_y1[i]) col = ind_col[i];
+        for (int i = 0; i < 7; ++i) {
+          const float x0 = vp[VP_IND + i * 4], x1 = vp[VP_IND + i * 4 + 1], y0 = vp[VP_IND + i * 4 + 2], y1 = vp[VP_IND + i * 4 + 3];
+          if (x1 > x0 && y1 > y0 && cx >= x0 && cx <= x1 && cy >= y0 && cy <= y1) col = ind_col[i];
+        }
         if (show_flag && (fe[0] * cx + fe[1] * cy + fe[2] >= 0.0f) && (fe[3] * cx + fe[4] * cy + fe[5] >= 0.0f) && (fe[6] * cx + fe[7] * cy + fe[8] >= 0.0f)) col = PAL_BLUE255;
       }
       fb[(95 - iy) * 96 + ix] = (uint8_t)col;                          // arr[::-1] (:602)
+      int nb = 0;
+      if (lane == 0) nb = atomicAdd(&next_bin, 1);
+      b = __shfl(nb, 0);
     }
   }
   __syncthreads();
+  if (dbg & 8) return;
 
   // ---- packed RGB write-out: 16 B per lane = 6 pixels' worth of bytes in one of three phases
-  uint4* out = (uint4*)(p.obs + (size_t)vw * (96 * 96 * 3));
+  uint4* __restrict__ out = (uint4*)(p.obs + (size_t)vw * (96 * 96 * 3));
   for (int ch = tid; ch < 96 * 96 * 3 / 16; ch += VIEW_THREADS) {
     const int o = ch * 16; const int p0 = o / 3; const int ph = o - p0 * 3;
     uint32_t c[6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) { const int pi = p0 + j; c[j] = pal[fb[pi < 96 * 96 ? pi : 96 * 96 - 1]]; }
+    for (int j = 0; j < 6; ++j) c[j] = pal[fb[p0 + j]];
     uint32_t w0, w1, w2, w3;
     if (ph == 0) { w0 = c[0] | (c[1] << 24); w1 = (c[1] >> 8) | (c[2] << 16); w2 = (c[2] >> 16) | (c[3] << 8); w3 = c[4] | (c[5] << 24); }
     else if (ph == 1) { w0 = (c[0] >> 8) | (c[1] << 16); w1 = (c[1] >> 16) | (c[2] << 8); w2 = c[3] | (c[4] << 24); w3 = (c[4] >> 8) | (c[5] << 16); }

@@ -65,6 +65,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   const size_t o_tflags = carve(sizeof(uint16_t) * MCR_TILE_CAP * (size_t)B);
   const size_t o_cc = carve(sizeof(uint32_t) * (size_t)B * (MCR_CC_MAX * MCR_CC_WORDS + 4));
   const size_t o_shapes = carve(sizeof(McrShapes));
+  const size_t o_viewp = carve(sizeof(float) * MCR_VIEWP_FLOATS * BN);
   const size_t o_vscratch = carve(sizeof(float) * (size_t)VIEW_SCRATCH_FLOATS * BN);
   const size_t o_slots = carve((size_t)B * 2 * MCR_SLOT_BYTES);
   h->slab_bytes = off;
@@ -78,6 +79,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   P.env = (McrEnvState*)(base + o_env); P.tile_touch = (uint32_t*)(base + o_touch); P.tile_flags = (uint16_t*)(base + o_tflags);
   P.cc_store = (uint32_t*)(base + o_cc); P.shapes = (const McrShapes*)(base + o_shapes); P.slots = base + o_slots;
   h->view_scratch = (float*)(base + o_vscratch);
+  P.viewp = (float*)(base + o_viewp);
   P.auto_reset = cfg->auto_reset; P.max_steps = cfg->max_episode_steps; P.car_contacts = cfg->car_contacts;
   P.backwards_flag = cfg->backwards_flag; P.use_ego_color = cfg->use_ego_color; P.h_ratio = cfg->h_ratio;
   McrShapes S; mcr_build_shapes(&S);
@@ -129,11 +131,12 @@ static hipEvent_t get_event(mcr_env* h) {
   if (!h->free_events.empty()) { hipEvent_t e = h->free_events.back(); h->free_events.pop_back(); return e; }
   hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
-#define LAUNCH(kid_, kernel, grid, block, st, ...)                                         \
+#define LAUNCH(kid_, kernel, grid, block, st, ...) LAUNCH_LDS(kid_, kernel, grid, block, 0, st, __VA_ARGS__)
+#define LAUNCH_LDS(kid_, kernel, grid, block, lds_, st, ...)                                         \
   do {                                                                                   \
     TimedLaunch tl_; bool tm_ = (h->timing >> (kid_)) & 1;                                              \
     if (tm_) { tl_.id = (kid_); tl_.a = get_event(h); tl_.b = get_event(h); (void)hipEventRecord(tl_.a, st); } \
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, st, __VA_ARGS__);             \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds_, st, __VA_ARGS__);          \
     if (tm_) { (void)hipEventRecord(tl_.b, st); h->pending.push_back(tl_); }                   \
   } while (0)
 
@@ -142,7 +145,7 @@ static int run_reset_tail(mcr_env* h, McrParams& P, hipStream_t st, bool only_ju
   const int dyn_blocks = (B * P.G + 63) / 64;
   LAUNCH(0, k_collide, B, 64, st, P, 1);
   LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 1);
-  if (P.obs) LAUNCH(2, k_view, B * N, VIEW_THREADS, st, P, h->view_scratch, 0, only_just_reset ? 1 : 0);
+  if (P.obs) LAUNCH_LDS(2, k_view, B * N, VIEW_THREADS, (size_t)N * 12 * 6 * 16, st, P, h->view_scratch, 0, only_just_reset ? 1 : 0);
   return MCR_OK;
 }
 
@@ -174,7 +177,7 @@ extern "C" int mcr_step(mcr_env* h, const float* d_actions, uint8_t* d_obs, doub
     LAUNCH(0, k_collide, B, 64, st, P, 1);
     LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 1);
   }
-  LAUNCH(2, k_view, B * N, VIEW_THREADS, st, P, h->view_scratch, d_actions ? 1 : 0, 0);
+  LAUNCH_LDS(2, k_view, B * N, VIEW_THREADS, (size_t)N * 12 * 6 * 16, st, P, h->view_scratch, d_actions ? 1 : 0, 0);
   HIPCHK(hipGetLastError());
   return MCR_OK;
 }
@@ -291,6 +294,7 @@ extern "C" int mcr_sincos_device(mcr_env* h, const float* d_in, float* d_sin, fl
   return MCR_OK;
 }
 
+extern "C" int mcr_debug_set(mcr_env* h, int value) { if (!h) return MCR_ERR_ARG; h->P.debug = value; return MCR_OK; }
 extern "C" int mcr_timing_enable(mcr_env* h, int enable) { if (!h) return MCR_ERR_ARG; h->timing = enable; return MCR_OK; }
 extern "C" int mcr_timing_read(mcr_env* h, double* ms_out, int64_t* launches_out) {
   if (!h) return MCR_ERR_ARG;

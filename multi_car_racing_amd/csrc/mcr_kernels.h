@@ -14,6 +14,7 @@ struct McrParams {
   uint16_t* tile_flags;         // [B][TILE_CAP]  bits 0..7 road_visited[car], bit 8 recoloured
   uint32_t* cc_store;           // [B][...] car<->car manifold store (warm starting)
   const McrShapes* shapes;
+  float* viewp;                 // [BN][MCR_VIEWP_FLOATS] per-car camera + HUD geometry, written by k_dynamics, read by k_view
   int32_t* consumed_host;       // [B] mapped host memory: episode counter of the last install
   // step I/O
   const float* actions;         // [B,N,3] or null
@@ -23,8 +24,13 @@ struct McrParams {
   uint8_t* trunc_out;           // [B] or null
   const uint8_t* reset_mask;    // [B] or null (k_install)
   int32_t auto_reset, max_steps, car_contacts, backwards_flag, use_ego_color;
+  int32_t debug;                // ablation switches for profiling (0 in production)
   double h_ratio;
 };
+
+// per-car view parameters (f32): camera (:540-556) and HUD rectangles (:634-674) in pixel units
+#define MCR_VIEWP_FLOATS 48
+enum { VP_CAM = 0 /*m00 m01 m10 m11 tx ty*/, VP_INV = 6 /*ax bx cx0 ay by cy0*/, VP_IND = 12 /*7 x (x0 x1 y0 y1)*/, VP_HUDTOP = 40 };
 
 #define MCR_CC_MAX 24           // touching car<->car fixture pairs kept per env (warm start)
 #define MCR_CC_WORDS 20         // u32 words per stored manifold

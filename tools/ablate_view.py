@@ -1,0 +1,27 @@
+"""Within-process ablation of the raster kernel (mcr_debug_set bits) -> per-phase cost. Not a test."""
+import sys, os, ctypes, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from multi_car_racing_amd.vec_env import VecMultiCarRacing
+from multi_car_racing_amd import _lib
+
+B, N = int(os.environ.get("B", 4096)), int(os.environ.get("N", 2))
+env = VecMultiCarRacing(B, N, seed=1, use_random_direction=True, auto_reset=True)
+env.reset()
+act = torch.rand((B, N, 3), device="cuda"); act[..., 0] = act[..., 0] * 2 - 1
+for _ in range(80): env.step(act)
+torch.cuda.synchronize()
+names = {0: "full", 1: "-flags", 2: "-road shade", 4: "-cars", 8: "-writeout", 16: "-cull", 31: "-all", 18: "-cull-road", 26: "-cull-road-writeout"}
+res = {}
+for rnd in range(3):
+    for mask in names:
+        _lib.check(env.L.mcr_debug_set(env.h, mask))
+        env.timing(7)
+        for _ in range(30): env.step(act)
+        ms, n = env.timing_read(); env.timing(0)
+        res.setdefault(mask, []).append(ms / np.maximum(n, 1))
+_lib.check(env.L.mcr_debug_set(env.h, 0))
+for mask, v in res.items():
+    v = np.array(v)
+    print(f"{names[mask]:>22}: view {np.median(v[:,2])*1e3:8.1f} us   collide {np.median(v[:,0])*1e3:6.1f} us  dynamics {np.median(v[:,1])*1e3:6.1f} us")
+env.close()
