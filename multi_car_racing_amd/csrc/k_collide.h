@@ -13,6 +13,7 @@
 // distance < 10*FLT_EPSILON): SAT for penetration / early-out, exact vertex-edge distance otherwise.
 #pragma once
 #include "mcr_kernels.h"
+#include "k_carcontacts.h"
 
 namespace col {
 
@@ -86,6 +87,8 @@ __global__ __launch_bounds__(64) void k_collide(McrParams p, int pass) {
   __shared__ float fvx[64][8], fvy[64][8], fnx[64][8], fny[64][8];
   __shared__ int fcnt[64];
   __shared__ float cbox[MCR_MAX_AGENTS][4];
+  __shared__ float4 fxf[64], fbox[64];                 // per fixture: body transform (p.x p.y s c), world AABB +-0.05
+  __shared__ uint32_t newrec[MCR_CC_MAX][16];
   {
     const int c = lane >> 3, fi = lane & 7;
     float lox = MCR_MAXFLT, loy = MCR_MAXFLT, hix = -MCR_MAXFLT, hiy = -MCR_MAXFLT;
@@ -99,12 +102,14 @@ __global__ __launch_bounds__(64) void k_collide(McrParams p, int pass) {
       V2 lc = body == 0 ? v2(S.hull_lcx, S.hull_lcy) : v2(0.0f, 0.0f);
       Xf xf = xf_of(cc, a, lc);
       fcnt[lane] = P.n;
+      fxf[lane] = make_float4(xf.p.x, xf.p.y, xf.q.s, xf.q.c);
       for (int i = 0; i < P.n; ++i) {
         V2 w = xmul(xf, v2(P.vx[i], P.vy[i]));
         V2 n = rmul(xf.q, v2(P.nx[i], P.ny[i]));
         fvx[lane][i] = w.x; fvy[lane][i] = w.y; fnx[lane][i] = n.x; fny[lane][i] = n.y;
         lox = mcr_min(lox, w.x); loy = mcr_min(loy, w.y); hix = mcr_max(hix, w.x); hiy = mcr_max(hiy, w.y);
       }
+      fbox[lane] = make_float4(lox - 0.05f, loy - 0.05f, hix + 0.05f, hiy + 0.05f);
     } else fcnt[lane] = 0;
     for (int o = 1; o < 8; o <<= 1) {
       lox = mcr_min(lox, __shfl_xor(lox, o)); loy = mcr_min(loy, __shfl_xor(loy, o));
@@ -185,4 +190,71 @@ __global__ __launch_bounds__(64) void k_collide(McrParams p, int pass) {
     p.card[CD_REWARD * BN + ci] = r;
     p.caru[CU_TVC * BN + ci] = (uint32_t)tv;
   }
+
+  // ---- car<->car manifolds (b2Contact::Update for the dynamic pairs) at the same entry poses.
+  // Candidate fixture pairs are enumerated in the DEFINED contact order (carA, fixA, carB, fixB); touching
+  // ones are compacted in that order and inherit the stored impulses of the previous step by feature id.
+  uint32_t* store = p.cc_store + (size_t)env * (MCR_CC_MAX * MCR_CC_WORDS + 4);
+  if (p.car_contacts && N > 1) {
+    const int old_n = (pass == 1) ? 0 : (int)store[0];
+    const McrShapes& S = *p.shapes;
+    int total = 0;
+    for (int a = 0; a < N - 1; ++a) total += 64 * (N - 1 - a);
+    int base = 0;
+    for (int r0 = 0; r0 < total; r0 += 64) {
+      const int idx = r0 + lane;
+      bool valid = idx < total;
+      int a = 0, fa = 0, b = 1, fb = 0;
+      if (valid) {
+        int r = idx;
+        for (a = 0; a < N - 1; ++a) { const int cnt = 64 * (N - 1 - a); if (r < cnt) break; r -= cnt; }
+        const int per_fa = (N - 1 - a) * 8;
+        fa = r / per_fa; const int r2 = r - fa * per_fa;
+        b = a + 1 + (r2 >> 3); fb = r2 & 7;
+        if (fa >= 4 && fb >= 4) valid = false;                            // wheel (0x20, mask 1) vs wheel: filtered
+      }
+      cc::Manifold M; M.n = 0; M.type = 0; M.pl[0] = M.pl[1] = v2(0.0f, 0.0f); M.id[0] = M.id[1] = 0; M.localNormal = M.localPoint = v2(0.0f, 0.0f);
+      if (valid) {
+        const int ia = a * 8 + fa, ib = b * 8 + fb;
+        const float4 A = fbox[ia], Bb = fbox[ib];
+        if (!(A.x > Bb.z || A.z < Bb.x || A.y > Bb.w || A.w < Bb.y)) {
+          cc::LPoly pa, pb;
+          cc::load_poly(fa < 4 ? S.hull[fa] : S.wheel, pa); cc::load_poly(fb < 4 ? S.hull[fb] : S.wheel, pb);
+          Xf xa, xb; const float4 ta = fxf[ia], tb = fxf[ib];
+          xa.p = v2(ta.x, ta.y); xa.q.s = ta.z; xa.q.c = ta.w; xb.p = v2(tb.x, tb.y); xb.q.s = tb.z; xb.q.c = tb.w;
+          cc::collide_polygons(M, pa, xa, pb, xb);
+        }
+      }
+      const bool hit = valid && M.n > 0;
+      const unsigned long long mask = __ballot(hit);
+      if (hit) {
+        const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+        if (slot < MCR_CC_MAX) {
+          const uint32_t key = (uint32_t)a | ((uint32_t)fa << 4) | ((uint32_t)b << 8) | ((uint32_t)fb << 12);
+          float ni[2] = {0.0f, 0.0f}, ti[2] = {0.0f, 0.0f};
+          for (int j = 0; j < old_n; ++j) {
+            const uint32_t* o = store + 4 + j * MCR_CC_WORDS;
+            if (o[0] != key) continue;
+            const int on = (int)(o[1] >> 8);
+            for (int i = 0; i < M.n; ++i)
+              for (int jj = 0; jj < on; ++jj)
+                if (o[6 + jj * 5 + 4] == M.id[i]) { ni[i] = __uint_as_float(o[6 + jj * 5 + 2]); ti[i] = __uint_as_float(o[6 + jj * 5 + 3]); break; }
+          }
+          uint32_t* d = newrec[slot];
+          d[0] = key; d[1] = (uint32_t)M.type | ((uint32_t)M.n << 8);
+          d[2] = __float_as_uint(M.localNormal.x); d[3] = __float_as_uint(M.localNormal.y);
+          d[4] = __float_as_uint(M.localPoint.x); d[5] = __float_as_uint(M.localPoint.y);
+          for (int i = 0; i < 2; ++i) {
+            d[6 + i * 5 + 0] = __float_as_uint(M.pl[i].x); d[6 + i * 5 + 1] = __float_as_uint(M.pl[i].y);
+            d[6 + i * 5 + 2] = __float_as_uint(ni[i]); d[6 + i * 5 + 3] = __float_as_uint(ti[i]); d[6 + i * 5 + 4] = M.id[i];
+          }
+        }
+      }
+      base += __popcll(mask);
+    }
+    __syncthreads();
+    const int nn = base < MCR_CC_MAX ? base : MCR_CC_MAX;
+    for (int i = lane; i < nn * 16; i += 64) store[4 + (i >> 4) * MCR_CC_WORDS + (i & 15)] = newrec[i >> 4][i & 15];
+    if (lane == 0) { store[0] = (uint32_t)nn; store[1] = base > MCR_CC_MAX ? 1u : 0u; }
+  } else if (lane == 0 && pass == 1) store[0] = 0;
 }

@@ -12,6 +12,7 @@
 // 4- or 8-byte access per SoA field per lane.
 #pragma once
 #include "mcr_kernels.h"
+#include "k_carcontacts.h"
 
 namespace dyn {
 
@@ -166,12 +167,218 @@ __device__ __forceinline__ bool joint_position(const Joint& J, Body& A, Body& B,
 
 __device__ __forceinline__ double np_sign(double x) { return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : 0.0); }
 
+// ---------------------------------------------------------------------------------------------------------
+// car<->car contact constraints, executed by the env's leader lane on LDS-resident body state.
+// xs[comp*5 + body][lane]: comp 0..2 = (vx, vy, w) or (cx, cy, a) of `body` of the car owned by `lane`.
+#define DYN_VC_POOL 48
+__device__ __forceinline__ void cc_masses(const McrShapes& S, int body, float& m, float& i, V2& lc) {
+  if (body == 0) { m = S.hull_invMass; i = S.hull_invI; lc = v2(S.hull_lcx, S.hull_lcy); }
+  else { m = S.wheel_invMass; i = S.wheel_invI; lc = v2(0.0f, 0.0f); }
+}
+// b2ContactSolver ctor + InitializeVelocityConstraints + WarmStart for one stored manifold
+__device__ inline void cc_init(const McrShapes& S, const uint32_t* rec, int rec_index, int leader_lane, float (*xp)[64], float (*xv)[64], float* vc) {
+  const uint32_t key = rec[0];
+  const int carA = key & 15, fixA = (key >> 4) & 15, carB = (key >> 8) & 15, fixB = (key >> 12) & 15;
+  const int bA = cc::fixture_body(fixA), bB = cc::fixture_body(fixB);
+  const int LA = leader_lane + carA, LB = leader_lane + carB;
+  const int type = rec[1] & 255; int n = (int)(rec[1] >> 8);
+  float mA, iA, mB, iB; V2 lcA, lcB; cc_masses(S, bA, mA, iA, lcA); cc_masses(S, bB, mB, iB, lcB);
+  const V2 cA = v2(xp[0 * 5 + bA][LA], xp[1 * 5 + bA][LA]); const float aA = xp[2 * 5 + bA][LA];
+  const V2 cB = v2(xp[0 * 5 + bB][LB], xp[1 * 5 + bB][LB]); const float aB = xp[2 * 5 + bB][LB];
+  Xf xfA, xfB; xfA.q = rot_of(aA); xfB.q = rot_of(aB);
+  xfA.p = cA - rmul(xfA.q, lcA); xfB.p = cB - rmul(xfB.q, lcB);
+  const V2 localNormal = v2(__uint_as_float(rec[2]), __uint_as_float(rec[3])), localPoint = v2(__uint_as_float(rec[4]), __uint_as_float(rec[5]));
+  // b2WorldManifold::Initialize
+  V2 normal, pts[2];
+  const float rA_ = B2_POLYGON_RADIUS, rB_ = B2_POLYGON_RADIUS;
+  if (type == 1) {
+    normal = rmul(xfA.q, localNormal);
+    const V2 planePoint = xmul(xfA, localPoint);
+    for (int j = 0; j < n; ++j) {
+      const V2 clip = xmul(xfB, v2(__uint_as_float(rec[6 + j * 5]), __uint_as_float(rec[6 + j * 5 + 1])));
+      const V2 pa = clip + (rA_ - dot(clip - planePoint, normal)) * normal;
+      const V2 pb = clip - rB_ * normal;
+      pts[j] = 0.5f * (pa + pb);
+    }
+  } else {
+    normal = rmul(xfB.q, localNormal);
+    const V2 planePoint = xmul(xfB, localPoint);
+    for (int j = 0; j < n; ++j) {
+      const V2 clip = xmul(xfA, v2(__uint_as_float(rec[6 + j * 5]), __uint_as_float(rec[6 + j * 5 + 1])));
+      const V2 pb = clip + (rB_ - dot(clip - planePoint, normal)) * normal;
+      const V2 pa = clip - rA_ * normal;
+      pts[j] = 0.5f * (pa + pb);
+    }
+    normal = -normal;
+  }
+  const V2 tangent = cross(normal, 1.0f);
+  for (int j = 0; j < 2; ++j) {
+    float* q = vc + (j == 0 ? cc::VC_P0 : cc::VC_P1);
+    if (j < n) {
+      const V2 rA = pts[j] - cA, rB = pts[j] - cB;
+      const float rnA = cross(rA, normal), rnB = cross(rB, normal);
+      const float kN = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+      const float rtA = cross(rA, tangent), rtB = cross(rB, tangent);
+      const float kT = mA + mB + iA * rtA * rtA + iB * rtB * rtB;
+      q[0] = rA.x; q[1] = rA.y; q[2] = rB.x; q[3] = rB.y;
+      q[4] = 1.0f * __uint_as_float(rec[6 + j * 5 + 2]); q[5] = 1.0f * __uint_as_float(rec[6 + j * 5 + 3]);
+      q[6] = kN > 0.0f ? 1.0f / kN : 0.0f; q[7] = kT > 0.0f ? 1.0f / kT : 0.0f;
+    } else { for (int t = 0; t < 8; ++t) q[t] = 0.0f; }
+  }
+  if (n == 2) {
+    const float* p0 = vc + cc::VC_P0; const float* p1 = vc + cc::VC_P1;
+    const float rn1A = cross(v2(p0[0], p0[1]), normal), rn1B = cross(v2(p0[2], p0[3]), normal);
+    const float rn2A = cross(v2(p1[0], p1[1]), normal), rn2B = cross(v2(p1[2], p1[3]), normal);
+    const float k11 = mA + mB + iA * rn1A * rn1A + iB * rn1B * rn1B;
+    const float k22 = mA + mB + iA * rn2A * rn2A + iB * rn2B * rn2B;
+    const float k12 = mA + mB + iA * rn1A * rn2A + iB * rn1B * rn2B;
+    if (k11 * k11 < 1000.0f * (k11 * k22 - k12 * k12)) {
+      vc[cc::VC_K11] = k11; vc[cc::VC_K12] = k12; vc[cc::VC_K22] = k22;
+      float det = k11 * k22 - k12 * k12; if (det != 0.0f) det = 1.0f / det;
+      vc[cc::VC_NM11] = det * k22; vc[cc::VC_NM12] = -det * k12; vc[cc::VC_NM22] = det * k11;
+    } else n = 1;
+  }
+  vc[cc::VC_NX] = normal.x; vc[cc::VC_NY] = normal.y;
+  ((int*)vc)[cc::VC_N] = n; ((int*)vc)[cc::VC_LA] = LA * 8 + bA; ((int*)vc)[cc::VC_LB] = LB * 8 + bB; ((int*)vc)[cc::VC_REC] = rec_index;
+  // WarmStart
+  V2 vA = v2(xv[0 * 5 + bA][LA], xv[1 * 5 + bA][LA]); float wA = xv[2 * 5 + bA][LA];
+  V2 vB = v2(xv[0 * 5 + bB][LB], xv[1 * 5 + bB][LB]); float wB = xv[2 * 5 + bB][LB];
+  for (int j = 0; j < n; ++j) {
+    const float* q = vc + (j == 0 ? cc::VC_P0 : cc::VC_P1);
+    const V2 P = q[4] * normal + q[5] * tangent;
+    wA -= iA * cross(v2(q[0], q[1]), P); vA = vA - mA * P;
+    wB += iB * cross(v2(q[2], q[3]), P); vB = vB + mB * P;
+  }
+  xv[0 * 5 + bA][LA] = vA.x; xv[1 * 5 + bA][LA] = vA.y; xv[2 * 5 + bA][LA] = wA;
+  xv[0 * 5 + bB][LB] = vB.x; xv[1 * 5 + bB][LB] = vB.y; xv[2 * 5 + bB][LB] = wB;
+}
+
+// b2ContactSolver::SolveVelocityConstraints for one contact
+__device__ inline void cc_velocity(const McrShapes& S, float* vc, float (*xv)[64]) {
+  const int n = ((int*)vc)[cc::VC_N];
+  const int sa = ((int*)vc)[cc::VC_LA], sb = ((int*)vc)[cc::VC_LB];
+  const int LA = sa >> 3, bA = sa & 7, LB = sb >> 3, bB = sb & 7;
+  float mA, iA, mB, iB; V2 lcA, lcB; cc_masses(S, bA, mA, iA, lcA); cc_masses(S, bB, mB, iB, lcB);
+  V2 vA = v2(xv[0 * 5 + bA][LA], xv[1 * 5 + bA][LA]); float wA = xv[2 * 5 + bA][LA];
+  V2 vB = v2(xv[0 * 5 + bB][LB], xv[1 * 5 + bB][LB]); float wB = xv[2 * 5 + bB][LB];
+  const V2 normal = v2(vc[cc::VC_NX], vc[cc::VC_NY]); const V2 tangent = cross(normal, 1.0f);
+  const float friction = sqrtf(0.2f * 0.2f);
+  for (int j = 0; j < n; ++j) {
+    float* q = vc + (j == 0 ? cc::VC_P0 : cc::VC_P1);
+    const V2 rA = v2(q[0], q[1]), rB = v2(q[2], q[3]);
+    const V2 dv = vB + cross(wB, rB) - vA - cross(wA, rA);
+    const float vt = dot(dv, tangent) - 0.0f;
+    float lambda = q[7] * (-vt);
+    const float maxF = friction * q[4];
+    const float newImp = mcr_clamp(q[5] + lambda, -maxF, maxF);
+    lambda = newImp - q[5]; q[5] = newImp;
+    const V2 P = lambda * tangent;
+    vA = vA - mA * P; wA -= iA * cross(rA, P);
+    vB = vB + mB * P; wB += iB * cross(rB, P);
+  }
+  if (n == 1) {
+    float* q = vc + cc::VC_P0;
+    const V2 rA = v2(q[0], q[1]), rB = v2(q[2], q[3]);
+    const V2 dv = vB + cross(wB, rB) - vA - cross(wA, rA);
+    const float vn = dot(dv, normal);
+    float lambda = -q[6] * (vn - 0.0f);
+    const float newImp = mcr_max(q[4] + lambda, 0.0f);
+    lambda = newImp - q[4]; q[4] = newImp;
+    const V2 P = lambda * normal;
+    vA = vA - mA * P; wA -= iA * cross(rA, P);
+    vB = vB + mB * P; wB += iB * cross(rB, P);
+  } else if (n == 2) {
+    float* q1 = vc + cc::VC_P0; float* q2 = vc + cc::VC_P1;
+    const V2 r1A = v2(q1[0], q1[1]), r1B = v2(q1[2], q1[3]), r2A = v2(q2[0], q2[1]), r2B = v2(q2[2], q2[3]);
+    const V2 a = v2(q1[4], q2[4]);
+    const V2 dv1 = vB + cross(wB, r1B) - vA - cross(wA, r1A);
+    const V2 dv2 = vB + cross(wB, r2B) - vA - cross(wA, r2A);
+    float vn1 = dot(dv1, normal), vn2 = dot(dv2, normal);
+    const float k11 = vc[cc::VC_K11], k12 = vc[cc::VC_K12], k22 = vc[cc::VC_K22];
+    const float nm11 = vc[cc::VC_NM11], nm12 = vc[cc::VC_NM12], nm22 = vc[cc::VC_NM22];
+    V2 b = v2(vn1 - 0.0f, vn2 - 0.0f);
+    b = b - v2(k11 * a.x + k12 * a.y, k12 * a.x + k22 * a.y);
+    V2 x; bool ok = false;
+    for (;;) {
+      x = -v2(nm11 * b.x + nm12 * b.y, nm12 * b.x + nm22 * b.y);
+      if (x.x >= 0.0f && x.y >= 0.0f) { ok = true; break; }
+      x.x = -q1[6] * b.x; x.y = 0.0f; vn1 = 0.0f; vn2 = k12 * x.x + b.y;
+      if (x.x >= 0.0f && vn2 >= 0.0f) { ok = true; break; }
+      x.x = 0.0f; x.y = -q2[6] * b.y; vn1 = k12 * x.y + b.x; vn2 = 0.0f;
+      if (x.y >= 0.0f && vn1 >= 0.0f) { ok = true; break; }
+      x.x = 0.0f; x.y = 0.0f; vn1 = b.x; vn2 = b.y;
+      if (vn1 >= 0.0f && vn2 >= 0.0f) { ok = true; break; }
+      break;
+    }
+    if (ok) {
+      const V2 d = x - a;
+      const V2 P1 = d.x * normal, P2 = d.y * normal;
+      vA = vA - mA * (P1 + P2); wA -= iA * (cross(r1A, P1) + cross(r2A, P2));
+      vB = vB + mB * (P1 + P2); wB += iB * (cross(r1B, P1) + cross(r2B, P2));
+      q1[4] = x.x; q2[4] = x.y;
+    }
+  }
+  xv[0 * 5 + bA][LA] = vA.x; xv[1 * 5 + bA][LA] = vA.y; xv[2 * 5 + bA][LA] = wA;
+  xv[0 * 5 + bB][LB] = vB.x; xv[1 * 5 + bB][LB] = vB.y; xv[2 * 5 + bB][LB] = wB;
+}
+
+// b2ContactSolver::SolvePositionConstraints for one contact; returns its min separation
+__device__ inline float cc_position(const McrShapes& S, const uint32_t* rec, int leader_lane, float (*xp)[64]) {
+  const uint32_t key = rec[0];
+  const int carA = key & 15, fixA = (key >> 4) & 15, carB = (key >> 8) & 15, fixB = (key >> 12) & 15;
+  const int bA = cc::fixture_body(fixA), bB = cc::fixture_body(fixB);
+  const int LA = leader_lane + carA, LB = leader_lane + carB;
+  const int type = rec[1] & 255; const int n = (int)(rec[1] >> 8);
+  float mA, iA, mB, iB; V2 lcA, lcB; cc_masses(S, bA, mA, iA, lcA); cc_masses(S, bB, mB, iB, lcB);
+  V2 cA = v2(xp[0 * 5 + bA][LA], xp[1 * 5 + bA][LA]); float aA = xp[2 * 5 + bA][LA];
+  V2 cB = v2(xp[0 * 5 + bB][LB], xp[1 * 5 + bB][LB]); float aB = xp[2 * 5 + bB][LB];
+  const V2 localNormal = v2(__uint_as_float(rec[2]), __uint_as_float(rec[3])), localPoint = v2(__uint_as_float(rec[4]), __uint_as_float(rec[5]));
+  float minSep = 0.0f;
+  for (int j = 0; j < n; ++j) {
+    Xf xfA, xfB; xfA.q = rot_of(aA); xfB.q = rot_of(aB);
+    xfA.p = cA - rmul(xfA.q, lcA); xfB.p = cB - rmul(xfB.q, lcB);
+    const V2 lp = v2(__uint_as_float(rec[6 + j * 5]), __uint_as_float(rec[6 + j * 5 + 1]));
+    V2 normal, point; float separation;
+    if (type == 1) {
+      normal = rmul(xfA.q, localNormal);
+      const V2 planePoint = xmul(xfA, localPoint);
+      const V2 clip = xmul(xfB, lp);
+      separation = dot(clip - planePoint, normal) - B2_POLYGON_RADIUS - B2_POLYGON_RADIUS;
+      point = clip;
+    } else {
+      normal = rmul(xfB.q, localNormal);
+      const V2 planePoint = xmul(xfB, localPoint);
+      const V2 clip = xmul(xfA, lp);
+      separation = dot(clip - planePoint, normal) - B2_POLYGON_RADIUS - B2_POLYGON_RADIUS;
+      point = clip;
+      normal = -normal;
+    }
+    const V2 rA = point - cA, rB = point - cB;
+    minSep = mcr_min(minSep, separation);
+    const float C = mcr_clamp(B2_BAUMGARTE * (separation + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
+    const float rnA = cross(rA, normal), rnB = cross(rB, normal);
+    const float K = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+    const float impulse = K > 0.0f ? -C / K : 0.0f;
+    const V2 P = impulse * normal;
+    cA = cA - mA * P; aA -= iA * cross(rA, P);
+    cB = cB + mB * P; aB += iB * cross(rB, P);
+  }
+  xp[0 * 5 + bA][LA] = cA.x; xp[1 * 5 + bA][LA] = cA.y; xp[2 * 5 + bA][LA] = aA;
+  xp[0 * 5 + bB][LB] = cB.x; xp[1 * 5 + bB][LB] = cB.y; xp[2 * 5 + bB][LB] = aB;
+  return minSep;
+}
+
 }  // namespace dyn
 
 // mode 0: regular step (bookkeeping, TimeLimit, auto-reset install)
 // mode 1: the action-less step of reset() (:408) for envs whose `resetting` flag is set
 __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
   using namespace dyn;
+  // LDS used only by waves that contain a touching car<->car pair
+  __shared__ float xv[15][64], xp[15][64];            // body exchange: (vx,vy,w) / (cx,cy,a) x 5 bodies per lane
+  __shared__ float vcpool[DYN_VC_POOL][cc::VC_SIZE];
+  __shared__ int xisl[64], xact[64], xjok[64], xcok[64];
+  __shared__ float xms[64];
   const int g = blockIdx.x * 64 + threadIdx.x;
   const int env = g / p.G, agent = g % p.G;
   const bool lane_ok = env < p.B && agent < p.N;
@@ -281,14 +488,111 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
       b[k + 1].vx = b[k + 1].vx + h * (mW * (0.0f + fx[k])); b[k + 1].vy = b[k + 1].vy + h * (mW * (0.0f + fy[k]));
       b[k + 1].w += h * iW * 0.0f;
     }
+  }
+
+  // ---- car<->car contacts of this env (manifolds prepared by the collide kernel).  The common case — no
+  // touching pair in the whole wave — skips every contact block below with one wave-uniform branch.
+  const int lane = threadIdx.x;
+  const int leader_lane = lane - agent;
+  uint32_t* store = p.cc_store + (size_t)(env < p.B ? env : 0) * (MCR_CC_MAX * MCR_CC_WORDS + 4);
+  int ccn = 0;
+  if (run && p.car_contacts && p.N > 1) ccn = (int)store[0];
+  const bool wave_cc = __any(ccn > 0) != 0;
+  int pool_base = 0;
+  int isl = agent;                        // island id of this car = lowest car id linked to it by touching contacts
+  if (wave_cc) {
+    // LDS pool of velocity-constraint records: exclusive prefix sum of the leaders' needs across the wave
+    int need = (agent == 0) ? ccn : 0;
+    int incl = need;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    pool_base = incl - need;
+    if (agent == 0 && pool_base + ccn > DYN_VC_POOL) { ccn = DYN_VC_POOL - pool_base; if (ccn < 0) ccn = 0; store[1] = 2u; }
+    ccn = __shfl(ccn, leader_lane); pool_base = __shfl(pool_base, leader_lane);
+    if (ccn > 0) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        xv[0 * 5 + k][lane] = b[k].vx; xv[1 * 5 + k][lane] = b[k].vy; xv[2 * 5 + k][lane] = b[k].w;
+        xp[0 * 5 + k][lane] = b[k].cx; xp[1 * 5 + k][lane] = b[k].cy; xp[2 * 5 + k][lane] = b[k].a;
+      }
+    }
+    __syncthreads();
+    if (ccn > 0 && agent == 0) {
+      int root[MCR_MAX_AGENTS];
+#pragma unroll
+      for (int c = 0; c < MCR_MAX_AGENTS; ++c) root[c] = c;
+      for (int i = 0; i < ccn; ++i) {
+        const uint32_t* rec = store + 4 + i * MCR_CC_WORDS;
+        cc_init(S, rec, i, leader_lane, xp, xv, vcpool[pool_base + i]);
+        // union-find over cars (b2World::Solve island DFS through touching contacts)
+        const int ca = rec[0] & 15, cb = (rec[0] >> 8) & 15;
+        int ra = ca, rb = cb;
+        for (int t = 0; t < MCR_MAX_AGENTS; ++t) {
+          int na = ra, nb = rb;
+#pragma unroll
+          for (int c = 0; c < MCR_MAX_AGENTS; ++c) { if (c == ra) na = root[c]; if (c == rb) nb = root[c]; }
+          ra = na; rb = nb;
+        }
+        if (ra != rb) {
+          const int hi = ra > rb ? ra : rb, lo = ra > rb ? rb : ra;
+#pragma unroll
+          for (int c = 0; c < MCR_MAX_AGENTS; ++c) if (c == hi) root[c] = lo;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < MCR_MAX_AGENTS; ++c) {
+        int r = c;
+        for (int t = 0; t < MCR_MAX_AGENTS; ++t) {
+          int nr = r;
+#pragma unroll
+          for (int d = 0; d < MCR_MAX_AGENTS; ++d) if (d == r) nr = root[d];
+          r = nr;
+        }
+        if (c < p.N) xisl[leader_lane + c] = r;
+      }
+    }
+    __syncthreads();
+    if (ccn > 0) {
+      isl = xisl[lane];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) { b[k].vx = xv[0 * 5 + k][lane]; b[k].vy = xv[1 * 5 + k][lane]; b[k].w = xv[2 * 5 + k][lane]; }
+    }
+  }
+
+  bool positionSolved = false;
+  if (run) {
     // joints, island order 3,2,1,0
 #pragma unroll
     for (int q = 3; q >= 0; --q) joint_init(J[q], b[0], b[q + 1], S.anchor_x[q], S.anchor_y[q], lcx, lcy, mH, iH, mW, iW);
-    const float maxImpulse = h * (float)(180 * 900 * MCR_SIZE * MCR_SIZE);
-    for (int it = 0; it < 180; ++it) {
+  }
+  const float maxImpulse = h * (float)(180 * 900 * MCR_SIZE * MCR_SIZE);
+  for (int it = 0; it < 180; ++it) {
+    if (run) {
 #pragma unroll
       for (int q = 3; q >= 0; --q) joint_velocity(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);
     }
+    if (wave_cc) {
+      if (ccn > 0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { xv[0 * 5 + k][lane] = b[k].vx; xv[1 * 5 + k][lane] = b[k].vy; xv[2 * 5 + k][lane] = b[k].w; }
+      }
+      __syncthreads();
+      if (ccn > 0 && agent == 0) for (int i = 0; i < ccn; ++i) cc_velocity(S, vcpool[pool_base + i], xv);
+      __syncthreads();
+      if (ccn > 0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { b[k].vx = xv[0 * 5 + k][lane]; b[k].vy = xv[1 * 5 + k][lane]; b[k].w = xv[2 * 5 + k][lane]; }
+      }
+    }
+  }
+  if (wave_cc && ccn > 0 && agent == 0) {            // StoreImpulses
+    for (int i = 0; i < ccn; ++i) {
+      const float* vc = vcpool[pool_base + i];
+      uint32_t* rec = store + 4 + i * MCR_CC_WORDS;
+      const int n = ((const int*)vc)[cc::VC_N];
+      for (int j = 0; j < n; ++j) { const float* q = vc + (j == 0 ? cc::VC_P0 : cc::VC_P1); rec[6 + j * 5 + 2] = __float_as_uint(q[4]); rec[6 + j * 5 + 3] = __float_as_uint(q[5]); }
+    }
+  }
+  if (run) {
     // integrate positions
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -301,30 +605,95 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
       if (rot * rot > B2_MAX_ROTATION * B2_MAX_ROTATION) { float ratio = B2_MAX_ROTATION / fabsf(rot); b[k].w *= ratio; }
       b[k].cx = b[k].cx + h * b[k].vx; b[k].cy = b[k].cy + h * b[k].vy; b[k].a += h * b[k].w;
     }
-    // position iterations with early exit
-    bool positionSolved = false;
-    for (int it = 0; it < 60; ++it) {
-      bool ok = true;
+  }
+  // position iterations with the per-island early exit
+  if (!wave_cc) {
+    if (run) {
+      for (int it = 0; it < 60; ++it) {
+        bool ok = true;
 #pragma unroll
-      for (int q = 3; q >= 0; --q) {
-        bool jo = joint_position(J[q], b[0], b[q + 1], S.anchor_x[q], S.anchor_y[q], lcx, lcy, mH, iH, mW, iW);
-        ok = ok && jo;
+        for (int q = 3; q >= 0; --q) {
+          bool jo = joint_position(J[q], b[0], b[q + 1], S.anchor_x[q], S.anchor_y[q], lcx, lcy, mH, iH, mW, iW);
+          ok = ok && jo;
+        }
+        if (ok) { positionSolved = true; break; }
       }
-      if (ok) { positionSolved = true; break; }
     }
+  } else {
+    bool active = run;
+    for (int it = 0; it < 60; ++it) {
+      if (!__any(active)) break;
+      const bool in_cc = active && ccn > 0;
+      if (in_cc) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { xp[0 * 5 + k][lane] = b[k].cx; xp[1 * 5 + k][lane] = b[k].cy; xp[2 * 5 + k][lane] = b[k].a; }
+      }
+      xact[lane] = active ? 1 : 0;
+      __syncthreads();
+      if (ccn > 0 && agent == 0) {
+        // contacts of the still-iterating islands, in contact order; min separation per island
+        float minSep[MCR_MAX_AGENTS];
+#pragma unroll
+        for (int c = 0; c < MCR_MAX_AGENTS; ++c) minSep[c] = 0.0f;
+        for (int i = 0; i < ccn; ++i) {
+          const uint32_t* rec = store + 4 + i * MCR_CC_WORDS;
+          const int ca = rec[0] & 15;
+          const int r = xisl[leader_lane + ca];
+          if (!xact[leader_lane + r]) continue;
+          const float ms = cc_position(S, rec, leader_lane, xp);
+#pragma unroll
+          for (int c = 0; c < MCR_MAX_AGENTS; ++c) if (c == r) minSep[c] = mcr_min(minSep[c], ms);
+        }
+#pragma unroll
+        for (int c = 0; c < MCR_MAX_AGENTS; ++c) if (c < p.N) xcok[leader_lane + c] = (minSep[c] >= -3.0f * B2_LINEAR_SLOP) ? 1 : 0;
+      }
+      __syncthreads();
+      bool jointsOk = true;
+      if (active) {
+        if (in_cc) {
+#pragma unroll
+          for (int k = 0; k < 5; ++k) { b[k].cx = xp[0 * 5 + k][lane]; b[k].cy = xp[1 * 5 + k][lane]; b[k].a = xp[2 * 5 + k][lane]; }
+        }
+#pragma unroll
+        for (int q = 3; q >= 0; --q) {
+          bool jo = joint_position(J[q], b[0], b[q + 1], S.anchor_x[q], S.anchor_y[q], lcx, lcy, mH, iH, mW, iW);
+          jointsOk = jointsOk && jo;
+        }
+      }
+      xjok[lane] = jointsOk ? 1 : 0;
+      __syncthreads();
+      if (active) {
+        bool ok = jointsOk;
+        if (ccn > 0) {
+          ok = xcok[leader_lane + isl] != 0;
+          for (int c = 0; c < p.N; ++c) if (xisl[leader_lane + c] == isl) ok = ok && (xjok[leader_lane + c] != 0);
+        }
+        if (ok) { positionSolved = true; active = false; }
+      }
+      __syncthreads();
+    }
+  }
+  float minSleep = MCR_MAXFLT;
+  if (run) {
     // sleep (b2Island::Solve tail).  Car.step re-wakes every body next step, so "asleep" reduces to:
-    // zero the velocities and restart the timers.
-    float minSleep = MCR_MAXFLT;
+    // zero the velocities and restart the timers.  The decision is per island.
     const float linTol2 = B2_LINEAR_SLEEP_TOL * B2_LINEAR_SLEEP_TOL, angTol2 = B2_ANGULAR_SLEEP_TOL * B2_ANGULAR_SLEEP_TOL;
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
       if (b[k].w * b[k].w > angTol2 || (b[k].vx * b[k].vx + b[k].vy * b[k].vy) > linTol2) { sleepT[k] = 0.0f; minSleep = 0.0f; }
       else { sleepT[k] += h; minSleep = mcr_min(minSleep, sleepT[k]); }
     }
-    if (minSleep >= B2_TIME_TO_SLEEP && positionSolved) {
+  }
+  bool island_solved = positionSolved;
+  if (wave_cc) {                          // members of a merged island decide together
+    if (ccn > 0) { xms[lane] = minSleep; xjok[lane] = positionSolved ? 1 : 0; }
+    __syncthreads();
+    if (run && ccn > 0)
+      for (int c = 0; c < p.N; ++c) if (xisl[leader_lane + c] == isl) { minSleep = mcr_min(minSleep, xms[leader_lane + c]); island_solved = island_solved && (xjok[leader_lane + c] != 0); }
+  }
+  if (run && minSleep >= B2_TIME_TO_SLEEP && island_solved) {
 #pragma unroll
-      for (int k = 0; k < 5; ++k) { sleepT[k] = 0.0f; b[k].vx = 0.0f; b[k].vy = 0.0f; b[k].w = 0.0f; }
-    }
+    for (int k = 0; k < 5; ++k) { sleepT[k] = 0.0f; b[k].vx = 0.0f; b[k].vy = 0.0f; b[k].w = 0.0f; }
   }
 
   // ---- env bookkeeping (:433-443, :497-507) + TimeLimit, across the env's lane group

@@ -214,7 +214,7 @@ def lib():
         L.orc_create.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         for name in ("orc_destroy", "orc_set_track", "orc_reset", "orc_step", "orc_render", "orc_get_state",
                      "orc_set_body", "orc_get_env", "orc_positions", "orc_contact_event", "orc_set_hull_pose",
-                     "orc_bookkeeping", "orc_wheel_tile_counts", "orc_reset_nostep"):
+                     "orc_bookkeeping", "orc_wheel_tile_counts", "orc_reset_nostep", "orc_step_masked", "orc_reset_masked"):
             getattr(L, name).restype = None
         L.orc_num_car_contacts.restype = ctypes.c_int
         L.orc_num_car_contacts.argtypes = [ctypes.c_void_p]
@@ -275,7 +275,9 @@ class OracleEnv:
             self.set_episode(ep)
         self.L.orc_set_trig_mode(self.trig_mode)
         obs = np.zeros((self.N, 96, 96, 3), np.uint8)
-        self.L.orc_reset(self.h, _p(self._poses), _p(obs) if render else None)
+        self.last_amb = np.zeros((self.N, 96, 96), np.uint8)
+        self.L.orc_reset_masked(self.h, _p(self._poses), _p(obs) if render else None, _p(self.last_amb))
+        self.last_obs = obs
         return obs
 
     def step(self, action, render=True):
@@ -284,7 +286,10 @@ class OracleEnv:
         rew = np.zeros(self.N, np.float64)
         done = np.zeros(1, np.uint8)
         a = None if action is None else np.ascontiguousarray(np.reshape(action, (self.N, -1))[:, :3], dtype=np.float32)
-        self.L.orc_step(self.h, _p(a) if a is not None else None, _p(obs) if render else None, _p(rew), _p(done))
+        self.last_amb = np.zeros((self.N, 96, 96), np.uint8) if render else None
+        self.L.orc_step_masked(self.h, _p(a) if a is not None else None, _p(obs) if render else None,
+                               _p(self.last_amb) if render else None, _p(rew), _p(done))
+        self.last_obs = obs
         return obs, rew, bool(done[0]), {}
 
     def render_with_mask(self):

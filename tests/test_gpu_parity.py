@@ -50,8 +50,10 @@ def _assert_state_equal(env, orcs, what=""):
 
 
 def _assert_pixels(obs, orcs, budget=12):
+    """GPU obs vs the frame the oracle rendered INSIDE its last step/reset (call step(..., render=True))."""
     for e, o in enumerate(orcs):
-        oo, amb = o.render_with_mask()
+        oo, amb = o.last_obs, o.last_amb
+        assert oo is not None, "oracle step was not rendered"
         d = (oo != obs[e]).any(-1)
         assert (d & (amb == 0)).sum() == 0, f"env {e}: {(d & (amb == 0)).sum()} unambiguous pixels differ"
         assert d.sum() <= budget * len(oo), f"env {e}: {d.sum()} edge pixels differ"
@@ -72,7 +74,7 @@ def test_rollout_bit_exact_no_car_contacts(torch_cuda, oracle, N, direction):
         obs, rew, done, _ = env.step(torch.from_numpy(a).cuda())
         rw, dn = rew.cpu().numpy(), done.cpu().numpy()
         for e, o in enumerate(orcs):
-            _, r, d, _ = o.step(a[e], render=False)
+            _, r, d, _ = o.step(a[e], render=(k % 40 == 39))
             assert np.array_equal(r, rw[e]) and bool(dn[e]) == d, f"step {k} env {e}: reward/done differ"
         if k % 40 == 39:
             _assert_state_equal(env, orcs, f"step {k}"); _assert_pixels(obs.cpu().numpy(), orcs)
@@ -95,7 +97,7 @@ def test_render_options_and_zoom_in(torch_cuda, oracle):
             a[..., 1] = 0.0; a[..., 2] = 0.0
         obs, _, _, _ = env.step(torch.from_numpy(a).cuda())
         for e, o in enumerate(orcs):
-            o.step(a[e], render=False)
+            o.step(a[e], render=True)
         _assert_pixels(obs.cpu().numpy(), orcs, budget=40)
     env.close()
 
@@ -114,12 +116,11 @@ def test_backward_flag_and_grass_flags(torch_cuda, oracle):
         obs, _, _, _ = env.step(torch.from_numpy(a).cuda())
         es = env.get_env_state()
         for e, o in enumerate(orcs):
-            o.step(a[e], render=False); eo = o.env_state()
+            o.step(a[e], render=True); eo = o.env_state()
             assert np.array_equal(es["driving_backward"][e], eo["driving_backward"]), (k, e)
             assert np.array_equal(es["driving_on_grass"][e], eo["driving_on_grass"]), (k, e)
             seen_flag |= bool(eo["driving_backward"].any())
-        if k % 30 == 29:
-            _assert_pixels(obs.cpu().numpy(), orcs, budget=40)
+        _assert_pixels(obs.cpu().numpy(), orcs, budget=40)          # every frame: the flag shows one step late
     assert seen_flag, "scenario never set driving_backward"
     env.close()
 
@@ -166,7 +167,7 @@ def test_time_limit_and_auto_reset(torch_cuda, oracle):
         oracle.new_episode(N, tr, gr, use_random_direction=True)
         ep2 = oracle.new_episode(N, tr, gr, use_random_direction=True)
         o = oracle.OracleEnv(N, car_contacts=False); o2 = o.reset(ep2)
-        _, amb = o.render_with_mask()
+        amb = o.last_amb
         d = (o2 != obs[e].cpu().numpy()).any(-1)
         assert (d & (amb == 0)).sum() == 0
         assert np.array_equal(env.get_state()["bodies"][e], o.state()["bodies"])
@@ -241,7 +242,7 @@ def test_facade_matches_reference_surface(torch_cuda, oracle):
     rs, _ = seeding.np_random(3)
     ep = oracle.new_episode(2, rs, np.random, direction="CCW", use_random_direction=False)
     o = oracle.OracleEnv(2); oo = o.reset(ep)
-    _, amb = o.render_with_mask()
+    amb = o.last_amb
     assert ((oo != obs).any(-1) & (amb == 0)).sum() == 0
     assert len(env.track) == len(ep["track"]) and np.array_equal(np.array(env.track), ep["track"])
     total = np.zeros(2)
@@ -260,3 +261,65 @@ def test_facade_matches_reference_surface(torch_cuda, oracle):
     with pytest.raises(AttributeError):
         e2.step(np.zeros(3))
     e2.close()
+
+
+def _rear_end_setup(env, orcs, gap=5.2):
+    """Put car 1 of every env `gap` behind car 0 (same heading) so that full gas on car 1 + brake on car 0 collide."""
+    st = env.get_state()["bodies"].copy()
+    for e in range(env.B):
+        a = st[e, 0, 0, 2]
+        fwd = np.array([-np.sin(a), np.cos(a)], np.float32)          # hull forward axis
+        delta = (st[e, 0, 0, :2] - fwd * np.float32(gap)) - st[e, 1, 0, :2]
+        st[e, 1, :, 0] += delta[0]; st[e, 1, :, 1] += delta[1]
+        st[e, 1, :, 2] = a
+    env.set_bodies(st)
+    for e, o in enumerate(orcs):
+        for k in range(5):
+            o.set_body(1, k, st[e, 1, k])
+
+
+@pytest.mark.parametrize("N", [2, 4])
+def test_car_car_contacts_bit_exact(torch_cuda, oracle, N):
+    """Rigid car<->car contacts (b2CollidePolygons + b2ContactSolver + merged islands): rear-end collisions,
+    compared bit-exact with the oracle, including warm-started impulses across steps."""
+    torch = torch_cuda
+    B, seed = 5, 60 + N
+    env = _make(B, N, seed, contacts=True); env.reset()
+    orcs = _oracles(oracle, B, N, seed, contacts=True)
+    _rear_end_setup(env, orcs)
+    rng = np.random.RandomState(4)
+    touched = 0
+    for k in range(160):
+        a = random_actions(rng, B, N, 0.0)
+        a[:, 0, 1] = 0.0; a[:, 0, 2] = 0.8 if k < 60 else 0.0          # car 0 brakes, then coasts
+        a[:, 1, 0] *= 0.2; a[:, 1, 1] = 1.0                              # car 1 floors it
+        obs, rew, done, _ = env.step(torch.from_numpy(a).cuda())
+        rw = rew.cpu().numpy()
+        for e, o in enumerate(orcs):
+            _, r, d, _ = o.step(a[e], render=(k == 159 or k % 20 == 19))
+            touched += o.num_car_contacts()
+            assert np.array_equal(r, rw[e]), f"step {k} env {e}"
+        if k % 20 == 19:
+            _assert_state_equal(env, orcs, f"contacts step {k}"); _assert_pixels(obs.cpu().numpy(), orcs, budget=40)
+    assert touched > 50, "scenario produced no car<->car contacts"
+    _assert_pixels(obs.cpu().numpy(), orcs, budget=40)
+    env.close()
+
+
+def test_random_rollout_with_contacts_enabled(torch_cuda, oracle):
+    """Default configuration (contacts on), N=8 crowded start: whatever happens, HIP == oracle."""
+    torch = torch_cuda
+    B, N, seed = 3, 8, 300
+    env = _make(B, N, seed, contacts=True); env.reset()
+    orcs = _oracles(oracle, B, N, seed, contacts=True)
+    rng = np.random.RandomState(8)
+    for k in range(150):
+        a = random_actions(rng, B, N, 0.1); a[..., 0] *= 1.0
+        a[:, ::2, 1] = 1.0                                               # half the field accelerates hard
+        _, rew, _, _ = env.step(torch.from_numpy(a).cuda())
+        for e, o in enumerate(orcs):
+            _, r, _, _ = o.step(a[e], render=False)
+            assert np.array_equal(r, rew[e].cpu().numpy()), f"step {k} env {e}"
+        if k % 30 == 29:
+            _assert_state_equal(env, orcs, f"N=8 step {k}")
+    env.close()
