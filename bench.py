@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--agents", type=int, default=2)
     ap.add_argument("--obs", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=0, help="env sub-batches pipelined on internal HIP streams (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event time all three kernels (adds overhead)")
     args = ap.parse_args()
@@ -83,7 +84,7 @@ def main():
 
     B, N, K, W = args.envs, args.agents, args.steps, args.warmup
     env = ShardedVecEnv(B * world, N, seed=0, rank=rank, world_size=world, device=dev, obs=bool(args.obs),
-                        auto_reset=True, use_random_direction=True)
+                        auto_reset=True, use_random_direction=True, streams=args.streams)
     env.reset()
     # synthetic actions resident in HBM: a pool of i.i.d. (steer~U(-1,1), gas~U(0,1), brake~U(0,1)) batches
     g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
@@ -92,7 +93,7 @@ def main():
     for k in range(W):
         env.step(pool[k % 64])
     env.wait_refills()
-    env.timing(7 if args.time_all_kernels else 4)
+    env.timing(31 if args.time_all_kernels else 4)
     gen0 = env.env.episodes_generated
     torch.cuda.synchronize()
     if world > 1:
@@ -143,7 +144,8 @@ def main():
             "roofline": roofline,
         }
         if args.time_all_kernels:
-            out["kernel_ms"] = {"collide": ms[0] / max(nl[0], 1), "dynamics": ms[1] / max(nl[1], 1), "view": ms[2] / max(nl[2], 1)}
+            out["kernel_ms"] = {"collide": ms[0] / max(nl[0], 1), "dynamics": ms[1] / max(nl[1], 1), "view": ms[2] / max(nl[2], 1),
+                                "collide_reset_pass": ms[3] / max(nl[3], 1), "dynamics_reset_pass": ms[4] / max(nl[4], 1)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, bool(args.obs))
         print(json.dumps(out))

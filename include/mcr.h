@@ -45,7 +45,7 @@ typedef struct mcr_config {
   int32_t use_ego_color;     /* :160 */
   int32_t car_contacts;      /* 1: car<->car rigid contacts (Box2D default); 0: ghost cars (debug) */
   int32_t max_episode_steps; /* gym TimeLimit from __init__.py:8 (1000); 0 disables */
-  int32_t reserved;
+  int32_t num_streams;       /* env sub-batches pipelined on internal HIP streams (0 = default 1 = none; >1 needs cheap launches to pay off) */
   double h_ratio;            /* :159 */
 } mcr_config;
 
@@ -120,13 +120,14 @@ void mcr_sincos_host(float a, float* s, float* c);
 int mcr_sincos_device(mcr_env* h, const float* d_in, float* d_sin, float* d_cos, int n, void* stream);
 
 /* ---- instrumentation for bench.py: HIP-event timing of the kernels enqueued by mcr_step, recorded on the
- * launch stream.  `mask` bit k enables kernel id k (0 collide, 1 dynamics, 2 view; 7 = all, 0 = off).
+ * launch stream.  `mask` bit k enables kernel id k (0 collide, 1 dynamics, 2 view, 3/4 = collide/dynamics of
+ * the auto-reset pass; 31 = all, 0 = off).
  * mcr_timing_read synchronises the device and drains accumulated milliseconds + launch counts. */
 int mcr_timing_enable(mcr_env* h, int mask);
 /* profiling ablations of the raster kernel (bit 0 skip flags block, 1 skip road shading, 2 skip cars, 3 skip
  * write-out, 4 skip binning/cull); 0 in production.  Results are WRONG when non-zero. */
 int mcr_debug_set(mcr_env* h, int value);
-int mcr_timing_read(mcr_env* h, double* ms_out /*[3]*/, int64_t* launches_out /*[3]*/);
+int mcr_timing_read(mcr_env* h, double* ms_out /*[5]*/, int64_t* launches_out /*[5]*/);
 
 #ifdef __cplusplus
 }

@@ -73,7 +73,7 @@ __device__ __forceinline__ bool overlap(const float* avx, const float* avy, cons
 // pass 0: every active env.  pass 1: only envs with `resetting` set (their per-tile state is cleared first).
 __global__ __launch_bounds__(64) void k_collide(McrParams p, int pass) {
   using namespace col;
-  const int env = blockIdx.x, lane = threadIdx.x;
+  const int env = p.env0 + blockIdx.x, lane = threadIdx.x;
   const McrEnvState es = p.env[env];
   if (!es.active) return;
   if (pass == 1 && !es.resetting) return;

@@ -253,58 +253,70 @@ __device__ inline void cc_init(const McrShapes& S, const uint32_t* rec, int rec_
   xv[0 * 5 + bB][LB] = vB.x; xv[1 * 5 + bB][LB] = vB.y; xv[2 * 5 + bB][LB] = wB;
 }
 
-// b2ContactSolver::SolveVelocityConstraints for one contact
-__device__ inline void cc_velocity(const McrShapes& S, float* vc, float (*xv)[64]) {
-  const int n = ((int*)vc)[cc::VC_N];
-  const int sa = ((int*)vc)[cc::VC_LA], sb = ((int*)vc)[cc::VC_LB];
+// b2ContactSolver::SolveVelocityConstraints for one contact.  The record and both bodies are pulled into
+// registers with a few wide LDS reads, and only the accumulated impulses + body velocities are written back
+// (one LDS round trip per contact per iteration instead of one per scalar).
+__device__ inline void cc_velocity(const McrShapes& S, float* __restrict__ vcf, float (* __restrict__ xv)[64]) {
+  const float4* __restrict__ v4 = (const float4*)vcf;
+  const float4 r0 = v4[0], r1 = v4[1], r2 = v4[2], r3 = v4[3], r4 = v4[4], r5 = v4[5], r6 = v4[6];
+  // layout: [0]=nx [1]=ny [2]=n [3]=LA | [4]=LB [5..12]=P0 | [13..20]=P1 | [21]=k11 [22]=k12 [23]=k22 [24]=nm11 [25]=nm12 [26]=nm22
+  const int n = __float_as_int(r0.z);
+  const int sa = __float_as_int(r0.w), sb = __float_as_int(r1.x);
   const int LA = sa >> 3, bA = sa & 7, LB = sb >> 3, bB = sb & 7;
   float mA, iA, mB, iB; V2 lcA, lcB; cc_masses(S, bA, mA, iA, lcA); cc_masses(S, bB, mB, iB, lcB);
   V2 vA = v2(xv[0 * 5 + bA][LA], xv[1 * 5 + bA][LA]); float wA = xv[2 * 5 + bA][LA];
   V2 vB = v2(xv[0 * 5 + bB][LB], xv[1 * 5 + bB][LB]); float wB = xv[2 * 5 + bB][LB];
-  const V2 normal = v2(vc[cc::VC_NX], vc[cc::VC_NY]); const V2 tangent = cross(normal, 1.0f);
+  const V2 normal = v2(r0.x, r0.y); const V2 tangent = cross(normal, 1.0f);
   const float friction = sqrtf(0.2f * 0.2f);
-  for (int j = 0; j < n; ++j) {
-    float* q = vc + (j == 0 ? cc::VC_P0 : cc::VC_P1);
-    const V2 rA = v2(q[0], q[1]), rB = v2(q[2], q[3]);
-    const V2 dv = vB + cross(wB, rB) - vA - cross(wA, rA);
+  // point 0: rA rB nImp tImp normalMass tangentMass = words 5..12 ; point 1 = words 13..20
+  const V2 r1A = v2(r1.y, r1.z), r1B = v2(r1.w, r2.x); float n1 = r2.y, t1 = r2.z; const float nm1 = r2.w, tm1 = r3.x;
+  const V2 r2A = v2(r3.y, r3.z), r2B = v2(r3.w, r4.x); float n2 = r4.y, t2 = r4.z; const float nm2 = r4.w, tm2 = r5.x;
+  {
+    const V2 dv = vB + cross(wB, r1B) - vA - cross(wA, r1A);
     const float vt = dot(dv, tangent) - 0.0f;
-    float lambda = q[7] * (-vt);
-    const float maxF = friction * q[4];
-    const float newImp = mcr_clamp(q[5] + lambda, -maxF, maxF);
-    lambda = newImp - q[5]; q[5] = newImp;
+    float lambda = tm1 * (-vt);
+    const float maxF = friction * n1;
+    const float newImp = mcr_clamp(t1 + lambda, -maxF, maxF);
+    lambda = newImp - t1; t1 = newImp;
     const V2 P = lambda * tangent;
-    vA = vA - mA * P; wA -= iA * cross(rA, P);
-    vB = vB + mB * P; wB += iB * cross(rB, P);
+    vA = vA - mA * P; wA -= iA * cross(r1A, P);
+    vB = vB + mB * P; wB += iB * cross(r1B, P);
+  }
+  if (n == 2) {
+    const V2 dv = vB + cross(wB, r2B) - vA - cross(wA, r2A);
+    const float vt = dot(dv, tangent) - 0.0f;
+    float lambda = tm2 * (-vt);
+    const float maxF = friction * n2;
+    const float newImp = mcr_clamp(t2 + lambda, -maxF, maxF);
+    lambda = newImp - t2; t2 = newImp;
+    const V2 P = lambda * tangent;
+    vA = vA - mA * P; wA -= iA * cross(r2A, P);
+    vB = vB + mB * P; wB += iB * cross(r2B, P);
   }
   if (n == 1) {
-    float* q = vc + cc::VC_P0;
-    const V2 rA = v2(q[0], q[1]), rB = v2(q[2], q[3]);
-    const V2 dv = vB + cross(wB, rB) - vA - cross(wA, rA);
+    const V2 dv = vB + cross(wB, r1B) - vA - cross(wA, r1A);
     const float vn = dot(dv, normal);
-    float lambda = -q[6] * (vn - 0.0f);
-    const float newImp = mcr_max(q[4] + lambda, 0.0f);
-    lambda = newImp - q[4]; q[4] = newImp;
+    float lambda = -nm1 * (vn - 0.0f);
+    const float newImp = mcr_max(n1 + lambda, 0.0f);
+    lambda = newImp - n1; n1 = newImp;
     const V2 P = lambda * normal;
-    vA = vA - mA * P; wA -= iA * cross(rA, P);
-    vB = vB + mB * P; wB += iB * cross(rB, P);
-  } else if (n == 2) {
-    float* q1 = vc + cc::VC_P0; float* q2 = vc + cc::VC_P1;
-    const V2 r1A = v2(q1[0], q1[1]), r1B = v2(q1[2], q1[3]), r2A = v2(q2[0], q2[1]), r2B = v2(q2[2], q2[3]);
-    const V2 a = v2(q1[4], q2[4]);
+    vA = vA - mA * P; wA -= iA * cross(r1A, P);
+    vB = vB + mB * P; wB += iB * cross(r1B, P);
+  } else {
+    const V2 a = v2(n1, n2);
     const V2 dv1 = vB + cross(wB, r1B) - vA - cross(wA, r1A);
     const V2 dv2 = vB + cross(wB, r2B) - vA - cross(wA, r2A);
     float vn1 = dot(dv1, normal), vn2 = dot(dv2, normal);
-    const float k11 = vc[cc::VC_K11], k12 = vc[cc::VC_K12], k22 = vc[cc::VC_K22];
-    const float nm11 = vc[cc::VC_NM11], nm12 = vc[cc::VC_NM12], nm22 = vc[cc::VC_NM22];
+    const float k11 = r5.y, k12 = r5.z, k22 = r5.w, nm11 = r6.x, nm12 = r6.y, nm22 = r6.z;
     V2 b = v2(vn1 - 0.0f, vn2 - 0.0f);
     b = b - v2(k11 * a.x + k12 * a.y, k12 * a.x + k22 * a.y);
     V2 x; bool ok = false;
     for (;;) {
       x = -v2(nm11 * b.x + nm12 * b.y, nm12 * b.x + nm22 * b.y);
       if (x.x >= 0.0f && x.y >= 0.0f) { ok = true; break; }
-      x.x = -q1[6] * b.x; x.y = 0.0f; vn1 = 0.0f; vn2 = k12 * x.x + b.y;
+      x.x = -nm1 * b.x; x.y = 0.0f; vn1 = 0.0f; vn2 = k12 * x.x + b.y;
       if (x.x >= 0.0f && vn2 >= 0.0f) { ok = true; break; }
-      x.x = 0.0f; x.y = -q2[6] * b.y; vn1 = k12 * x.y + b.x; vn2 = 0.0f;
+      x.x = 0.0f; x.y = -nm2 * b.y; vn1 = k12 * x.y + b.x; vn2 = 0.0f;
       if (x.y >= 0.0f && vn1 >= 0.0f) { ok = true; break; }
       x.x = 0.0f; x.y = 0.0f; vn1 = b.x; vn2 = b.y;
       if (vn1 >= 0.0f && vn2 >= 0.0f) { ok = true; break; }
@@ -315,9 +327,10 @@ __device__ inline void cc_velocity(const McrShapes& S, float* vc, float (*xv)[64
       const V2 P1 = d.x * normal, P2 = d.y * normal;
       vA = vA - mA * (P1 + P2); wA -= iA * (cross(r1A, P1) + cross(r2A, P2));
       vB = vB + mB * (P1 + P2); wB += iB * (cross(r1B, P1) + cross(r2B, P2));
-      q1[4] = x.x; q2[4] = x.y;
+      n1 = x.x; n2 = x.y;
     }
   }
+  vcf[cc::VC_P0 + 4] = n1; vcf[cc::VC_P0 + 5] = t1; vcf[cc::VC_P1 + 4] = n2; vcf[cc::VC_P1 + 5] = t2;
   xv[0 * 5 + bA][LA] = vA.x; xv[1 * 5 + bA][LA] = vA.y; xv[2 * 5 + bA][LA] = wA;
   xv[0 * 5 + bB][LB] = vB.x; xv[1 * 5 + bB][LB] = vB.y; xv[2 * 5 + bB][LB] = wB;
 }
@@ -376,16 +389,17 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
   using namespace dyn;
   // LDS used only by waves that contain a touching car<->car pair
   __shared__ float xv[15][64], xp[15][64];            // body exchange: (vx,vy,w) / (cx,cy,a) x 5 bodies per lane
-  __shared__ float vcpool[DYN_VC_POOL][cc::VC_SIZE];
+  __shared__ __attribute__((aligned(16))) float vcpool[DYN_VC_POOL][cc::VC_SIZE];
   __shared__ int xisl[64], xact[64], xjok[64], xcok[64];
   __shared__ float xms[64];
   const int g = blockIdx.x * 64 + threadIdx.x;
-  const int env = g / p.G, agent = g % p.G;
-  const bool lane_ok = env < p.B && agent < p.N;
+  const int env = p.env0 + g / p.G, agent = g % p.G;
+  const int env_end = p.env0 + p.nenv;
+  const bool lane_ok = env < env_end && agent < p.N;
   const int ci = lane_ok ? env * p.N + agent : 0;
   const int BN = p.BN;
   McrEnvState es;
-  if (env < p.B) es = p.env[env]; else { es.active = 0; es.resetting = 0; }
+  if (env < env_end) es = p.env[env]; else { es.active = 0; es.resetting = 0; }
   bool run = lane_ok && es.active;
   if (mode == 1) run = run && es.resetting;
 
@@ -494,7 +508,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
   // touching pair in the whole wave — skips every contact block below with one wave-uniform branch.
   const int lane = threadIdx.x;
   const int leader_lane = lane - agent;
-  uint32_t* store = p.cc_store + (size_t)(env < p.B ? env : 0) * (MCR_CC_MAX * MCR_CC_WORDS + 4);
+  uint32_t* store = p.cc_store + (size_t)(env < env_end ? env : 0) * (MCR_CC_MAX * MCR_CC_WORDS + 4);
   int ccn = 0;
   if (run && p.car_contacts && p.N > 1) ccn = (int)store[0];
   const bool wave_cc = __any(ccn > 0) != 0;
@@ -702,7 +716,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
   uint32_t tvc = 0, flags = 0;
   if (run) { reward = p.card[CD_REWARD * BN + ci]; prev_reward = p.card[CD_PREV_REWARD * BN + ci]; tvc = p.caru[CU_TVC * BN + ci]; flags = p.caru[CU_FLAGS * BN + ci]; }
   int T = 0;
-  if (env < p.B && es.active) T = ((const McrSlotHeader*)(p.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES))->T;
+  if (env < env_end && es.active) T = ((const McrSlotHeader*)(p.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES))->T;
   if (mode == 0) {
     const bool has_action = p.actions != nullptr;
     int d = 0;
@@ -851,8 +865,8 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
 // runs collide(pass 1) -> dynamics(mode 1) -> view to complete `return self.step(None)[0]` (:408).
 __global__ __launch_bounds__(64) void k_install(McrParams p) {
   const int g = blockIdx.x * 64 + threadIdx.x;
-  const int env = g / p.G, agent = g % p.G;
-  if (env >= p.B || agent >= p.N) return;
+  const int env = p.env0 + g / p.G, agent = g % p.G;
+  if (env >= p.env0 + p.nenv || agent >= p.N) return;
   if (p.reset_mask && !p.reset_mask[env]) return;
   McrEnvState es = p.env[env];
   if (!es.staged_ready) return;

@@ -109,9 +109,10 @@ __device__ __forceinline__ bool box_may_touch(const float* e, int n, float X0, f
 // dynamic LDS: car polygon records, N*12 x 6 float4 (8 edges each, padded with always-true edges)
 __global__ __launch_bounds__(VIEW_THREADS) void k_view(McrParams p, float* __restrict__ scratch, int flags_mode, int only_just_reset) {
   using namespace view;
-  const int vw = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int N = p.N, BN = p.BN;
+  const int vw = p.env0 * N + blockIdx.x;
   const int env = vw / N, agent = vw % N;
   const McrEnvState es = p.env[env];
   if (!es.active) return;

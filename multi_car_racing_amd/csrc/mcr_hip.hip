@@ -38,8 +38,11 @@ struct mcr_env {
   int timing;                 // bit mask of kernel ids to time with HIP events
   std::vector<TimedLaunch> pending;
   std::vector<hipEvent_t> free_events;
-  double t_ms[3]; int64_t t_n[3];
+  double t_ms[5]; int64_t t_n[5];
   bool any_reset;
+  int ngroups;                // env sub-batches pipelined on internal streams (1 = caller's stream only)
+  hipStream_t gstream[8];
+  hipEvent_t ev_fork, ev_done[8];
   float* view_scratch;        // per-view spill area of the rasteriser (zoomed-out frames only)
 };
 
@@ -51,7 +54,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   HIPCHK(hipSetDevice(cfg->device));
   mcr_env* h = new mcr_env();
   h->cfg = *cfg; h->timing = 0; h->any_reset = false;
-  for (int i = 0; i < 3; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
+  for (int i = 0; i < 5; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
   const int B = cfg->num_envs, N = cfg->num_agents;
   int G = 1; while (G < N) G <<= 1;
   const size_t BN = (size_t)B * N;
@@ -90,6 +93,17 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   (void)hipHostGetDevicePointer(&dptr, h->consumed_host, 0);
   P.consumed_host = (int32_t*)dptr;
   h->consumed_seen = new int32_t[B]();
+  // Stream-level pipelining: the dynamics kernel is a long serial dependency chain on few wavefronts while the
+  // raster kernel is throughput bound, so env sub-batches on separate streams overlap one group's dynamics
+  // with another group's raster/collide.  cfg.num_streams selects the group count (0 = default).
+  h->ngroups = cfg->num_streams > 0 ? cfg->num_streams : 1;   // measured: without graph replay the extra launches cost more than the overlap wins
+  if (h->ngroups > 8) h->ngroups = 8;
+  while (h->ngroups > 1 && B / h->ngroups < 256) h->ngroups >>= 1;
+  P.env0 = 0; P.nenv = B;
+  if (h->ngroups > 1) {
+    for (int g = 0; g < h->ngroups; ++g) { (void)hipStreamCreateWithFlags(&h->gstream[g], hipStreamNonBlocking); (void)hipEventCreateWithFlags(&h->ev_done[g], hipEventDisableTiming); }
+    (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+  }
   (void)hipDeviceSynchronize();
   *out = h;
   return MCR_OK;
@@ -101,6 +115,7 @@ extern "C" int mcr_destroy(mcr_env* h) {
   (void)hipDeviceSynchronize();
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : h->free_events) (void)hipEventDestroy(e);
+  if (h->ngroups > 1) { for (int g = 0; g < h->ngroups; ++g) { (void)hipStreamDestroy(h->gstream[g]); (void)hipEventDestroy(h->ev_done[g]); } (void)hipEventDestroy(h->ev_fork); }
   (void)hipFree(h->slab);
   (void)hipHostFree(h->consumed_host);
   delete[] h->consumed_seen;
@@ -140,13 +155,37 @@ static hipEvent_t get_event(mcr_env* h) {
     if (tm_) { (void)hipEventRecord(tl_.b, st); h->pending.push_back(tl_); }                   \
   } while (0)
 
-static int run_reset_tail(mcr_env* h, McrParams& P, hipStream_t st, bool only_just_reset) {
-  const int B = P.B, N = P.N;
-  const int dyn_blocks = (B * P.G + 63) / 64;
-  LAUNCH(0, k_collide, B, 64, st, P, 1);
-  LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 1);
-  if (P.obs) LAUNCH_LDS(2, k_view, B * N, VIEW_THREADS, (size_t)N * 12 * 6 * 16, st, P, h->view_scratch, 0, only_just_reset ? 1 : 0);
-  return MCR_OK;
+// One env sub-range [e0, e0+ne) through the whole step on stream st.
+static void launch_group(mcr_env* h, McrParams P, int e0, int ne, hipStream_t st, bool install, bool step_pass, bool reset_pass,
+                         int view_flags, int view_only_just_reset) {
+  P.env0 = e0; P.nenv = ne;
+  const int N = P.N;
+  const int dyn_blocks = (ne * P.G + 63) / 64;
+  if (install) hipLaunchKernelGGL(k_install, dim3(dyn_blocks), dim3(64), 0, st, P);
+  if (step_pass) {
+    LAUNCH(0, k_collide, ne, 64, st, P, 0);
+    LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 0);
+  }
+  if (reset_pass) {   // the action-less first step of a freshly installed episode (:408)
+    LAUNCH(3, k_collide, ne, 64, st, P, 1);
+    LAUNCH(4, k_dynamics, dyn_blocks, 64, st, P, 1);
+  }
+  if (P.obs || view_flags) LAUNCH_LDS(2, k_view, ne * N, VIEW_THREADS, (size_t)N * 12 * 6 * 16, st, P, h->view_scratch, view_flags, view_only_just_reset);
+}
+
+static void launch_all(mcr_env* h, const McrParams& P, hipStream_t st, bool install, bool step_pass, bool reset_pass, int view_flags, int only_jr) {
+  const int B = P.B;
+  if (h->ngroups <= 1) { launch_group(h, P, 0, B, st, install, step_pass, reset_pass, view_flags, only_jr); return; }
+  (void)hipEventRecord(h->ev_fork, st);
+  const int per = (B + h->ngroups - 1) / h->ngroups;
+  for (int g = 0; g < h->ngroups; ++g) {
+    const int e0 = g * per; const int ne = (e0 + per <= B) ? per : B - e0;
+    if (ne <= 0) break;
+    (void)hipStreamWaitEvent(h->gstream[g], h->ev_fork, 0);
+    launch_group(h, P, e0, ne, h->gstream[g], install, step_pass, reset_pass, view_flags, only_jr);
+    (void)hipEventRecord(h->ev_done[g], h->gstream[g]);
+    (void)hipStreamWaitEvent(st, h->ev_done[g], 0);
+  }
 }
 
 extern "C" int mcr_reset(mcr_env* h, const uint8_t* d_env_mask, uint8_t* d_obs, void* stream) {
@@ -154,9 +193,7 @@ extern "C" int mcr_reset(mcr_env* h, const uint8_t* d_env_mask, uint8_t* d_obs, 
   hipStream_t st = (hipStream_t)stream;
   McrParams P = h->P;
   P.reset_mask = d_env_mask; P.obs = h->cfg.obs_enabled ? d_obs : nullptr; P.actions = nullptr;
-  const int dyn_blocks = (P.B * P.G + 63) / 64;
-  hipLaunchKernelGGL(k_install, dim3(dyn_blocks), dim3(64), 0, st, P);
-  run_reset_tail(h, P, st, true);
+  launch_all(h, P, st, true, false, true, 0, 1);
   HIPCHK(hipGetLastError());
   h->any_reset = true;
   return MCR_OK;
@@ -169,15 +206,9 @@ extern "C" int mcr_step(mcr_env* h, const float* d_actions, uint8_t* d_obs, doub
   McrParams P = h->P;
   P.actions = d_actions; P.obs = h->cfg.obs_enabled ? d_obs : nullptr;
   P.reward_out = d_reward; P.done_out = d_done; P.trunc_out = d_trunc;
-  const int B = P.B, N = P.N;
-  const int dyn_blocks = (B * P.G + 63) / 64;
-  LAUNCH(0, k_collide, B, 64, st, P, 0);
-  LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 0);
-  if (P.auto_reset) {   // device-side respawn of finished envs: the action-less first step of their new episode
-    LAUNCH(0, k_collide, B, 64, st, P, 1);
-    LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 1);
-  }
-  LAUNCH_LDS(2, k_view, B * N, VIEW_THREADS, (size_t)N * 12 * 6 * 16, st, P, h->view_scratch, d_actions ? 1 : 0, 0);
+  // with auto_reset, finished envs are re-spawned on the device and take the action-less first step of their
+  // new episode inside this call; the view kernel always runs (it also owns the backward/on-grass flags)
+  launch_all(h, P, st, false, true, P.auto_reset != 0, d_actions ? 1 : 0, 0);
   HIPCHK(hipGetLastError());
   return MCR_OK;
 }
@@ -305,6 +336,6 @@ extern "C" int mcr_timing_read(mcr_env* h, double* ms_out, int64_t* launches_out
     h->free_events.push_back(t.a); h->free_events.push_back(t.b);
   }
   h->pending.clear();
-  for (int i = 0; i < 3; ++i) { if (ms_out) ms_out[i] = h->t_ms[i]; if (launches_out) launches_out[i] = h->t_n[i]; h->t_ms[i] = 0; h->t_n[i] = 0; }
+  for (int i = 0; i < 5; ++i) { if (ms_out) ms_out[i] = h->t_ms[i]; if (launches_out) launches_out[i] = h->t_n[i]; h->t_ms[i] = 0; h->t_n[i] = 0; }
   return MCR_OK;
 }

@@ -5,6 +5,7 @@
 struct McrParams {
   int32_t B, N, G;              // envs, agents, lanes per env in the dynamics kernel (pow2 >= N)
   int32_t BN;                   // B*N: stride of every per-car SoA field
+  int32_t env0, nenv;           // env sub-range [env0, env0+nenv) covered by this launch (stream-level pipelining)
   float* carf;                  // [CF_COUNT][BN]
   double* card;                 // [CD_COUNT][BN]
   uint32_t* caru;               // [CU_COUNT][BN]

@@ -29,7 +29,7 @@ class VecMultiCarRacing:
     def __init__(self, num_envs, num_agents=2, device=None, seed=0, env_offset=0, direction="CCW",
                  use_random_direction=True, backwards_flag=True, h_ratio=0.25, use_ego_color=False,
                  obs=True, auto_reset=True, max_episode_steps=1000, car_contacts=True,
-                 gen_threads=None, async_refill=True):
+                 gen_threads=None, async_refill=True, streams=0):
         if not torch.cuda.is_available():
             raise _lib.McrError("VecMultiCarRacing needs a HIP device: the step path has no CPU fallback")
         self.L = _lib.load()
@@ -41,7 +41,7 @@ class VecMultiCarRacing:
         self.direction_mode = 2 if use_random_direction else _DIRECTION_MODE[direction]
         self.gen_threads = gen_threads or max(1, (os.cpu_count() or 2) - 1)
         cfg = _lib.Config(self.B, self.N, self.device.index or 0, int(self.obs_enabled), int(self.auto_reset),
-                          int(backwards_flag), int(use_ego_color), int(car_contacts), int(max_episode_steps), 0,
+                          int(backwards_flag), int(use_ego_color), int(car_contacts), int(max_episode_steps), int(streams),
                           float(h_ratio))
         self.h = ctypes.c_void_p()
         _lib.check(self.L.mcr_create(ctypes.byref(cfg), ctypes.byref(self.h)), "mcr_create")
@@ -204,11 +204,11 @@ class VecMultiCarRacing:
         return _lib.unpack_episode(np.ascontiguousarray(self._blobs_np[e]))
 
     def timing(self, mask):
-        """HIP-event kernel timing; mask bit 0 collide, 1 dynamics, 2 view (7 = all, 0 = off)."""
+        """HIP-event kernel timing; mask bit 0 collide, 1 dynamics, 2 view, 3/4 reset-pass collide/dynamics."""
         _lib.check(self.L.mcr_timing_enable(self.h, int(mask)))
 
     def timing_read(self):
-        ms = np.zeros(3); n = np.zeros(3, np.int64)
+        ms = np.zeros(5); n = np.zeros(5, np.int64)
         _lib.check(self.L.mcr_timing_read(self.h, _lib.ptr(ms), _lib.ptr(n)))
         return ms, n
 

@@ -6,7 +6,7 @@ from multi_car_racing_amd.vec_env import VecMultiCarRacing
 from multi_car_racing_amd import _lib
 
 B, N = int(os.environ.get("B", 4096)), int(os.environ.get("N", 2))
-env = VecMultiCarRacing(B, N, seed=1, use_random_direction=True, auto_reset=True)
+env = VecMultiCarRacing(B, N, seed=1, use_random_direction=True, auto_reset=True, streams=int(os.environ.get("STREAMS", 0)))
 env.reset()
 act = torch.rand((B, N, 3), device="cuda"); act[..., 0] = act[..., 0] * 2 - 1
 for _ in range(80): env.step(act)
@@ -16,12 +16,12 @@ res = {}
 for rnd in range(3):
     for mask in names:
         _lib.check(env.L.mcr_debug_set(env.h, mask))
-        env.timing(7)
+        env.timing(31)
         for _ in range(30): env.step(act)
         ms, n = env.timing_read(); env.timing(0)
         res.setdefault(mask, []).append(ms / np.maximum(n, 1))
 _lib.check(env.L.mcr_debug_set(env.h, 0))
 for mask, v in res.items():
     v = np.array(v)
-    print(f"{names[mask]:>22}: view {np.median(v[:,2])*1e3:8.1f} us   collide {np.median(v[:,0])*1e3:6.1f} us  dynamics {np.median(v[:,1])*1e3:6.1f} us")
+    print(f"{names[mask]:>22}: view {np.median(v[:,2])*1e3:8.1f} us   collide {np.median(v[:,0])*1e3:6.1f} us  dynamics {np.median(v[:,1])*1e3:6.1f} us  reset-pass {np.median(v[:,3])*1e3:5.1f}+{np.median(v[:,4])*1e3:5.1f} us")
 env.close()
