@@ -226,6 +226,20 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+def rollout(envs, actions, render=True, threads=None):
+    """CPU baseline helper: advance independent OracleEnv objects with actions [steps, n, N, 3] on `threads`
+    OpenMP threads (one C call, no Python in the loop)."""
+    L = lib()
+    n = len(envs); steps = actions.shape[0]; N = envs[0].N
+    hs = (ctypes.c_void_p * n)(*[e.h for e in envs])
+    a = np.ascontiguousarray(actions, np.float32)
+    obs = np.zeros((n, N, 96, 96, 3), np.uint8) if render else None
+    L.orc_rollout.restype = None
+    L.orc_rollout(hs, ctypes.c_int(n), _p(a), ctypes.c_int(steps), ctypes.c_int(int(render)), _p(obs) if render else None,
+                  ctypes.c_int(threads or os.cpu_count() or 1))
+    return obs
+
+
 def sincos(a, mode=0):
     L = lib()
     L.orc_set_trig_mode(mode)
