@@ -16,13 +16,7 @@
 
 namespace cc {
 
-struct LPoly { int n; float vx[8], vy[8], nx[8], ny[8]; };
-
-__device__ __forceinline__ void load_poly(const McrPoly& P, LPoly& L) {
-  L.n = P.n;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { L.vx[i] = P.vx[i]; L.vy[i] = P.vy[i]; L.nx[i] = P.nx[i]; L.ny[i] = P.ny[i]; }
-}
+typedef McrPoly LPoly;     // polygons are read in place from the shape table in HBM (dynamic indexing is a plain load)
 __device__ __forceinline__ int fixture_body(int fix) { return fix < 4 ? 0 : fix - 3; }
 __device__ __forceinline__ Xf xf_mulT(const Xf& A, const Xf& B) {   // b2MulT(A,B)
   Xf C; C.q.s = A.q.c * B.q.s - A.q.s * B.q.c; C.q.c = A.q.c * B.q.c + A.q.s * B.q.s;
@@ -73,20 +67,15 @@ __device__ inline void collide_polygons(Manifold& M, const LPoly& pA, const Xf& 
   else { p1 = &pA; p2 = &pB; xf1 = xfA; xf2 = xfB; edge1 = edgeA; M.type = 1; flip = 0; }
   ClipV inc[2];
   {
-    V2 n1l = v2(0, 0);
-    for (int i = 0; i < 8; ++i) if (i == edge1) n1l = v2(p1->nx[i], p1->ny[i]);
-    const V2 normal1 = rmulT(xf2.q, rmul(xf1.q, n1l));
+    const V2 normal1 = rmulT(xf2.q, rmul(xf1.q, v2(p1->nx[edge1], p1->ny[edge1])));
     int index = 0; float minDot = MCR_MAXFLT;
     for (int i = 0; i < p2->n; ++i) { const float d = dot(normal1, v2(p2->nx[i], p2->ny[i])); if (d < minDot) { minDot = d; index = i; } }
     const int i1 = index, i2 = i1 + 1 < p2->n ? i1 + 1 : 0;
-    V2 a = v2(0, 0), b = v2(0, 0);
-    for (int i = 0; i < 8; ++i) { if (i == i1) a = v2(p2->vx[i], p2->vy[i]); if (i == i2) b = v2(p2->vx[i], p2->vy[i]); }
-    inc[0].v = xmul(xf2, a); inc[0].id = mkid(edge1, i1, 1, 0);
-    inc[1].v = xmul(xf2, b); inc[1].id = mkid(edge1, i2, 1, 0);
+    inc[0].v = xmul(xf2, v2(p2->vx[i1], p2->vy[i1])); inc[0].id = mkid(edge1, i1, 1, 0);
+    inc[1].v = xmul(xf2, v2(p2->vx[i2], p2->vy[i2])); inc[1].id = mkid(edge1, i2, 1, 0);
   }
   const int iv1 = edge1, iv2 = edge1 + 1 < p1->n ? edge1 + 1 : 0;
-  V2 v11 = v2(0, 0), v12 = v2(0, 0);
-  for (int i = 0; i < 8; ++i) { if (i == iv1) v11 = v2(p1->vx[i], p1->vy[i]); if (i == iv2) v12 = v2(p1->vx[i], p1->vy[i]); }
+  V2 v11 = v2(p1->vx[iv1], p1->vy[iv1]), v12 = v2(p1->vx[iv2], p1->vy[iv2]);
   V2 localTangent = v12 - v11;
   { const float len = length(localTangent); if (len >= B2_EPSILON) { const float inv = 1.0f / len; localTangent.x *= inv; localTangent.y *= inv; } }
   const V2 localNormal = cross(localTangent, 1.0f);

@@ -17,32 +17,32 @@
 
 namespace col {
 
+// Tile sensor hull (3 or 4 vertices) kept in NAMED registers: every loop over it is fully unrolled with an
+// `i < n` predicate so that nothing is indexed dynamically (dynamic indexing would put it in scratch memory).
 struct TilePoly { int n; float vx[4], vy[4], nx[4], ny[4]; };
 
-// max over A's edge normals of the min projection of B's vertices (A from LDS, B = tile)
+#define TILE_FOR(i) _Pragma("unroll") for (int i = 0; i < 4; ++i)
+
+// max over A's edge normals of the min projection of B's vertices (A = car fixture in LDS, B = tile)
 __device__ __forceinline__ float sat_fixture_tile(const float* avx, const float* avy, const float* anx, const float* any_, int an,
                                                   const TilePoly& T) {
   float best = -MCR_MAXFLT;
   for (int i = 0; i < an; ++i) {
+    const float nx = anx[i], ny = any_[i], ax = avx[i], ay = avy[i];
     float mn = MCR_MAXFLT;
-    for (int j = 0; j < T.n; ++j) {
-      float d = anx[i] * (T.vx[j] - avx[i]) + any_[i] * (T.vy[j] - avy[i]);
-      mn = mcr_min(mn, d);
-    }
+    TILE_FOR(j) { if (j < T.n) { const float d = nx * (T.vx[j] - ax) + ny * (T.vy[j] - ay); mn = mcr_min(mn, d); } }
     best = mcr_max(best, mn);
   }
   return best;
 }
 __device__ __forceinline__ float sat_tile_fixture(const TilePoly& T, const float* bvx, const float* bvy, int bn) {
-  float best = -MCR_MAXFLT;
-  for (int i = 0; i < T.n; ++i) {
-    float mn = MCR_MAXFLT;
-    for (int j = 0; j < bn; ++j) {
-      float d = T.nx[i] * (bvx[j] - T.vx[i]) + T.ny[i] * (bvy[j] - T.vy[i]);
-      mn = mcr_min(mn, d);
-    }
-    best = mcr_max(best, mn);
+  float mn[4] = {MCR_MAXFLT, MCR_MAXFLT, MCR_MAXFLT, MCR_MAXFLT};
+  for (int j = 0; j < bn; ++j) {
+    const float bx = bvx[j], by = bvy[j];
+    TILE_FOR(i) { const float d = T.nx[i] * (bx - T.vx[i]) + T.ny[i] * (by - T.vy[i]); mn[i] = mcr_min(mn[i], d); }
   }
+  float best = -MCR_MAXFLT;
+  TILE_FOR(i) { if (i < T.n) best = mcr_max(best, mn[i]); }
   return best;
 }
 __device__ __forceinline__ float pt_seg_d2(float px, float py, float ax, float ay, float bx, float by) {
@@ -60,11 +60,19 @@ __device__ __forceinline__ bool overlap(const float* avx, const float* avy, cons
   float s = mcr_max(sat_fixture_tile(avx, avy, anx, any_, an, T), sat_tile_fixture(T, avx, avy, an));
   if (s > TH) return false;
   if (s <= 0.0f) return true;
+  // exact distance between the disjoint convex polygons: min over vertex-edge pairs, both ways
+  float ex[4], ey[4];                                  // end point of tile edge j: vertex (j+1) % n
+  ex[0] = T.vx[1]; ey[0] = T.vy[1]; ex[1] = T.vx[2]; ey[1] = T.vy[2];
+  ex[2] = T.n == 3 ? T.vx[0] : T.vx[3]; ey[2] = T.n == 3 ? T.vy[0] : T.vy[3]; ex[3] = T.vx[0]; ey[3] = T.vy[0];
   float d2 = MCR_MAXFLT;
-  for (int i = 0; i < an; ++i)
-    for (int j = 0; j < T.n; ++j) { int k = (j + 1) % T.n; d2 = mcr_min(d2, pt_seg_d2(avx[i], avy[i], T.vx[j], T.vy[j], T.vx[k], T.vy[k])); }
-  for (int i = 0; i < T.n; ++i)
-    for (int j = 0; j < an; ++j) { int k = (j + 1) % an; d2 = mcr_min(d2, pt_seg_d2(T.vx[i], T.vy[i], avx[j], avy[j], avx[k], avy[k])); }
+  for (int i = 0; i < an; ++i) {
+    const float px = avx[i], py = avy[i];
+    TILE_FOR(j) { if (j < T.n) d2 = mcr_min(d2, pt_seg_d2(px, py, T.vx[j], T.vy[j], ex[j], ey[j])); }
+  }
+  TILE_FOR(i) {
+    if (i < T.n)
+      for (int j = 0; j < an; ++j) { const int k = (j + 1 == an) ? 0 : j + 1; d2 = mcr_min(d2, pt_seg_d2(T.vx[i], T.vy[i], avx[j], avy[j], avx[k], avy[k])); }
+  }
   return d2 < TH * TH;
 }
 
@@ -195,7 +203,15 @@ __global__ __launch_bounds__(64) void k_collide(McrParams p, int pass) {
   // Candidate fixture pairs are enumerated in the DEFINED contact order (carA, fixA, carB, fixB); touching
   // ones are compacted in that order and inherit the stored impulses of the previous step by feature id.
   uint32_t* store = p.cc_store + (size_t)env * (MCR_CC_MAX * MCR_CC_WORDS + 4);
+  // cheap exit: no pair of car boxes (tight AABB + 0.05) overlaps -> no fixture pair can touch
+  bool any_pair = false;
   if (p.car_contacts && N > 1) {
+    for (int a = 0; a < N - 1; ++a) for (int b = a + 1; b < N; ++b)
+      any_pair = any_pair || !(cbox[a][0] > cbox[b][2] || cbox[a][2] < cbox[b][0] || cbox[a][1] > cbox[b][3] || cbox[a][3] < cbox[b][1]);
+  }
+  if (p.car_contacts && N > 1 && !any_pair) {
+    if (lane == 0) { store[0] = 0; store[1] = 0; }
+  } else if (p.car_contacts && N > 1) {
     const int old_n = (pass == 1) ? 0 : (int)store[0];
     const McrShapes& S = *p.shapes;
     int total = 0;
@@ -218,8 +234,7 @@ __global__ __launch_bounds__(64) void k_collide(McrParams p, int pass) {
         const int ia = a * 8 + fa, ib = b * 8 + fb;
         const float4 A = fbox[ia], Bb = fbox[ib];
         if (!(A.x > Bb.z || A.z < Bb.x || A.y > Bb.w || A.w < Bb.y)) {
-          cc::LPoly pa, pb;
-          cc::load_poly(fa < 4 ? S.hull[fa] : S.wheel, pa); cc::load_poly(fb < 4 ? S.hull[fb] : S.wheel, pb);
+          const McrPoly& pa = fa < 4 ? S.hull[fa] : S.wheel; const McrPoly& pb = fb < 4 ? S.hull[fb] : S.wheel;
           Xf xa, xb; const float4 ta = fxf[ia], tb = fxf[ib];
           xa.p = v2(ta.x, ta.y); xa.q.s = ta.z; xa.q.c = ta.w; xb.p = v2(tb.x, tb.y); xb.q.s = tb.z; xb.q.c = tb.w;
           cc::collide_polygons(M, pa, xa, pb, xb);

@@ -112,7 +112,14 @@ __global__ __launch_bounds__(VIEW_THREADS) void k_view(McrParams p, float* __res
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int N = p.N, BN = p.BN;
-  const int vw = p.env0 * N + blockIdx.x;
+  // XCD-aware mapping: workgroup b runs on XCD b % 8, so hand the N views of one env to workgroups b, b+8,
+  // b+16, ... — they share that XCD's L2 for the env's road_poly instead of fetching it once per XCD.
+  int vw;
+  {
+    const int b = blockIdx.x, full = (p.nenv / 8) * 8 * N;
+    if (b < full) { const int grp = b / (8 * N), r = b - grp * 8 * N; vw = (p.env0 + grp * 8 + (r & 7)) * N + (r >> 3); }
+    else vw = p.env0 * N + b;
+  }
   const int env = vw / N, agent = vw % N;
   const McrEnvState es = p.env[env];
   if (!es.active) return;
