@@ -127,6 +127,8 @@ int mcr_timing_enable(mcr_env* h, int mask);
 /* profiling ablations of the raster kernel (bit 0 skip flags block, 1 skip road shading, 2 skip cars, 3 skip
  * write-out, 4 skip binning/cull); 0 in production.  Results are WRONG when non-zero. */
 int mcr_debug_set(mcr_env* h, int value);
+/* debug bit 5 (32): the raster kernel stamps s_memtime per phase; read the 64-float tail of a view's scratch */
+int mcr_debug_read_view_scratch(mcr_env* h, int view, void* out, int nbytes);
 int mcr_timing_read(mcr_env* h, double* ms_out /*[5]*/, int64_t* launches_out /*[5]*/);
 
 #ifdef __cplusplus

@@ -48,6 +48,7 @@ SYMBOLS = {
     "mcr_sincos_device": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "mcr_timing_enable": (_i, [_vp, _i]),
     "mcr_debug_set": (_i, [_vp, _i]),
+    "mcr_debug_read_view_scratch": (_i, [_vp, _i, _vp, _i]),
     "mcr_timing_read": (_i, [_vp, _vp, _vp]),
 }
 

@@ -579,12 +579,20 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
     for (int q = 3; q >= 0; --q) joint_init(J[q], b[0], b[q + 1], S.anchor_x[q], S.anchor_y[q], lcx, lcy, mH, iH, mW, iW);
   }
   const float maxImpulse = h * (float)(180 * 900 * MCR_SIZE * MCR_SIZE);
-  for (int it = 0; it < 180; ++it) {
+  if (!wave_cc) {
+    // hot loop of the common case: nothing but the four revolute joints, state in registers
     if (run) {
+      for (int it = 0; it < 180; ++it) {
 #pragma unroll
-      for (int q = 3; q >= 0; --q) joint_velocity(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);
+        for (int q = 3; q >= 0; --q) joint_velocity(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);
+      }
     }
-    if (wave_cc) {
+  } else {
+    for (int it = 0; it < 180; ++it) {
+      if (run) {
+#pragma unroll
+        for (int q = 3; q >= 0; --q) joint_velocity(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);
+      }
       if (ccn > 0) {
 #pragma unroll
         for (int k = 0; k < 5; ++k) { xv[0 * 5 + k][lane] = b[k].vx; xv[1 * 5 + k][lane] = b[k].vy; xv[2 * 5 + k][lane] = b[k].w; }
@@ -858,6 +866,34 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
       vp[VP_IND + (5 + i) * 4 + 2] = (float)(2 * hH) * ky; vp[VP_IND + (5 + i) * 4 + 3] = (float)(4 * hH) * ky;
     }
     vp[VP_HUDTOP] = hud_top;
+    // world-space vertices of the 12 Car.draw polygons (trans*v in f32, as pybox2d hands them to the viewer)
+    float* cp = p.carpoly + (size_t)ci * MCR_CARPOLY_FLOATS;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const Xf wxf = xf_of(v2(b[k + 1].cx, b[k + 1].cy), b[k + 1].a, v2(0.0f, 0.0f));
+      float* box = cp + (2 * k) * 16; float* stripe = cp + (2 * k + 1) * 16;
+      for (int i = 0; i < 8; ++i) { const int ii = i < 4 ? i : 3; const V2 w = xmul(wxf, v2(S.wheel.vx[ii], S.wheel.vy[ii])); box[i * 2] = w.x; box[i * 2 + 1] = w.y; }   // padded to 8 by repeating the last vertex
+      cp[MCR_CARPOLY_NOFF + 2 * k] = __int_as_float(S.wheel.n);
+      const double a1 = phase[k], a2 = phase[k] + 1.2;
+      const double s1 = sin(a1), s2 = sin(a2); double c1 = cos(a1), c2 = cos(a2);
+      int ns = 0;
+      if (!(s1 > 0 && s2 > 0)) {
+        if (s1 > 0) c1 = np_sign(c1);
+        if (s2 > 0) c2 = np_sign(c2);
+        ns = 4;
+        const float lx[4] = {(float)(-MCR_WHEEL_W * MCR_SIZE), (float)(+MCR_WHEEL_W * MCR_SIZE), (float)(+MCR_WHEEL_W * MCR_SIZE), (float)(-MCR_WHEEL_W * MCR_SIZE)};
+        const float ly[4] = {(float)(+MCR_WHEEL_R * c1 * MCR_SIZE), (float)(+MCR_WHEEL_R * c1 * MCR_SIZE), (float)(+MCR_WHEEL_R * c2 * MCR_SIZE), (float)(+MCR_WHEEL_R * c2 * MCR_SIZE)};
+        for (int i = 0; i < 8; ++i) { const int ii = i < 4 ? i : 3; const V2 w = xmul(wxf, v2(lx[ii], ly[ii])); stripe[i * 2] = w.x; stripe[i * 2 + 1] = w.y; }
+      }
+      cp[MCR_CARPOLY_NOFF + 2 * k + 1] = __int_as_float(ns);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float* hp = cp + (8 + k) * 16;
+      const int n = S.hull[k].n;
+      for (int i = 0; i < 8; ++i) { const int ii = i < n ? i : n - 1; const V2 w = xmul(hxf, v2(S.hull[k].vx[ii], S.hull[k].vy[ii])); hp[i * 2] = w.x; hp[i * 2 + 1] = w.y; }
+      cp[MCR_CARPOLY_NOFF + 8 + k] = __int_as_float(n);
+    }
   }
 }
 

@@ -6,15 +6,17 @@
 // car state, write 27,648 B of packed RGB with 16-byte-per-lane stores.  Everything else lives in ~30 KB of
 // LDS so that 5 workgroups (20 waves) share a CU:
 //   1. camera (:540-556) -> 2x3 world->pixel matrix (f32, like the GL pipeline);
-//   2. cull + setup: threads stride over quads, transform, reject by pixel bbox (incl. "contains no pixel
-//      centre"), store oriented edge equations of the survivors (LDS; rare overflow spills to a per-view HBM
-//      scratch) and the car polygons (12 per car);
+//   2. cull in two passes: every thread transforms its quads and rejects by pixel bbox (incl. "contains no
+//      pixel centre"), survivors are ballot-compacted; then consecutive threads set the survivors up (oriented
+//      edge equations -> LDS, rare overflow spills to a per-view HBM scratch).  Car polygons arrive as world
+//      vertices from k_dynamics (12 per car).  The backward/on-grass bookkeeping rides on the same quad pass:
+//      f32 prefilter on the quads already in registers, exact f64 only for the 1-3 candidates;
 //   3. bin: the thread that set a polygon up appends it to the lists of the 8x8-pixel bins it can touch
 //      (box-vs-convex test, LDS atomics; order is irrelevant because the highest draw index wins);
 //   4. shade: one wave per bin, lane = pixel; list walking is wave-uniform (LDS broadcast reads).  Background
 //      (playfield + checker) is analytic in world space; road/kerb: highest road_poly index wins (== painter's
 //      order); then cars; then the HUD in window space.  Result: one palette index per pixel (u8 framebuffer);
-//   5. write-out: palette -> packed RGB, 16 B per lane, three byte-phase patterns.
+//   5. write-out: 4 pixels (one aligned palette word) -> 12 packed RGB bytes per lane, contiguous across lanes.
 // Sampling rule: pixel centres; a pixel belongs to a convex polygon iff all oriented edge functions are >= 0.
 #pragma once
 #include "mcr_kernels.h"
@@ -104,13 +106,46 @@ __device__ __forceinline__ bool box_may_touch(const float* e, int n, float X0, f
   }
   return !out;
 }
+#define UNI(x) __builtin_amdgcn_readfirstlane(x)
+// per-phase s_memtime stamps of thread 0 (debug bit 32) into the tail of the view's spill area
+#define PHASE_STAMP(i) do { if ((dbg & 32) && tid == 0) ((unsigned long long*)(spill + VIEW_SCRATCH_FLOATS - 64))[i] = __builtin_readcyclecounter(); } while (0)
+
+// strict-interior point-in-quad (shapely `within`, mcr.py:470-472) on the f64 polygon the reference builds for
+// tile t (kerb == false, :313-317) or for its kerb (kerb == true, :329-333)
+__device__ inline bool point_in_road_poly_f64(const uint8_t* __restrict__ slot, int t, int T, bool kerb, double px, double py) {
+  const double* TX = (const double*)(slot + MCR_OFF_TRACK_X); const double* TY = (const double*)(slot + MCR_OFF_TRACK_Y); const double* TB = (const double*)(slot + MCR_OFF_TRACK_B);
+  const double* TC = (const double*)(slot + MCR_OFF_TRACK_C); const double* TS = (const double*)(slot + MCR_OFF_TRACK_S);
+  const double TW = 40 / MCR_SCALE, TBW = 8 / MCR_SCALE;
+  const int u = t == 0 ? T - 1 : t - 1;
+  const double x1 = TX[t], y1 = TY[t], c1 = TC[t], s1 = TS[t], x2 = TX[u], y2 = TY[u], c2 = TC[u], s2 = TS[u];
+  double X[4], Y[4];
+  if (!kerb) {
+    X[0] = x1 - TW * c1; Y[0] = y1 - TW * s1; X[1] = x1 + TW * c1; Y[1] = y1 + TW * s1;
+    X[2] = x2 + TW * c2; Y[2] = y2 + TW * s2; X[3] = x2 - TW * c2; Y[3] = y2 - TW * s2;
+  } else {
+    const double side = dyn::np_sign(TB[u] - TB[t]);
+    const double w0 = side * TW, w1 = side * (TW + TBW);
+    X[0] = x1 + w0 * c1; Y[0] = y1 + w0 * s1; X[1] = x1 + w1 * c1; Y[1] = y1 + w1 * s1;
+    X[2] = x2 + w1 * c2; Y[2] = y2 + w1 * s2; X[3] = x2 + w0 * c2; Y[3] = y2 + w0 * s2;
+  }
+  bool pos = true, neg = true;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = (i + 1) & 3;
+    const double cr = (X[j] - X[i]) * (py - Y[i]) - (Y[j] - Y[i]) * (px - X[i]);
+    if (!(cr > 0)) pos = false;
+    if (!(cr < 0)) neg = false;
+  }
+  return pos || neg;
+}
 
 // flags_mode: 1 = evaluate the backward/on-grass block (:446-495) for this agent.
 // dynamic LDS: car polygon records, N*12 x 6 float4 (8 edges each, padded with always-true edges)
-__global__ __launch_bounds__(VIEW_THREADS) void k_view(McrParams p, float* __restrict__ scratch, int flags_mode, int only_just_reset) {
+__global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __restrict__ scratch, int flags_mode, int only_just_reset) {
   using namespace view;
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
+  const int lane = tid & 63;
+  const int wave = UNI(tid >> 6);
   const int N = p.N, BN = p.BN;
   // XCD-aware mapping: workgroup b runs on XCD b % 8, so hand the N views of one env to workgroups b, b+8,
   // b+16, ... — they share that XCD's L2 for the env's road_poly instead of fetching it once per XCD.
@@ -134,80 +169,141 @@ __global__ __launch_bounds__(VIEW_THREADS) void k_view(McrParams p, float* __res
   extern __shared__ __attribute__((aligned(16))) float4 car8[];             // [N*12][6]
   __shared__ __attribute__((aligned(16))) uint8_t fb[96 * 96];
   __shared__ __attribute__((aligned(16))) float4 qe[VIS_LDS][3];          // 4 oriented edges (A,B,C) of each surviving quad
-  __shared__ uint32_t qinfo[VIS_LDS];                                       // bins(16) | quad index(10) << 3 | colour(3)
+  __shared__ uint32_t qinfo[VIS_LDS];                                       // quad index << 3 | colour
   __shared__ uint16_t bins[NBINS][BIN_CAP];
   __shared__ int bcnt[NBINS];
+  __shared__ uint16_t surv[MCR_QUAD_CAP];
   __shared__ uint32_t cinfo[CARPOLY_CAP];                                   // 0x100 | palette ; 0 = not drawn
   __shared__ uint32_t pal[32];
-  __shared__ double red_d[4]; __shared__ int red_i[4];
-  __shared__ int nvis, any_inside, next_bin;
+  __shared__ float fmin_w[4];
+  __shared__ double cand_d[16]; __shared__ int cand_i[16];
+  __shared__ int nsurv, ncand, any_inside;
+  __shared__ float hud[32];                                                 // 7 gauge rectangles (x0 x1 y0 y1) + hud_top
 
-  if (tid == 0) { nvis = 0; any_inside = 0; next_bin = 4; }
+  if (tid == 0) { nsurv = 0; ncand = 0; any_inside = 0; }
   if (tid < 32) pal[tid] = palette_rgb(tid);
   if (tid < NBINS) bcnt[tid] = 0;
+  if (p.obs != nullptr && tid >= 64 && tid < 64 + 29) hud[tid - 64] = p.viewp[(size_t)(vw) * MCR_VIEWP_FLOATS + VP_IND + (tid - 64)];
   const uint32_t old_flags = p.caru[CU_FLAGS * BN + ci];
   const float hvx = p.carf[(CF_VX + 0) * BN + ci], hvy = p.carf[(CF_VY + 0) * BN + ci], ha = p.carf[(CF_A + 0) * BN + ci];
   const bool draw = p.obs != nullptr;
+  const bool do_flags = flags_mode && !(dbg & 1);
   const float* __restrict__ vp = p.viewp + (size_t)ci * MCR_VIEWP_FLOATS;
   float m00 = 0, m01 = 0, m10 = 0, m11 = 0, ctx = 0, cty = 0;
   if (draw) { m00 = vp[VP_CAM + 0]; m01 = vp[VP_CAM + 1]; m10 = vp[VP_CAM + 2]; m11 = vp[VP_CAM + 3]; ctx = vp[VP_CAM + 4]; cty = vp[VP_CAM + 5]; }
   float* __restrict__ spill = scratch + (size_t)vw * VIEW_SCRATCH_FLOATS;
+  // hull.position (body origin) for the bookkeeping block
+  float fpx = 0.0f, fpy = 0.0f;
+  if (do_flags) { const Xf hxf = xf_of(v2(p.carf[(CF_CX + 0) * BN + ci], p.carf[(CF_CY + 0) * BN + ci]), ha, v2(S.hull_lcx, S.hull_lcy)); fpx = hxf.p.x; fpy = hxf.p.y; }
+  const double dpx = (double)fpx, dpy = (double)fpy;
+  PHASE_STAMP(0);
   __syncthreads();
+  PHASE_STAMP(1);
 
-  // ---- car polygons (Car.draw): per car 4x(wheel box, white stripe) then 4 hull polys, cars in id order.
-  // Threads 0..12N-1 set one polygon up each, then join the road loop.
-  if (draw && tid < N * 12) {
-    const int k = tid, c = k / 12, j = k % 12;
-    const int cj = env * N + c;
-    uint32_t info = 0;
-    float lx[8], ly[8]; int n = 0; uint32_t colr = 0; Xf xf;
-    if (j < 8) {
-      const int wk = j >> 1;
-      const V2 cc = v2(p.carf[(CF_CX + 1 + wk) * BN + cj], p.carf[(CF_CY + 1 + wk) * BN + cj]);
-      xf = xf_of(cc, p.carf[(CF_A + 1 + wk) * BN + cj], v2(0.0f, 0.0f));
-      if ((j & 1) == 0) { n = S.wheel.n; for (int i = 0; i < n; ++i) { lx[i] = S.wheel.vx[i]; ly[i] = S.wheel.vy[i]; } colr = PAL_BLACK; }
-      else {
-        const double ph = p.card[(CD_PHASE + wk) * BN + cj];
-        const double a1 = ph, a2 = ph + 1.2;
-        const double s1 = sin(a1), s2 = sin(a2); double c1 = cos(a1), c2 = cos(a2);
-        if (!(s1 > 0 && s2 > 0)) {
-          if (s1 > 0) c1 = dyn::np_sign(c1);
-          if (s2 > 0) c2 = dyn::np_sign(c2);
-          n = 4;
-          lx[0] = (float)(-MCR_WHEEL_W * MCR_SIZE); ly[0] = (float)(+MCR_WHEEL_R * c1 * MCR_SIZE);
-          lx[1] = (float)(+MCR_WHEEL_W * MCR_SIZE); ly[1] = (float)(+MCR_WHEEL_R * c1 * MCR_SIZE);
-          lx[2] = (float)(+MCR_WHEEL_W * MCR_SIZE); ly[2] = (float)(+MCR_WHEEL_R * c2 * MCR_SIZE);
-          lx[3] = (float)(-MCR_WHEEL_W * MCR_SIZE); ly[3] = (float)(+MCR_WHEEL_R * c2 * MCR_SIZE);
-          colr = PAL_WHEELWHITE;
+  const float4* __restrict__ QA = (const float4*)(slot + MCR_OFF_QA); const float4* __restrict__ QB = (const float4*)(slot + MCR_OFF_QB);
+  const uint32_t* __restrict__ QM = (const uint32_t*)(slot + MCR_OFF_QMETA);
+
+  // ---- pass 1 over road_poly: cull (ballot-compacted survivor list) + bookkeeping prefilter
+  float cd2[3] = {MCR_MAXFLT, MCR_MAXFLT, MCR_MAXFLT}; int cti[3] = {-1, -1, -1};       // nearest-track-point candidates (f32)
+  bool inside = false;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int q = tid + r * VIEW_THREADS;
+    bool keep = false;
+    if (q < P) {
+      const float4 a = QA[q], b = QB[q];
+      const uint32_t meta = QM[q];
+      if (draw && !(dbg & 16)) {
+        float x0 = MCR_MAXFLT, x1 = -MCR_MAXFLT, y0 = MCR_MAXFLT, y1 = -MCR_MAXFLT;
+        const float wx[4] = {a.x, a.z, b.x, b.z}, wy[4] = {a.y, a.w, b.y, b.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float px = m00 * wx[i] + m01 * wy[i] + ctx, py = m10 * wx[i] + m11 * wy[i] + cty;
+          x0 = fminf(x0, px); x1 = fmaxf(x1, px); y0 = fminf(y0, py); y1 = fmaxf(y1, py);
+        }
+        int i0, i1, j0, j1;
+        keep = centre_range(x0, x1, 0, 95, i0, i1) && centre_range(y0, y1, 12, 95, j0, j1);   // rows < 12: HUD bar
+      }
+      if (do_flags) {
+        const uint32_t tile1 = (meta >> 8) & 0x3ffu, owner1 = meta >> 18;
+        // on-grass: f32 bbox of the quad (+margin for the f32 rounding of its vertices) before the exact f64 test
+        const float bx0 = fminf(fminf(a.x, a.z), fminf(b.x, b.z)) - 0.02f, bx1 = fmaxf(fmaxf(a.x, a.z), fmaxf(b.x, b.z)) + 0.02f;
+        const float by0 = fminf(fminf(a.y, a.w), fminf(b.y, b.w)) - 0.02f, by1 = fmaxf(fmaxf(a.y, a.w), fmaxf(b.y, b.w)) + 0.02f;
+        if (fpx >= bx0 && fpx <= bx1 && fpy >= by0 && fpy <= by1)
+          inside = inside || point_in_road_poly_f64(slot, (int)(tile1 ? tile1 : owner1) - 1, T, tile1 == 0, dpx, dpy);
+        if (tile1) {   // track point ~ midpoint of the tile's leading edge (v0,v1): f32 estimate of the distance
+          const float mx = 0.5f * (a.x + a.z), my = 0.5f * (a.y + a.w);
+          const float ddx = fpx - mx, ddy = fpy - my;
+          cd2[r] = ddx * ddx + ddy * ddy; cti[r] = (int)tile1 - 1;
         }
       }
-    } else {
-      const int hk = j - 8;
-      const V2 cc = v2(p.carf[(CF_CX + 0) * BN + cj], p.carf[(CF_CY + 0) * BN + cj]);
-      xf = xf_of(cc, p.carf[(CF_A + 0) * BN + cj], v2(S.hull_lcx, S.hull_lcy));
-      n = S.hull[hk].n; for (int i = 0; i < n; ++i) { lx[i] = S.hull[hk].vx[i]; ly[i] = S.hull[hk].vy[i]; }
-      colr = PAL_CAR0 + (c & 7);                                              // CAR_COLORS[c % 8] (:402)
-      if (p.use_ego_color) colr = (c == agent) ? PAL_CAR0 + 0 : PAL_CAR0 + 1; // (:560-563)
     }
+    const unsigned long long mask = __ballot(keep);
+    if (mask) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&nsurv, __popcll(mask));
+      base = __shfl(base, 0);
+      if (keep) surv[base + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)q;
+    }
+  }
+  if (do_flags) {
+    if (__any(inside) && lane == 0) atomicOr(&any_inside, 1);
+    float m = fminf(cd2[0], fminf(cd2[1], cd2[2]));
+    for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
+    if (lane == 0) fmin_w[wave] = m;
+  }
+
+  PHASE_STAMP(2);
+  // ---- car polygons (Car.draw): world vertices come from k_dynamics; threads 0..12N-1 set one polygon up each
+  if (draw && tid < N * 12) {
+    const int k = tid, c = k / 12, j = k % 12;
+    const float* __restrict__ cp = p.carpoly + (size_t)(env * N + c) * MCR_CARPOLY_FLOATS;
+    // one burst: 8 vertices (4 x float4) + the vertex count, all issued before anything is consumed
+    const float4* __restrict__ cv = (const float4*)(cp + j * 16);
+    const float4 v01 = cv[0], v23 = cv[1], v45 = cv[2], v67 = cv[3];
+    const int n = __float_as_int(cp[MCR_CARPOLY_NOFF + j]);
+    uint32_t info = 0;
     if (n > 0 && !(dbg & 4)) {
+      uint32_t colr;
+      if (j < 8) colr = (j & 1) ? PAL_WHEELWHITE : PAL_BLACK;
+      else { colr = PAL_CAR0 + (c & 7); if (p.use_ego_color) colr = (c == agent) ? PAL_CAR0 + 0 : PAL_CAR0 + 1; }   // :402, :560-563
+      // every car polygon arrives padded to 8 vertices (last vertex repeated): the extra edges are degenerate
+      // (A = B = C = 0 -> always "inside"), so all loops below are fixed-size and fully unrolled
+      const float wxs[8] = {v01.x, v01.z, v23.x, v23.z, v45.x, v45.z, v67.x, v67.z}, wys[8] = {v01.y, v01.w, v23.y, v23.w, v45.y, v45.w, v67.y, v67.w};
       float px[8], py[8];
       float x0 = MCR_MAXFLT, x1 = -MCR_MAXFLT, y0 = MCR_MAXFLT, y1 = -MCR_MAXFLT;
-      for (int i = 0; i < n; ++i) {
-        const V2 w = xmul(xf, v2(lx[i], ly[i]));                 // trans*v in f32, as pybox2d returns it
-        px[i] = m00 * w.x + m01 * w.y + ctx; py[i] = m10 * w.x + m11 * w.y + cty;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        px[i] = m00 * wxs[i] + m01 * wys[i] + ctx; py[i] = m10 * wxs[i] + m11 * wys[i] + cty;
         x0 = fminf(x0, px[i]); x1 = fmaxf(x1, px[i]); y0 = fminf(y0, py[i]); y1 = fmaxf(y1, py[i]);
       }
       float e[24];
       int ix0, ix1, iy0, iy1;
-      if (centre_range(x0, x1, 0, 95, ix0, ix1) && centre_range(y0, y1, 12, 95, iy0, iy1) && edge_setup(px, py, n, e)) {
-        for (int i = n * 3; i < 24; i += 3) { e[i] = 0.0f; e[i + 1] = 0.0f; e[i + 2] = 1.0f; }     // always-true padding edges
+      float area = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const int j = (i + 1) & 7; area += px[i] * py[j] - px[j] * py[i]; }
+      if (centre_range(x0, x1, 0, 95, ix0, ix1) && centre_range(y0, y1, 12, 95, iy0, iy1) && area != 0.0f) {
+        const float sg = area > 0.0f ? 1.0f : -1.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int j = (i + 1) & 7;
+          const float ex = px[j] - px[i], ey = py[j] - py[i];
+          const float A = -sg * ey, B = sg * ex;
+          e[i * 3 + 0] = A; e[i * 3 + 1] = B; e[i * 3 + 2] = -(A * px[i] + B * py[i]);
+        }
 #pragma unroll
         for (int i = 0; i < 6; ++i) car8[k * 6 + i] = make_float4(e[i * 4], e[i * 4 + 1], e[i * 4 + 2], e[i * 4 + 3]);
         info = 0x100u | colr;
         for (int by = iy0 >> 3; by <= (iy1 >> 3); ++by)
           for (int bx = ix0 >> 3; bx <= (ix1 >> 3); ++bx) {
-            const float X0 = (float)(bx * 8) + 0.5f, Y0 = (float)(by * 8) + 0.5f;
-            if (!box_may_touch(e, n, X0, X0 + 7.0f, Y0, Y0 + 7.0f)) continue;
+            const float X0 = (float)(bx * 8) + 0.5f, Y0 = (float)(by * 8) + 0.5f, X1 = X0 + 7.0f, Y1 = Y0 + 7.0f;
+            bool out = false;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+              const float A = e[kk * 3], B = e[kk * 3 + 1], C = e[kk * 3 + 2];
+              out = out || (A * (A >= 0.0f ? X1 : X0) + B * (B >= 0.0f ? Y1 : Y0) + C < 0.0f);
+            }
+            if (out) continue;
             const int b = by * 12 + bx;
             const int at = atomicAdd(&bcnt[b], 1);
             if (at < BIN_CAP) bins[b][at] = (uint16_t)(CAR_KEY + k);
@@ -216,13 +312,17 @@ __global__ __launch_bounds__(VIEW_THREADS) void k_view(McrParams p, float* __res
     }
     cinfo[k] = info;
   }
+  PHASE_STAMP(3);
+  __syncthreads();
+  PHASE_STAMP(4);
 
-  // ---- road quads: cull + edge setup + bin
-  if (draw && !(dbg & 16)) {
-    const float4* QA = (const float4*)(slot + MCR_OFF_QA); const float4* QB = (const float4*)(slot + MCR_OFF_QB);
-    const uint32_t* QM = (const uint32_t*)(slot + MCR_OFF_QMETA);
-    const uint16_t* tflags = p.tile_flags + (size_t)env * MCR_TILE_CAP;
-    for (int q = tid; q < P; q += VIEW_THREADS) {
+  // ---- pass 2: dense set-up of the survivors (edge equations, colour, bins)
+  const int nq = nsurv;
+  const int nq_lds = nq < VIS_LDS ? nq : VIS_LDS;
+  if (draw) {
+    const uint16_t* __restrict__ tflags = p.tile_flags + (size_t)env * MCR_TILE_CAP;
+    for (int s = tid; s < nq; s += VIEW_THREADS) {
+      const int q = surv[s];
       const float4 a = QA[q], b = QB[q];
       const float wx[4] = {a.x, a.z, b.x, b.z}, wy[4] = {a.y, a.w, b.y, b.w};
       float px[4], py[4];
@@ -233,14 +333,14 @@ __global__ __launch_bounds__(VIEW_THREADS) void k_view(McrParams p, float* __res
         x0 = fminf(x0, px[i]); x1 = fmaxf(x1, px[i]); y0 = fminf(y0, py[i]); y1 = fmaxf(y1, py[i]);
       }
       int ix0, ix1, iy0, iy1;
-      if (!centre_range(x0, x1, 0, 95, ix0, ix1) || !centre_range(y0, y1, 12, 95, iy0, iy1)) continue;   // rows < 12: HUD bar
+      centre_range(x0, x1, 0, 95, ix0, ix1); centre_range(y0, y1, 12, 95, iy0, iy1);
       float e[12];
-      if (!edge_setup(px, py, 4, e)) continue;
+      const bool ok = edge_setup(px, py, 4, e);
+      if (!ok) { for (int i = 0; i < 12; i += 3) { e[i] = 0.0f; e[i + 1] = 0.0f; e[i + 2] = -1.0f; } }   // never covers a pixel
       const uint32_t meta = QM[q];
-      uint32_t col = meta & 0xffu; const uint32_t tile1 = meta >> 8;
+      uint32_t col = meta & 0xffu; const uint32_t tile1 = (meta >> 8) & 0x3ffu;
       if (tile1 && (tflags[tile1 - 1] & 0x100u)) col = MCR_COL_ROAD0;           // touched tile -> ROAD_COLOR (:102-104)
       const uint32_t info = ((uint32_t)q << 3) | col;
-      const int s = atomicAdd(&nvis, 1);
       if (s < VIS_LDS) {
         qe[s][0] = make_float4(e[0], e[1], e[2], e[3]); qe[s][1] = make_float4(e[4], e[5], e[6], e[7]); qe[s][2] = make_float4(e[8], e[9], e[10], e[11]);
         qinfo[s] = info;
@@ -249,81 +349,55 @@ __global__ __launch_bounds__(VIEW_THREADS) void k_view(McrParams p, float* __res
         d[0] = make_float4(e[0], e[1], e[2], e[3]); d[1] = make_float4(e[4], e[5], e[6], e[7]); d[2] = make_float4(e[8], e[9], e[10], e[11]);
         d[3] = make_float4(__uint_as_float(info), 0.0f, 0.0f, 0.0f);
       }
-      for (int by = iy0 >> 3; by <= (iy1 >> 3); ++by)
-        for (int bx = ix0 >> 3; bx <= (ix1 >> 3); ++bx) {
-          const float X0 = (float)(bx * 8) + 0.5f, Y0 = (float)(by * 8) + 0.5f;
-          if (!box_may_touch(e, 4, X0, X0 + 7.0f, Y0, Y0 + 7.0f)) continue;
-          const int bb = by * 12 + bx;
-          const int at = atomicAdd(&bcnt[bb], 1);
-          if (at < BIN_CAP) bins[bb][at] = (uint16_t)s;
-        }
+      if (ok)
+        for (int by = iy0 >> 3; by <= (iy1 >> 3); ++by)
+          for (int bx = ix0 >> 3; bx <= (ix1 >> 3); ++bx) {
+            const float X0 = (float)(bx * 8) + 0.5f, Y0 = (float)(by * 8) + 0.5f;
+            const float X1 = X0 + 7.0f, Y1 = Y0 + 7.0f;
+            bool out = false;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              const float A = e[kk * 3], B = e[kk * 3 + 1], C = e[kk * 3 + 2];
+              out = out || (A * (A >= 0.0f ? X1 : X0) + B * (B >= 0.0f ? Y1 : Y0) + C < 0.0f);
+            }
+            if (out) continue;
+            const int bb = by * 12 + bx;
+            const int at = atomicAdd(&bcnt[bb], 1);
+            if (at < BIN_CAP) bins[bb][at] = (uint16_t)s;
+          }
     }
   }
-
-  // ---- backward / on-grass flags (:446-495) from the post-solve pose; they reach pixels one step later
-  const bool do_flags = flags_mode && !(dbg & 1);
+  // ---- bookkeeping stage 2: exact f64 distance for the tiles whose f32 distance is within the error band of the minimum
   if (do_flags) {
-    const Xf hxf = xf_of(v2(p.carf[(CF_CX + 0) * BN + ci], p.carf[(CF_CY + 0) * BN + ci]), ha, v2(S.hull_lcx, S.hull_lcy));
-    const double px = (double)hxf.p.x, py = (double)hxf.p.y;
-    const double* TX = (const double*)(slot + MCR_OFF_TRACK_X); const double* TY = (const double*)(slot + MCR_OFF_TRACK_Y); const double* TB = (const double*)(slot + MCR_OFF_TRACK_B);
-    const double* TC = (const double*)(slot + MCR_OFF_TRACK_C); const double* TS = (const double*)(slot + MCR_OFF_TRACK_S);
-    const uint32_t* TCNT = (const uint32_t*)(slot + MCR_OFF_TCNT);
-    const float4* TAABB = (const float4*)(slot + MCR_OFF_TAABB);
-    const double TW = 40 / MCR_SCALE, TBW = 8 / MCR_SCALE;
-    const float fpx = hxf.p.x, fpy = hxf.p.y, margin = (float)(8 / MCR_SCALE) + 0.01f;
-    double bd = 1e300; int bi = 0x7fffffff;
-    bool inside = false;
-    for (int t = tid; t < T; t += VIEW_THREADS) {
-      const double x1 = TX[t], y1 = TY[t];
-      const double dx = px - x1, dy = py - y1;
-      const double d = sqrt(dx * dx + dy * dy);            // np.linalg.norm(..., axis=1) then argmin (:465-467)
-      if (d < bd) { bd = d; bi = t; }
-      // strict-interior point-in-quad over road_poly (shapely `within`, :470-472) on the f64 polygons the
-      // reference builds (:313-317 tile, :329-333 kerb); a f32 AABB (+kerb width) prefilter skips far tiles
-      const float4 bb = TAABB[t];
-      if (fpx < bb.x - margin || fpx > bb.z + margin || fpy < bb.y - margin || fpy > bb.w + margin) continue;
-      const int u = t == 0 ? T - 1 : t - 1;
-      const double c1 = TC[t], s1 = TS[t], x2 = TX[u], y2 = TY[u], c2 = TC[u], s2 = TS[u];
-      const int nqd = (TCNT[t] & 0x100u) ? 2 : 1;
-      for (int k = 0; k < nqd; ++k) {
-        double X[4], Y[4];
-        if (k == 0) {
-          X[0] = x1 - TW * c1; Y[0] = y1 - TW * s1; X[1] = x1 + TW * c1; Y[1] = y1 + TW * s1;
-          X[2] = x2 + TW * c2; Y[2] = y2 + TW * s2; X[3] = x2 - TW * c2; Y[3] = y2 - TW * s2;
-        } else {
-          const double side = dyn::np_sign(TB[u] - TB[t]);
-          const double w0 = side * TW, w1 = side * (TW + TBW);
-          X[0] = x1 + w0 * c1; Y[0] = y1 + w0 * s1; X[1] = x1 + w1 * c1; Y[1] = y1 + w1 * s1;
-          X[2] = x2 + w1 * c2; Y[2] = y2 + w1 * s2; X[3] = x2 + w0 * c2; Y[3] = y2 + w0 * s2;
-        }
-        bool pos = true, neg = true;
+    const float m = fminf(fminf(fmin_w[0], fmin_w[1]), fminf(fmin_w[2], fmin_w[3]));
+    const float band = sqrtf(m) * (1.0f + 1e-5f) + 2e-3f;
+    const float thr = band * band;
+    const double* TX = (const double*)(slot + MCR_OFF_TRACK_X); const double* TY = (const double*)(slot + MCR_OFF_TRACK_Y);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int j = (i + 1) & 3;
-          const double cr = (X[j] - X[i]) * (py - Y[i]) - (Y[j] - Y[i]) * (px - X[i]);
-          if (!(cr > 0)) pos = false;
-          if (!(cr < 0)) neg = false;
-        }
-        inside = inside || pos || neg;
+    for (int r = 0; r < 3; ++r) {
+      if (cti[r] >= 0 && cd2[r] <= thr) {
+        const double dx = dpx - TX[cti[r]], dy = dpy - TY[cti[r]];
+        const double d = sqrt(dx * dx + dy * dy);             // np.linalg.norm(..., axis=1) then argmin (:465-467)
+        const int at = atomicAdd(&ncand, 1);
+        if (at < 16) { cand_d[at] = d; cand_i[at] = cti[r]; }
       }
     }
-    if (__any(inside) && lane == 0) atomicOr(&any_inside, 1);
-    // wave argmin (first index on ties), partials combined after the barrier
-    for (int o = 32; o > 0; o >>= 1) {
-      const double d2 = __shfl_xor(bd, o); const int i2 = __shfl_xor(bi, o);
-      if (d2 < bd || (d2 == bd && i2 < bi)) { bd = d2; bi = i2; }
-    }
-    if (lane == 0) { red_d[wave] = bd; red_i[wave] = bi; }
   }
+  PHASE_STAMP(5);
   __syncthreads();
-  const int nq = nvis;
-  const int nq_lds = nq < VIS_LDS ? nq : VIS_LDS;
+  PHASE_STAMP(6);
 
-  // ---- finish the flags on one lane of the last wave while the other waves start shading
+  // ---- bookkeeping stage 3 (one lane of the last wave, while the other waves shade)
   if (do_flags && tid == VIEW_THREADS - 1) {
     const double* TB = (const double*)(slot + MCR_OFF_TRACK_B);
-    double bd = red_d[0]; int bi = red_i[0];
-    for (int w = 1; w < 4; ++w) if (red_d[w] < bd || (red_d[w] == bd && red_i[w] < bi)) { bd = red_d[w]; bi = red_i[w]; }
+    int nc = ncand; if (nc > 16) nc = 16;
+    double bd = 1e300; int bi = 0x7fffffff;
+    for (int i = 0; i < nc; ++i) if (cand_d[i] < bd || (cand_d[i] == bd && cand_i[i] < bi)) { bd = cand_d[i]; bi = cand_i[i]; }
+    if (ncand > 16 || nc == 0) {          // pathological tie cluster: fall back to the exact full scan
+      const double* TX = (const double*)(slot + MCR_OFF_TRACK_X); const double* TY = (const double*)(slot + MCR_OFF_TRACK_Y);
+      bd = 1e300; bi = 0;
+      for (int t = 0; t < T; ++t) { const double dx = dpx - TX[t], dy = dpy - TY[t]; const double d = sqrt(dx * dx + dy * dy); if (d < bd) { bd = d; bi = t; } }
+    }
     const double TWO_PI = 2 * 3.141592653589793, PI = 3.141592653589793;
     double car_angle;
     const double vx = (double)hvx, vy = (double)hvy;
@@ -341,35 +415,42 @@ __global__ __launch_bounds__(VIEW_THREADS) void k_view(McrParams p, float* __res
   }
   if (!draw) return;
 
-  // ---- shade: one wave per 8x8 bin (lane = pixel), bins handed out dynamically
+  // ---- shade: one wave per 8x8 bin (lane = pixel); bin ids, list lengths and list entries are wave-uniform
+  // (scalar registers), so list walking costs scalar branches and broadcast LDS reads only
   {
     const bool show_flag = (old_flags & 1u) && p.backwards_flag;
     const float kx = 96.0f / 1000.0f, ky = 96.0f / 800.0f;
     float fe[9];
     { const float fx[3] = {900.0f * kx, 925.0f * kx, 950.0f * kx}, fy[3] = {30.0f * ky, 70.0f * ky, 30.0f * ky}; edge_setup(fx, fy, 3, fe); }
-    const float hud_top = vp[VP_HUDTOP];
+    const float hud_top = hud[VP_HUDTOP - VP_IND];
+    const int hud_rows = UNI((int)ceilf(hud_top * 0.125f));              // bin rows that can contain HUD pixels
     const int lx = lane & 7, ly = lane >> 3;
-    const float inv_kgrid = 1.0f / (float)(MCR_PLAYFIELD / 20.0), PF = (float)MCR_PLAYFIELD;
-    const float ax = vp[VP_INV + 0], bx_ = vp[VP_INV + 1], cx0 = vp[VP_INV + 2], ay = vp[VP_INV + 3], by_ = vp[VP_INV + 4], cy0 = vp[VP_INV + 5];
+    const float flx = (float)lx + 0.5f, fly = (float)ly + 0.5f;
+    // background in "checker units": U = world.x / (2k), V = world.y / (2k) with k = PLAYFIELD/20;
+    // playfield <=> |U|,|V| <= 10; light square <=> frac(U) < .5 and frac(V) < .5 (:615-627)
+    const float hk = 0.5f / (float)(MCR_PLAYFIELD / 20.0);
+    const float aU = vp[VP_INV + 0] * hk, bU = vp[VP_INV + 1] * hk, cU = vp[VP_INV + 2] * hk;
+    const float aV = vp[VP_INV + 3] * hk, bV = vp[VP_INV + 4] * hk, cV = vp[VP_INV + 5] * hk;
+    const float U_lane = aU * flx + bU * fly + cU, V_lane = aV * flx + bV * fly + cV;
+    const int fb_lane = (95 - ly) * 96 + lx;
     const int ncar = N * 12;
-    int b = wave;
-    while (b < NBINS) {
-      const int bxi = b % 12, byi = b / 12;
-      const int ix = bxi * 8 + lx, iy = byi * 8 + ly;                 // GL pixel coords (origin bottom-left)
-      const float cx = (float)ix + 0.5f, cy = (float)iy + 0.5f;
+    for (int it = 0; it < NBINS / 4; ++it) {
+      // wave w takes the bins with (bx + 2*by) % 4 == w: any 2x2 block of bins lands on four different waves
+      const int byi = it / 3, bxi = ((wave - 2 * byi) & 3) + 4 * (it - byi * 3);   // scalar
+      const int b = byi * 12 + bxi;
+      const float fbx = (float)(bxi * 8), fby = (float)(byi * 8);
+      const float cx = fbx + flx, cy = fby + fly;                       // pixel centre, GL coords (origin bottom-left)
       uint32_t col = PAL_BLACK;
       if (byi >= 1) {                                                   // bin row 0 (y < 8) is entirely under the HUD bar
-        const float wx = ax * cx + bx_ * cy + cx0, wy = ay * cx + by_ * cy + cy0;
-        if (fabsf(wx) <= PF && fabsf(wy) <= PF) {
-          const int gx = (int)floorf(wx * inv_kgrid), gy = (int)floorf(wy * inv_kgrid);
-          col = (((gx | gy) & 1) == 0) ? PAL_GRASS1 : PAL_GRASS0;
-        }
+        const float U = U_lane + aU * fbx + bU * fby, V = V_lane + aV * fbx + bV * fby;
+        if (fabsf(U) <= 10.0f && fabsf(V) <= 10.0f)
+          col = ((U - floorf(U)) < 0.5f && (V - floorf(V)) < 0.5f) ? PAL_GRASS1 : PAL_GRASS0;
         // highest draw index covering the pixel wins (painter's order): road_poly index, then car polygons
-        const int cnt = bcnt[b];
+        const int cnt = UNI(bcnt[b]);
         int best = -1;
         if (cnt <= BIN_CAP) {
           for (int k = 0; k < cnt; ++k) {
-            const int s = bins[b][k];
+            const int s = UNI((int)bins[b][k]);
             if (s >= CAR_KEY) {
               const float4* r = &car8[(s - CAR_KEY) * 6];
               const bool in = inside4(r[0], r[1], r[2], cx, cy) && inside4(r[3], r[4], r[5], cx, cy);
@@ -409,38 +490,36 @@ __global__ __launch_bounds__(VIEW_THREADS) void k_view(McrParams p, float* __res
             col = bc == MCR_COL_ROAD0 ? PAL_ROAD0 : bc == MCR_COL_ROAD1 ? PAL_ROAD1 : bc == MCR_COL_ROAD2 ? PAL_ROAD2 : bc == MCR_COL_KERB_WHITE ? PAL_WHITE : PAL_RED255;
           }
         }
-        if (iy < 12) col = PAL_BLACK;                                   // the HUD bar (window y < 100) covers the scene
+        if (byi == 1 && cy < 12.0f) col = PAL_BLACK;                   // the HUD bar (window y < 100) covers the scene
       }
-      if ((float)(byi * 8) < hud_top && cy < hud_top) {
+      if (byi < hud_rows && cy < hud_top) {
         // HUD (window space, drawn last): gauges in draw order (a tall gauge may poke above the bar), then the flag
         const uint32_t ind_col[7] = {PAL_WHITE, PAL_BLUE255, PAL_BLUE255, PAL_PURPLE, PAL_PURPLE, PAL_GREEN255, PAL_RED255};
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
-          const float x0 = vp[VP_IND + i * 4], x1 = vp[VP_IND + i * 4 + 1], y0 = vp[VP_IND + i * 4 + 2], y1 = vp[VP_IND + i * 4 + 3];
+          const float x0 = hud[i * 4], x1 = hud[i * 4 + 1], y0 = hud[i * 4 + 2], y1 = hud[i * 4 + 3];
           if (x1 > x0 && y1 > y0 && cx >= x0 && cx <= x1 && cy >= y0 && cy <= y1) col = ind_col[i];
         }
         if (show_flag && (fe[0] * cx + fe[1] * cy + fe[2] >= 0.0f) && (fe[3] * cx + fe[4] * cy + fe[5] >= 0.0f) && (fe[6] * cx + fe[7] * cy + fe[8] >= 0.0f)) col = PAL_BLUE255;
       }
-      fb[(95 - iy) * 96 + ix] = (uint8_t)col;                          // arr[::-1] (:602)
-      int nb = 0;
-      if (lane == 0) nb = atomicAdd(&next_bin, 1);
-      b = __shfl(nb, 0);
+      fb[fb_lane - byi * 768 + bxi * 8] = (uint8_t)col;                 // arr[::-1] (:602)
     }
   }
+  PHASE_STAMP(7);
   __syncthreads();
+  PHASE_STAMP(8);
   if (dbg & 8) return;
 
-  // ---- packed RGB write-out: 16 B per lane = 6 pixels' worth of bytes in one of three phases
-  uint4* __restrict__ out = (uint4*)(p.obs + (size_t)vw * (96 * 96 * 3));
-  for (int ch = tid; ch < 96 * 96 * 3 / 16; ch += VIEW_THREADS) {
-    const int o = ch * 16; const int p0 = o / 3; const int ph = o - p0 * 3;
-    uint32_t c[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) c[j] = pal[fb[p0 + j]];
-    uint32_t w0, w1, w2, w3;
-    if (ph == 0) { w0 = c[0] | (c[1] << 24); w1 = (c[1] >> 8) | (c[2] << 16); w2 = (c[2] >> 16) | (c[3] << 8); w3 = c[4] | (c[5] << 24); }
-    else if (ph == 1) { w0 = (c[0] >> 8) | (c[1] << 16); w1 = (c[1] >> 16) | (c[2] << 8); w2 = c[3] | (c[4] << 24); w3 = (c[4] >> 8) | (c[5] << 16); }
-    else { w0 = (c[0] >> 16) | (c[1] << 8); w1 = c[2] | (c[3] << 24); w2 = (c[3] >> 8) | (c[4] << 16); w3 = (c[4] >> 16) | (c[5] << 8); }
-    out[ch] = make_uint4(w0, w1, w2, w3);
+  // ---- packed RGB write-out: 4 pixels (one aligned LDS word of palette indices) -> 12 bytes per lane
+  {
+    uint32_t* __restrict__ out = (uint32_t*)(p.obs + (size_t)vw * (96 * 96 * 3));
+    const uint32_t* fb4 = (const uint32_t*)fb;
+    for (int i = tid; i < 96 * 96 / 4; i += VIEW_THREADS) {
+      const uint32_t ix4 = fb4[i];
+      const uint32_t c0 = pal[ix4 & 255u], c1 = pal[(ix4 >> 8) & 255u], c2 = pal[(ix4 >> 16) & 255u], c3 = pal[ix4 >> 24];
+      uint3 w; w.x = c0 | (c1 << 24); w.y = (c1 >> 8) | (c2 << 16); w.z = (c2 >> 16) | (c3 << 8);
+      *(uint3*)(out + (size_t)i * 3) = w;
+    }
   }
+  PHASE_STAMP(9);
 }

@@ -64,7 +64,7 @@ struct McrSlotHeader {
 #define MCR_OFF_TRACK_S (MCR_OFF_TRACK_C + 8 * MCR_TILE_CAP)  // f64 [TILE_CAP] sin(beta)  (on-grass test in f64, :470-472)
 #define MCR_OFF_QA (MCR_OFF_TRACK_S + 8 * MCR_TILE_CAP)       // float4 [QUAD_CAP]  x0 y0 x1 y1
 #define MCR_OFF_QB (MCR_OFF_QA + 16 * MCR_QUAD_CAP)           // float4 [QUAD_CAP]  x2 y2 x3 y3
-#define MCR_OFF_QMETA (MCR_OFF_QB + 16 * MCR_QUAD_CAP)        // u32    [QUAD_CAP]  (tile+1)<<8 | colour id
+#define MCR_OFF_QMETA (MCR_OFF_QB + 16 * MCR_QUAD_CAP)        // u32    [QUAD_CAP]  colour id | (tile+1)<<8 for tile quads | (owner tile+1)<<18 for kerb quads
 #define MCR_OFF_TAABB (MCR_OFF_QMETA + 4 * MCR_QUAD_CAP)      // float4 [TILE_CAP]  lo.xy hi.xy
 #define MCR_OFF_TVA (MCR_OFF_TAABB + 16 * MCR_TILE_CAP)       // float4 [TILE_CAP]  hull v0 v1 (CCW)
 #define MCR_OFF_TVB (MCR_OFF_TVA + 16 * MCR_TILE_CAP)         // float4             v2 v3

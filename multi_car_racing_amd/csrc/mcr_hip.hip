@@ -69,6 +69,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   const size_t o_cc = carve(sizeof(uint32_t) * (size_t)B * (MCR_CC_MAX * MCR_CC_WORDS + 4));
   const size_t o_shapes = carve(sizeof(McrShapes));
   const size_t o_viewp = carve(sizeof(float) * MCR_VIEWP_FLOATS * BN);
+  const size_t o_carpoly = carve(sizeof(float) * MCR_CARPOLY_FLOATS * BN);
   const size_t o_vscratch = carve(sizeof(float) * (size_t)VIEW_SCRATCH_FLOATS * BN);
   const size_t o_slots = carve((size_t)B * 2 * MCR_SLOT_BYTES);
   h->slab_bytes = off;
@@ -83,6 +84,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   P.cc_store = (uint32_t*)(base + o_cc); P.shapes = (const McrShapes*)(base + o_shapes); P.slots = base + o_slots;
   h->view_scratch = (float*)(base + o_vscratch);
   P.viewp = (float*)(base + o_viewp);
+  P.carpoly = (float*)(base + o_carpoly);
   P.auto_reset = cfg->auto_reset; P.max_steps = cfg->max_episode_steps; P.car_contacts = cfg->car_contacts;
   P.backwards_flag = cfg->backwards_flag; P.use_ego_color = cfg->use_ego_color; P.h_ratio = cfg->h_ratio;
   McrShapes S; mcr_build_shapes(&S);
@@ -325,6 +327,12 @@ extern "C" int mcr_sincos_device(mcr_env* h, const float* d_in, float* d_sin, fl
   return MCR_OK;
 }
 
+extern "C" int mcr_debug_read_view_scratch(mcr_env* h, int view, void* out, int nbytes) {
+  if (!h || !out) return MCR_ERR_ARG;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out, h->view_scratch + (size_t)(view + 1) * VIEW_SCRATCH_FLOATS - 64, nbytes, hipMemcpyDeviceToHost));
+  return MCR_OK;
+}
 extern "C" int mcr_debug_set(mcr_env* h, int value) { if (!h) return MCR_ERR_ARG; h->P.debug = value; return MCR_OK; }
 extern "C" int mcr_timing_enable(mcr_env* h, int enable) { if (!h) return MCR_ERR_ARG; h->timing = enable; return MCR_OK; }
 extern "C" int mcr_timing_read(mcr_env* h, double* ms_out, int64_t* launches_out) {

@@ -382,7 +382,7 @@ extern "C" int mcr_episode_generate(uint32_t* mt_track, int num_agents, int cw, 
       double ky[4] = {a.y + w0 * s1, a.y + w1 * s1, b.y + w1 * s2, b.y + w0 * s2};
       QA[q * 4 + 0] = (float)kx[0]; QA[q * 4 + 1] = (float)ky[0]; QA[q * 4 + 2] = (float)kx[1]; QA[q * 4 + 3] = (float)ky[1];
       QB[q * 4 + 0] = (float)kx[2]; QB[q * 4 + 1] = (float)ky[2]; QB[q * 4 + 2] = (float)kx[3]; QB[q * 4 + 3] = (float)ky[3];
-      QM[q] = (uint32_t)((i % 2 == 0) ? MCR_COL_KERB_WHITE : MCR_COL_KERB_RED);
+      QM[q] = ((uint32_t)(i + 1) << 18) | (uint32_t)((i % 2 == 0) ? MCR_COL_KERB_WHITE : MCR_COL_KERB_RED);   // bits 18..27: owner tile + 1
       ++q;
     }
   }

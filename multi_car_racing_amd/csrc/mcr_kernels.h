@@ -16,6 +16,7 @@ struct McrParams {
   uint32_t* cc_store;           // [B][...] car<->car manifold store (warm starting)
   const McrShapes* shapes;
   float* viewp;                 // [BN][MCR_VIEWP_FLOATS] per-car camera + HUD geometry, written by k_dynamics, read by k_view
+  float* carpoly;               // [BN][MCR_CARPOLY_FLOATS] world-space vertices of the car's 12 draw polygons (Car.draw)
   int32_t* consumed_host;       // [B] mapped host memory: episode counter of the last install
   // step I/O
   const float* actions;         // [B,N,3] or null
@@ -33,5 +34,9 @@ struct McrParams {
 #define MCR_VIEWP_FLOATS 48
 enum { VP_CAM = 0 /*m00 m01 m10 m11 tx ty*/, VP_INV = 6 /*ax bx cx0 ay by cy0*/, VP_IND = 12 /*7 x (x0 x1 y0 y1)*/, VP_HUDTOP = 40 };
 
+// Car.draw polygons per car in draw order: 4 x (wheel box, white stripe) then the 4 hull polygons; each slot holds
+// 8 vertices (x0 y0 .. x7 y7) and slot header words live in carpoly_n: vertex count (0 = not drawn)
+#define MCR_CARPOLY_FLOATS (12 * 16 + 16)
+#define MCR_CARPOLY_NOFF (12 * 16)
 #define MCR_CC_MAX 24           // touching car<->car fixture pairs kept per env (warm start)
 #define MCR_CC_WORDS 20         // u32 words per stored manifold

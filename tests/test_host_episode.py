@@ -52,15 +52,16 @@ def test_tracks_bit_exact_vs_reference_goldens(lib):
         assert info[2] == int(g[f"s{s}_retries"]) and ep["T"] == len(tr)
         assert np.array_equal(ep["track"], tr[:, [2, 3, 1]]) and np.array_equal(ep["alpha"], tr[:, 0])
         assert np.array_equal(ep["quads"], g[f"s{s}_poly"].astype(np.float32))       # glVertex3f / b2Vec2 see f32
-        assert np.array_equal((ep["quad_meta"] >> 8) > 0, g[f"s{s}_is_tile"].astype(bool))
+        assert np.array_equal(((ep["quad_meta"] >> 8) & 0x3ff) > 0, g[f"s{s}_is_tile"].astype(bool))
         # colour ids: tile i -> shade i%3; kerb -> white if i%2==0 else red
         col = g[f"s{s}_color"]; ids = ep["quad_meta"] & 0xff; ti = -1
         for q in range(ep["P"]):
-            if ep["quad_meta"][q] >> 8:
-                ti = int(ep["quad_meta"][q] >> 8) - 1
+            if (ep["quad_meta"][q] >> 8) & 0x3ff:
+                ti = int((ep["quad_meta"][q] >> 8) & 0x3ff) - 1
                 assert ids[q] == ti % 3 and abs(col[q, 0] - (0.4 + 0.01 * (ti % 3))) < 1e-12
             else:
                 assert ids[q] == (3 if ti % 2 == 0 else 4) and tuple(col[q]) == ((1, 1, 1) if ti % 2 == 0 else (1, 0, 0))
+                assert int(ep["quad_meta"][q] >> 18) - 1 == ti          # kerb quads name their owner tile
         # the numpy stream advanced exactly as the reference's did
         rs = np.random.RandomState(int(s))
         for _ in range(24 * (int(info[2]) + 1)):

@@ -1,0 +1,26 @@
+"""Per-phase latency of the raster kernel from in-kernel s_memtime stamps (debug bit 32). Not a test."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from multi_car_racing_amd.vec_env import VecMultiCarRacing
+from multi_car_racing_amd import _lib
+B, N = 4096, 2
+env = VecMultiCarRacing(B, N, seed=1, use_random_direction=True, auto_reset=True)
+env.reset()
+pool = torch.rand((64, B, N, 3), device="cuda"); pool[..., 0] = pool[..., 0] * 2 - 1
+for k in range(80): env.step(pool[k % 64])
+_lib.check(env.L.mcr_debug_set(env.h, 32))
+for k in range(3): env.step(pool[k])
+torch.cuda.synchronize()
+names = ["prologue", "init-barrier", "pass1(cull+flags)", "cars", "barrier", "pass2(setup+bin)+flags2", "barrier", "shade", "barrier", "writeout"]
+rows = []
+for v in range(0, B * N, 97):
+    buf = np.zeros(10, np.uint64)
+    env.L.mcr_debug_read_view_scratch(env.h, v, _lib.ptr(buf), 80)
+    rows.append(np.diff(buf.astype(np.int64)))
+d = np.array(rows)
+print("views sampled", len(d), " (s_memtime ticks; 100 MHz constant clock -> 10 ns per tick)")
+for i, nme in enumerate(names[1:]):
+    print(f"{nme:>26}: median {np.median(d[:, i]):8.0f} ticks  mean {d[:, i].mean():8.0f}  p90 {np.percentile(d[:, i], 90):8.0f}")
+print(f"{'total':>26}: median {np.median(d.sum(1)):8.0f} ticks")
+env.close()
