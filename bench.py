@@ -101,10 +101,19 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # The host is kept at most LOOKAHEAD steps ahead of the GPU (an RL loop would be 0 steps ahead): that way the
+    # consumed-episode poll inside env.step() sees the device-side auto-resets while the rollout is still running
+    # and the replacement tracks are generated + staged by the refill thread INSIDE the timed region.
+    LOOKAHEAD = 16
+    evs = [torch.cuda.Event() for _ in range(LOOKAHEAD)]
     t0 = time.perf_counter()
     for k in range(K):
         env.step(pool[(W + k) % 64])
+        if k >= LOOKAHEAD:
+            evs[k % LOOKAHEAD].synchronize()
+        evs[k % LOOKAHEAD].record()
     torch.cuda.synchronize()
+    env.wait_refills()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
