@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--agents", type=int, default=2)
     ap.add_argument("--obs", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=0, help="env sub-batches pipelined on internal HIP streams (0 = library default)")
+    ap.add_argument("--streams", type=int, default=1, help="1: single stream (default); 2: experimental dynamics||raster overlap on CU-masked streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event time all three kernels (adds overhead)")
     args = ap.parse_args()

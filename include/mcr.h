@@ -45,7 +45,7 @@ typedef struct mcr_config {
   int32_t use_ego_color;     /* :160 */
   int32_t car_contacts;      /* 1: car<->car rigid contacts (Box2D default); 0: ghost cars (debug) */
   int32_t max_episode_steps; /* gym TimeLimit from __init__.py:8 (1000); 0 disables */
-  int32_t num_streams;       /* env sub-batches pipelined on internal HIP streams (0 = default 1 = none; >1 needs cheap launches to pay off) */
+  int32_t num_streams;       /* 0/1 (default): every kernel on the caller's stream; 2: experimental dynamics||raster overlap on CU-masked streams */
   double h_ratio;            /* :159 */
 } mcr_config;
 

@@ -774,7 +774,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
     }
   }
 
-  if (!run) return;
+  if (run) {
   if (respawn) {
     // Car(world, angle, x, y): hull at the pose, wheels at UNROTATED offsets with the same angle
     const McrSlotHeader* H = (const McrSlotHeader*)(p.slots + ((size_t)env * 2 + (es.slot ^ 1)) * MCR_SLOT_BYTES);
@@ -894,6 +894,18 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
       for (int i = 0; i < 8; ++i) { const int ii = i < n ? i : n - 1; const V2 w = xmul(hxf, v2(S.hull[k].vx[ii], S.hull[k].vy[ii])); hp[i * 2] = w.x; hp[i * 2 + 1] = w.y; }
       cp[MCR_CARPOLY_NOFF + 8 + k] = __int_as_float(n);
     }
+  }
+  }   // run
+
+  // ---- publish: when the raster kernel runs concurrently (disjoint CUs) it gates each view on ready[env].
+  // Plain stores above -> wave barrier -> ONE agent-scope release -> relaxed agent-scope flag stores
+  // (cdna_hip_programming.md G16).  A re-spawned env is published by the reset pass (mode 1) instead.
+  if (p.wait_ready) {
+    __syncthreads();
+    if (threadIdx.x == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    __syncthreads();
+    const bool publish = lane_ok && agent == 0 && ((mode == 0 && !respawn) || (mode == 1 && es.active && es.resetting));
+    if (publish) __hip_atomic_store(&p.ready[env], p.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

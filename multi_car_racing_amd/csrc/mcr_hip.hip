@@ -10,6 +10,7 @@
 #include <vector>
 #include <cstring>
 #include <cstdio>
+#include <cstdlib>
 
 void mcr_build_shapes(McrShapes* S);   // mcr_host.cpp
 
@@ -40,9 +41,10 @@ struct mcr_env {
   std::vector<hipEvent_t> free_events;
   double t_ms[5]; int64_t t_n[5];
   bool any_reset;
-  int ngroups;                // env sub-batches pipelined on internal streams (1 = caller's stream only)
-  hipStream_t gstream[8];
-  hipEvent_t ev_fork, ev_done[8];
+  bool overlap;               // dynamics (latency bound, 128 waves) and raster (throughput bound) on disjoint CU sets
+  hipStream_t s_phys, s_view; // CU-masked internal streams
+  hipEvent_t ev_collide, ev_phys, ev_view;
+  uint32_t serial;
   float* view_scratch;        // per-view spill area of the rasteriser (zoomed-out frames only)
 };
 
@@ -67,6 +69,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   const size_t o_touch = carve(sizeof(uint32_t) * MCR_TILE_CAP * (size_t)B);
   const size_t o_tflags = carve(sizeof(uint16_t) * MCR_TILE_CAP * (size_t)B);
   const size_t o_cc = carve(sizeof(uint32_t) * (size_t)B * (MCR_CC_MAX * MCR_CC_WORDS + 4));
+  const size_t o_ready = carve(sizeof(uint32_t) * B);
   const size_t o_shapes = carve(sizeof(McrShapes));
   const size_t o_viewp = carve(sizeof(float) * MCR_VIEWP_FLOATS * BN);
   const size_t o_carpoly = carve(sizeof(float) * MCR_CARPOLY_FLOATS * BN);
@@ -84,6 +87,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   P.cc_store = (uint32_t*)(base + o_cc); P.shapes = (const McrShapes*)(base + o_shapes); P.slots = base + o_slots;
   h->view_scratch = (float*)(base + o_vscratch);
   P.viewp = (float*)(base + o_viewp);
+  P.ready = (uint32_t*)(base + o_ready);
   P.carpoly = (float*)(base + o_carpoly);
   P.auto_reset = cfg->auto_reset; P.max_steps = cfg->max_episode_steps; P.car_contacts = cfg->car_contacts;
   P.backwards_flag = cfg->backwards_flag; P.use_ego_color = cfg->use_ego_color; P.h_ratio = cfg->h_ratio;
@@ -95,16 +99,28 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   (void)hipHostGetDevicePointer(&dptr, h->consumed_host, 0);
   P.consumed_host = (int32_t*)dptr;
   h->consumed_seen = new int32_t[B]();
-  // Stream-level pipelining: the dynamics kernel is a long serial dependency chain on few wavefronts while the
-  // raster kernel is throughput bound, so env sub-batches on separate streams overlap one group's dynamics
-  // with another group's raster/collide.  cfg.num_streams selects the group count (0 = default).
-  h->ngroups = cfg->num_streams > 0 ? cfg->num_streams : 1;   // measured: without graph replay the extra launches cost more than the overlap wins
-  if (h->ngroups > 8) h->ngroups = 8;
-  while (h->ngroups > 1 && B / h->ngroups < 256) h->ngroups >>= 1;
-  P.env0 = 0; P.nenv = B;
-  if (h->ngroups > 1) {
-    for (int g = 0; g < h->ngroups; ++g) { (void)hipStreamCreateWithFlags(&h->gstream[g], hipStreamNonBlocking); (void)hipEventCreateWithFlags(&h->ev_done[g], hipEventDisableTiming); }
-    (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+  // Kernel-level overlap.  k_dynamics is a long serial dependency chain on B*N/64 wavefronts (1 per SIMD on 32
+  // CUs) whose duration is set by its slowest lane, k_view is throughput bound: give them disjoint CU sets
+  // (CU-masked streams) and let every view start as soon as its own env has been published (ready[env]).
+  // Disjoint CU sets make the wait deadlock-free: the raster can never occupy the CUs the physics needs.
+  P.env0 = 0; P.nenv = B; P.wait_ready = 0; P.serial = 0;
+  h->serial = 0; h->overlap = false;
+  if (cfg->num_streams == 2 && cfg->obs_enabled) {
+    int ncu = 0; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device);
+    const int phys_cus = 32;
+    if (ncu >= 128) {
+      uint32_t mphys[16] = {0}, mview[16] = {0};
+      for (int c = 0; c < ncu && c < 512; ++c) { if (c < phys_cus) mphys[c >> 5] |= 1u << (c & 31); else mview[c >> 5] |= 1u << (c & 31); }
+      const uint32_t words = (uint32_t)((ncu + 31) / 32);
+      if (hipExtStreamCreateWithCUMask(&h->s_phys, words, mphys) == hipSuccess) {
+        if (hipExtStreamCreateWithCUMask(&h->s_view, words, mview) == hipSuccess) {
+          (void)hipEventCreateWithFlags(&h->ev_collide, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_phys, hipEventDisableTiming);
+          (void)hipEventCreateWithFlags(&h->ev_view, hipEventDisableTiming);
+          h->overlap = true;
+        } else (void)hipStreamDestroy(h->s_phys);
+      }
+      (void)hipGetLastError();
+    }
   }
   (void)hipDeviceSynchronize();
   *out = h;
@@ -117,7 +133,7 @@ extern "C" int mcr_destroy(mcr_env* h) {
   (void)hipDeviceSynchronize();
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : h->free_events) (void)hipEventDestroy(e);
-  if (h->ngroups > 1) { for (int g = 0; g < h->ngroups; ++g) { (void)hipStreamDestroy(h->gstream[g]); (void)hipEventDestroy(h->ev_done[g]); } (void)hipEventDestroy(h->ev_fork); }
+  if (h->overlap) { (void)hipStreamDestroy(h->s_phys); (void)hipStreamDestroy(h->s_view); (void)hipEventDestroy(h->ev_collide); (void)hipEventDestroy(h->ev_phys); (void)hipEventDestroy(h->ev_view); }
   (void)hipFree(h->slab);
   (void)hipHostFree(h->consumed_host);
   delete[] h->consumed_seen;
@@ -157,36 +173,46 @@ static hipEvent_t get_event(mcr_env* h) {
     if (tm_) { (void)hipEventRecord(tl_.b, st); h->pending.push_back(tl_); }                   \
   } while (0)
 
-// One env sub-range [e0, e0+ne) through the whole step on stream st.
-static void launch_group(mcr_env* h, McrParams P, int e0, int ne, hipStream_t st, bool install, bool step_pass, bool reset_pass,
-                         int view_flags, int view_only_just_reset) {
-  P.env0 = e0; P.nenv = ne;
-  const int N = P.N;
-  const int dyn_blocks = (ne * P.G + 63) / 64;
-  if (install) hipLaunchKernelGGL(k_install, dim3(dyn_blocks), dim3(64), 0, st, P);
-  if (step_pass) {
-    LAUNCH(0, k_collide, ne, 64, st, P, 0);
-    LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 0);
-  }
-  if (reset_pass) {   // the action-less first step of a freshly installed episode (:408)
-    LAUNCH(3, k_collide, ne, 64, st, P, 1);
-    LAUNCH(4, k_dynamics, dyn_blocks, 64, st, P, 1);
-  }
-  if (P.obs || view_flags) LAUNCH_LDS(2, k_view, ne * N, VIEW_THREADS, (size_t)N * 12 * 6 * 16, st, P, h->view_scratch, view_flags, view_only_just_reset);
+// reset(): install -> collide(1) -> dynamics(1) -> view, in order on one stream
+static void launch_reset(mcr_env* h, McrParams P, hipStream_t st) {
+  const int B = P.B, N = P.N;
+  // (in overlap mode every step already joined s_phys/s_view into st, so st is ordered after them; the next
+  // step's physics waits for ev_collide recorded on st after this reset)
+  const int dyn_blocks = (B * P.G + 63) / 64;
+  P.wait_ready = 0;
+  hipLaunchKernelGGL(k_install, dim3(dyn_blocks), dim3(64), 0, st, P);
+  LAUNCH(3, k_collide, B, 64, st, P, 1);
+  LAUNCH(4, k_dynamics, dyn_blocks, 64, st, P, 1);
+  if (P.obs) LAUNCH_LDS(2, k_view, B * N, VIEW_THREADS, (size_t)N * 12 * 6 * 16, st, P, h->view_scratch, 0, 1);
 }
 
-static void launch_all(mcr_env* h, const McrParams& P, hipStream_t st, bool install, bool step_pass, bool reset_pass, int view_flags, int only_jr) {
-  const int B = P.B;
-  if (h->ngroups <= 1) { launch_group(h, P, 0, B, st, install, step_pass, reset_pass, view_flags, only_jr); return; }
-  (void)hipEventRecord(h->ev_fork, st);
-  const int per = (B + h->ngroups - 1) / h->ngroups;
-  for (int g = 0; g < h->ngroups; ++g) {
-    const int e0 = g * per; const int ne = (e0 + per <= B) ? per : B - e0;
-    if (ne <= 0) break;
-    (void)hipStreamWaitEvent(h->gstream[g], h->ev_fork, 0);
-    launch_group(h, P, e0, ne, h->gstream[g], install, step_pass, reset_pass, view_flags, only_jr);
-    (void)hipEventRecord(h->ev_done[g], h->gstream[g]);
-    (void)hipStreamWaitEvent(st, h->ev_done[g], 0);
+// step(): collide -> dynamics [-> auto-reset pass] -> view, all on the caller's stream by default.
+// Optional overlap (cfg.num_streams == 2): the dynamics chain (latency bound, B*N/64 wavefronts) and the raster
+// (throughput bound) run concurrently on CU-masked internal streams with disjoint CU sets; each view is gated IN
+// THE KERNEL on its env's ready word, so the spin can never starve the physics of CUs.  MEASURED on MI355X /
+// ROCm 7.0 runtime: every cross-stream event hop costs ~60-70 us here, which eats the overlap (0.72 ms/step vs
+// 0.65 ms/step serial at B=4096,N=2) — so it stays off until launches are replayed from a hipGraph.
+static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags) {
+  const int B = P.B, N = P.N;
+  const int dyn_blocks = (B * P.G + 63) / 64;
+  const bool ov = h->overlap && P.obs != nullptr;
+  P.serial = ++h->serial; P.wait_ready = ov ? 1 : 0;
+  LAUNCH(0, k_collide, B, 64, st, P, 0);
+  hipStream_t sp = st, sv = st;
+  if (ov) {
+    sp = h->s_phys; sv = h->s_view;
+    (void)hipEventRecord(h->ev_collide, st);
+    (void)hipStreamWaitEvent(sp, h->ev_collide, 0); (void)hipStreamWaitEvent(sv, h->ev_collide, 0);
+  }
+  LAUNCH(1, k_dynamics, dyn_blocks, 64, sp, P, 0);
+  if (P.auto_reset) {   // envs re-spawned by pass 0 take the action-less first step of their new episode (:408)
+    LAUNCH(3, k_collide, B, 64, sp, P, 1);
+    LAUNCH(4, k_dynamics, dyn_blocks, 64, sp, P, 1);
+  }
+  if (P.obs || view_flags) LAUNCH_LDS(2, k_view, B * N, VIEW_THREADS, (size_t)N * 12 * 6 * 16, sv, P, h->view_scratch, view_flags, 0);
+  if (ov) {
+    (void)hipEventRecord(h->ev_phys, sp); (void)hipEventRecord(h->ev_view, sv);
+    (void)hipStreamWaitEvent(st, h->ev_phys, 0); (void)hipStreamWaitEvent(st, h->ev_view, 0);
   }
 }
 
@@ -195,7 +221,7 @@ extern "C" int mcr_reset(mcr_env* h, const uint8_t* d_env_mask, uint8_t* d_obs, 
   hipStream_t st = (hipStream_t)stream;
   McrParams P = h->P;
   P.reset_mask = d_env_mask; P.obs = h->cfg.obs_enabled ? d_obs : nullptr; P.actions = nullptr;
-  launch_all(h, P, st, true, false, true, 0, 1);
+  launch_reset(h, P, st);
   HIPCHK(hipGetLastError());
   h->any_reset = true;
   return MCR_OK;
@@ -210,7 +236,7 @@ extern "C" int mcr_step(mcr_env* h, const float* d_actions, uint8_t* d_obs, doub
   P.reward_out = d_reward; P.done_out = d_done; P.trunc_out = d_trunc;
   // with auto_reset, finished envs are re-spawned on the device and take the action-less first step of their
   // new episode inside this call; the view kernel always runs (it also owns the backward/on-grass flags)
-  launch_all(h, P, st, false, true, P.auto_reset != 0, d_actions ? 1 : 0, 0);
+  launch_step(h, P, st, d_actions ? 1 : 0);
   HIPCHK(hipGetLastError());
   return MCR_OK;
 }

@@ -18,6 +18,9 @@ struct McrParams {
   float* viewp;                 // [BN][MCR_VIEWP_FLOATS] per-car camera + HUD geometry, written by k_dynamics, read by k_view
   float* carpoly;               // [BN][MCR_CARPOLY_FLOATS] world-space vertices of the car's 12 draw polygons (Car.draw)
   int32_t* consumed_host;       // [B] mapped host memory: episode counter of the last install
+  uint32_t* ready;              // [B] step serial published by k_dynamics once the env's post-step state is in HBM
+  uint32_t serial;              // serial of this mcr_step call (k_view waits for ready[env] == serial when overlapped)
+  int32_t wait_ready;           // 1: k_view runs concurrently with k_dynamics on disjoint CUs and gates each view on ready[env]
   // step I/O
   const float* actions;         // [B,N,3] or null
   uint8_t* obs;                 // [B,N,96,96,3] or null
