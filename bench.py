@@ -27,8 +27,9 @@ def cpu_baseline(num_agents, obs, steps=60):
     import numpy as np
     from oracle import oracle as O
     from tests.util import oracle_episode
-    cores = os.cpu_count() or 1
-    n_envs = 4 * cores
+    from multi_car_racing_amd._lib import effective_cpus
+    cores = effective_cpus()                   # min(affinity, cgroup CPU quota): what this job may really use
+    n_envs = 8 * cores
     envs = []
     for e in range(n_envs):
         o = O.OracleEnv(num_agents)
@@ -54,7 +55,7 @@ def cpu_baseline(num_agents, obs, steps=60):
     return {"value": n_envs * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{n_envs} envs x {steps} steps, num_agents={num_agents}, obs={'96x96x3' if obs else 'none'}, "
                       f"oracle/mcr_oracle.cpp with OpenMP over envs (CPU restatement; the reference's Box2D+pyglet path "
-                      f"is not installable here), {dt:.1f} s wall"}
+                      f"is not installable here), {dt:.1f} s wall; host reports {os.cpu_count()} logical CPUs, cgroup/affinity allows {cores}"}
 
 
 def main():

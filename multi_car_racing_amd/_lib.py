@@ -82,6 +82,23 @@ def load():
     return L
 
 
+def effective_cpus():
+    """CPUs this process may actually use: min(affinity mask, cgroup v2/v1 CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def check(rc, what=""):
     if rc < 0:
         raise McrError(f"{what} failed ({rc}): {load().mcr_last_error().decode()}")

@@ -57,18 +57,22 @@ __device__ __forceinline__ void solve22(const Joint& J, float bx, float by, floa
 
 struct Body { float cx, cy, a, vx, vy, w; };
 
+// The wheel's joint anchor is its own centre of mass (localAnchorB = localCenterB = 0), so Box2D's
+// rB = R(aB)*(0-0) is (+-0, +-0): every term it feeds is an exact zero and contributes nothing but the SIGN of a
+// zero.  The kernels below therefore drop rB (one sincos less per joint evaluation); results are identical up to
+// -0.0 vs +0.0, which compare equal and never reach a division or a sign test.
+
 // b2RevoluteJoint::InitVelocityConstraints (enableMotor, enableLimit, limits +-0.4, dtRatio 1)
 __device__ __forceinline__ void joint_init(Joint& J, Body& A, Body& B, float anchx, float anchy, float lcx, float lcy,
                                            float mA, float iA, float mB, float iB) {
-  Rot qA = rot_of(A.a), qB = rot_of(B.a);
+  Rot qA = rot_of(A.a);
   V2 rA = rmul(qA, v2(anchx, anchy) - v2(lcx, lcy));
-  V2 rB = rmul(qB, v2(0.0f, 0.0f) - v2(0.0f, 0.0f));
-  J.rAx = rA.x; J.rAy = rA.y; J.rBx = rB.x; J.rBy = rB.y;
-  J.exx = mA + mB + J.rAy * J.rAy * iA + J.rBy * J.rBy * iB;
-  J.eyx = -J.rAy * J.rAx * iA - J.rBy * J.rBx * iB;
-  J.ezx = -J.rAy * iA - J.rBy * iB;
-  J.eyy = mA + mB + J.rAx * J.rAx * iA + J.rBx * J.rBx * iB;
-  J.ezy = J.rAx * iA + J.rBx * iB;
+  J.rAx = rA.x; J.rAy = rA.y; J.rBx = 0.0f; J.rBy = 0.0f;
+  J.exx = mA + mB + J.rAy * J.rAy * iA;
+  J.eyx = -J.rAy * J.rAx * iA;
+  J.ezx = -J.rAy * iA;
+  J.eyy = mA + mB + J.rAx * J.rAx * iA;
+  J.ezy = J.rAx * iA;
   J.ezz = iA + iB;
   J.motorMass = iA + iB;
   if (J.motorMass > 0.0f) J.motorMass = 1.0f / J.motorMass;
@@ -81,7 +85,7 @@ __device__ __forceinline__ void joint_init(Joint& J, Body& A, Body& B, float anc
   A.vx = A.vx - mA * Px; A.vy = A.vy - mA * Py;
   A.w -= iA * ((J.rAx * Py - J.rAy * Px) + J.im + J.iz);
   B.vx = B.vx + mB * Px; B.vy = B.vy + mB * Py;
-  B.w += iB * ((J.rBx * Py - J.rBy * Px) + J.im + J.iz);
+  B.w += iB * (J.im + J.iz);
 }
 
 // b2RevoluteJoint::SolveVelocityConstraints
@@ -95,10 +99,10 @@ __device__ __forceinline__ void joint_velocity(Joint& J, Body& A, Body& B, float
     impulse = J.im - old;
     wA -= iA * impulse; wB += iB * impulse;
   }
+  // Cdot1 = vB + cross(wB, rB) - vA - cross(wA, rA)   with rB == 0
+  const float c1x = (vBx - vAx) - (-wA * J.rAy);
+  const float c1y = (vBy - vAy) - (wA * J.rAx);
   if (J.limit != 0) {
-    // Cdot1 = vB + cross(wB, rB) - vA - cross(wA, rA)
-    float c1x = ((vBx + (-wB * J.rBy)) - vAx) - (-wA * J.rAy);
-    float c1y = ((vBy + (wB * J.rBx)) - vAy) - (wA * J.rAx);
     float c2 = wB - wA;
     float sx, sy, sz; solve33(J, c1x, c1y, c2, sx, sy, sz);
     float impx = -sx, impy = -sy, impz = -sz;
@@ -113,16 +117,13 @@ __device__ __forceinline__ void joint_velocity(Joint& J, Body& A, Body& B, float
     vAx = vAx - mA * impx; vAy = vAy - mA * impy;
     wA -= iA * ((J.rAx * impy - J.rAy * impx) + impz);
     vBx = vBx + mB * impx; vBy = vBy + mB * impy;
-    wB += iB * ((J.rBx * impy - J.rBy * impx) + impz);
+    wB += iB * impz;
   } else {
-    float cx = ((vBx + (-wB * J.rBy)) - vAx) - (-wA * J.rAy);
-    float cy = ((vBy + (wB * J.rBx)) - vAy) - (wA * J.rAx);
-    float ix, iy; solve22(J, -cx, -cy, ix, iy);
+    float ix, iy; solve22(J, -c1x, -c1y, ix, iy);
     J.ix += ix; J.iy += iy;
     vAx = vAx - mA * ix; vAy = vAy - mA * iy;
     wA -= iA * (J.rAx * iy - J.rAy * ix);
     vBx = vBx + mB * ix; vBy = vBy + mB * iy;
-    wB += iB * (J.rBx * iy - J.rBy * ix);
   }
   A.vx = vAx; A.vy = vAy; A.w = wA; B.vx = vBx; B.vy = vBy; B.w = wB;
 }
@@ -147,19 +148,18 @@ __device__ __forceinline__ bool joint_position(const Joint& J, Body& A, Body& B,
     aA -= iA * limitImpulse; aB += iB * limitImpulse;
   }
   {
-    Rot qA = rot_of(aA), qB = rot_of(aB);
+    Rot qA = rot_of(aA);
     V2 rA = rmul(qA, v2(anchx, anchy) - v2(lcx, lcy));
-    V2 rB = rmul(qB, v2(0.0f, 0.0f) - v2(0.0f, 0.0f));
-    float Cx = ((cBx + rB.x) - cAx) - rA.x, Cy = ((cBy + rB.y) - cAy) - rA.y;
+    float Cx = (cBx - cAx) - rA.x, Cy = (cBy - cAy) - rA.y;
     positionError = sqrtf(Cx * Cx + Cy * Cy);
-    float k11 = mA + mB + iA * rA.y * rA.y + iB * rB.y * rB.y;
-    float k12 = -iA * rA.x * rA.y - iB * rB.x * rB.y;
-    float k22 = mA + mB + iA * rA.x * rA.x + iB * rB.x * rB.x;
+    float k11 = mA + mB + iA * rA.y * rA.y;
+    float k12 = -iA * rA.x * rA.y;
+    float k22 = mA + mB + iA * rA.x * rA.x;
     float det = k11 * k22 - k12 * k12;
     if (det != 0.0f) det = 1.0f / det;
     float ix = -(det * (k22 * Cx - k12 * Cy)), iy = -(det * (k11 * Cy - k12 * Cx));
     cAx = cAx - mA * ix; cAy = cAy - mA * iy; aA -= iA * (rA.x * iy - rA.y * ix);
-    cBx = cBx + mB * ix; cBy = cBy + mB * iy; aB += iB * (rB.x * iy - rB.y * ix);
+    cBx = cBx + mB * ix; cBy = cBy + mB * iy;
   }
   A.cx = cAx; A.cy = cAy; A.a = aA; B.cx = cBx; B.cy = cBy; B.a = aB;
   return positionError <= B2_LINEAR_SLOP && angularError <= B2_ANGULAR_SLOP;
@@ -631,7 +631,8 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
   // position iterations with the per-island early exit
   if (!wave_cc) {
     if (run) {
-      for (int it = 0; it < 60; ++it) {
+      const int pos_iters = (p.debug & 64) ? 2 : 60;          // debug bit 6: cap the position iterations (timing experiments only)
+      for (int it = 0; it < pos_iters; ++it) {
         bool ok = true;
 #pragma unroll
         for (int q = 3; q >= 0; --q) {

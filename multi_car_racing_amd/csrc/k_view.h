@@ -25,9 +25,9 @@ namespace view {
 
 #define VIEW_THREADS 256
 #define VIS_LDS 112                  // road survivors kept in LDS; more spill to HBM scratch (zoomed-out frames)
-#define BIN_CAP 14                   // entries per 8x8 bin list; overflow -> the bin walks every survivor
+#define BIN_CAP 20                   // entries per bin list; overflow -> the bin walks every survivor
 #define CAR_KEY 1024                 // bin-list ids >= CAR_KEY are car polygons (drawn after every road quad)
-#define NBINS 144
+#define NBINS 72                     // 12 x 6 bins of 8 x 16 pixels: one wave shades a bin, each lane two pixels (y, y+8)
 #define CARPOLY_CAP (MCR_MAX_AGENTS * 12)
 #define VIEW_SCRATCH_FLOATS (MCR_QUAD_CAP * 16)   // per-view spill area (3 x float4 edge eq + info)
 
@@ -320,9 +320,9 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
 #pragma unroll
         for (int i = 0; i < 6; ++i) car8[k * 6 + i] = make_float4(e[i * 4], e[i * 4 + 1], e[i * 4 + 2], e[i * 4 + 3]);
         info = 0x100u | colr;
-        for (int by = iy0 >> 3; by <= (iy1 >> 3); ++by)
+        for (int by = iy0 >> 4; by <= (iy1 >> 4); ++by)
           for (int bx = ix0 >> 3; bx <= (ix1 >> 3); ++bx) {
-            const float X0 = (float)(bx * 8) + 0.5f, Y0 = (float)(by * 8) + 0.5f, X1 = X0 + 7.0f, Y1 = Y0 + 7.0f;
+            const float X0 = (float)(bx * 8) + 0.5f, Y0 = (float)(by * 16) + 0.5f, X1 = X0 + 7.0f, Y1 = Y0 + 15.0f;
             bool out = false;
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
@@ -379,10 +379,10 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
         d[3] = make_float4(__uint_as_float(info), 0.0f, 0.0f, 0.0f);
       }
       if (ok)
-        for (int by = iy0 >> 3; by <= (iy1 >> 3); ++by)
+        for (int by = iy0 >> 4; by <= (iy1 >> 4); ++by)
           for (int bx = ix0 >> 3; bx <= (ix1 >> 3); ++bx) {
-            const float X0 = (float)(bx * 8) + 0.5f, Y0 = (float)(by * 8) + 0.5f;
-            const float X1 = X0 + 7.0f, Y1 = Y0 + 7.0f;
+            const float X0 = (float)(bx * 8) + 0.5f, Y0 = (float)(by * 16) + 0.5f;
+            const float X1 = X0 + 7.0f, Y1 = Y0 + 15.0f;
             bool out = false;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
@@ -444,15 +444,16 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
   }
   if (!draw) return;
 
-  // ---- shade: one wave per 8x8 bin (lane = pixel); bin ids, list lengths and list entries are wave-uniform
-  // (scalar registers), so list walking costs scalar branches and broadcast LDS reads only
+  // ---- shade: one wave per 8x16 bin, each lane owns the pixels (x, y) and (x, y+8) of the bin.  Bin ids, list
+  // lengths and list entries are wave-uniform (scalar registers): list walking costs scalar branches and broadcast
+  // LDS reads; the second pixel of a lane re-uses every edge value (e(y+8) = e(y) + 8*B).
   {
     const bool show_flag = (old_flags & 1u) && p.backwards_flag;
     const float kx = 96.0f / 1000.0f, ky = 96.0f / 800.0f;
     float fe[9];
     { const float fx[3] = {900.0f * kx, 925.0f * kx, 950.0f * kx}, fy[3] = {30.0f * ky, 70.0f * ky, 30.0f * ky}; edge_setup(fx, fy, 3, fe); }
     const float hud_top = hud[VP_HUDTOP - VP_IND];
-    const int hud_rows = UNI((int)ceilf(hud_top * 0.125f));              // bin rows that can contain HUD pixels
+    const int hud_rows = UNI((int)ceilf(hud_top * 0.0625f));             // bin rows that can contain HUD pixels
     const int lx = lane & 7, ly = lane >> 3;
     const float flx = (float)lx + 0.5f, fly = (float)ly + 0.5f;
     // background in "checker units": U = world.x / (2k), V = world.y / (2k) with k = PLAYFIELD/20;
@@ -461,77 +462,108 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
     const float aU = ld_f32(vp + VP_INV + 0) * hk, bU = ld_f32(vp + VP_INV + 1) * hk, cU = ld_f32(vp + VP_INV + 2) * hk;
     const float aV = ld_f32(vp + VP_INV + 3) * hk, bV = ld_f32(vp + VP_INV + 4) * hk, cV = ld_f32(vp + VP_INV + 5) * hk;
     const float U_lane = aU * flx + bU * fly + cU, V_lane = aV * flx + bV * fly + cV;
+    const float dU8 = 8.0f * bU, dV8 = 8.0f * bV;
     const int fb_lane = (95 - ly) * 96 + lx;
     const int ncar = N * 12;
     for (int it = 0; it < NBINS / 4; ++it) {
       // wave w takes the bins with (bx + 2*by) % 4 == w: any 2x2 block of bins lands on four different waves
       const int byi = it / 3, bxi = ((wave - 2 * byi) & 3) + 4 * (it - byi * 3);   // scalar
       const int b = byi * 12 + bxi;
-      const float fbx = (float)(bxi * 8), fby = (float)(byi * 8);
-      const float cx = fbx + flx, cy = fby + fly;                       // pixel centre, GL coords (origin bottom-left)
-      uint32_t col = PAL_BLACK;
-      if (byi >= 1) {                                                   // bin row 0 (y < 8) is entirely under the HUD bar
-        const float U = U_lane + aU * fbx + bU * fby, V = V_lane + aV * fbx + bV * fby;
-        if (fabsf(U) <= 10.0f && fabsf(V) <= 10.0f)
-          col = ((U - floorf(U)) < 0.5f && (V - floorf(V)) < 0.5f) ? PAL_GRASS1 : PAL_GRASS0;
-        // highest draw index covering the pixel wins (painter's order): road_poly index, then car polygons
-        const int cnt = UNI(bcnt[b]);
-        int best = -1;
-        if (cnt <= BIN_CAP) {
-          for (int k = 0; k < cnt; ++k) {
-            const int s = UNI((int)bins[b][k]);
-            if (s >= CAR_KEY) {
-              const float4* r = &car8[(s - CAR_KEY) * 6];
-              const bool in = inside4(r[0], r[1], r[2], cx, cy) && inside4(r[3], r[4], r[5], cx, cy);
-              const int key = (s << 5) | (int)(cinfo[s - CAR_KEY] & 31u);
-              if (in && key > best) best = key;
-            } else if (s < VIS_LDS) {
-              const int key = (int)qinfo[s] << 2;                        // (q << 5) | colour << 2
-              if (inside4(qe[s][0], qe[s][1], qe[s][2], cx, cy) && key > best && !(dbg & 2)) best = key;
-            } else {
-              const float4* d = (const float4*)(spill + (size_t)(s - VIS_LDS) * 16);
-              const int key = (int)__float_as_uint(d[3].x) << 2;
-              if (inside4(d[0], d[1], d[2], cx, cy) && key > best) best = key;
-            }
-          }
-        } else {
-          for (int s = 0; s < nq_lds; ++s) {
-            const int key = (int)qinfo[s] << 2;
-            if (inside4(qe[s][0], qe[s][1], qe[s][2], cx, cy) && key > best) best = key;
-          }
-          for (int s = VIS_LDS; s < nq; ++s) {
+      const float fbx = (float)(bxi * 8), fby = (float)(byi * 16);
+      const float cx = fbx + flx, cy0 = fby + fly, cy1 = cy0 + 8.0f;    // pixel centres, GL coords (origin bottom-left)
+      uint32_t col0 = PAL_BLACK, col1 = PAL_BLACK;
+      {
+        const float U0 = U_lane + aU * fbx + bU * fby, V0 = V_lane + aV * fbx + bV * fby;
+        const float U1 = U0 + dU8, V1 = V0 + dV8;
+        if (fabsf(U0) <= 10.0f && fabsf(V0) <= 10.0f) col0 = ((U0 - floorf(U0)) < 0.5f && (V0 - floorf(V0)) < 0.5f) ? PAL_GRASS1 : PAL_GRASS0;
+        if (fabsf(U1) <= 10.0f && fabsf(V1) <= 10.0f) col1 = ((U1 - floorf(U1)) < 0.5f && (V1 - floorf(V1)) < 0.5f) ? PAL_GRASS1 : PAL_GRASS0;
+      }
+      // highest draw index covering the pixel wins (painter's order): road_poly index, then car polygons
+      const int cnt = UNI(bcnt[b]);
+      int best0 = -1, best1 = -1;
+#define EDGE4_2PX(r0, r1, r2, in0, in1)                                                                                   \
+      {                                                                                                                  \
+        const float e0 = r0.x * cx + r0.y * cy0 + r0.z, e1 = r0.w * cx + r1.x * cy0 + r1.y, e2 = r1.z * cx + r1.w * cy0 + r2.x,  \
+                    e3 = r2.y * cx + r2.z * cy0 + r2.w;                                                                  \
+        in0 = fminf(fminf(e0, e1), fminf(e2, e3)) >= 0.0f;                                                               \
+        in1 = fminf(fminf(e0 + 8.0f * r0.y, e1 + 8.0f * r1.x), fminf(e2 + 8.0f * r1.w, e3 + 8.0f * r2.z)) >= 0.0f;       \
+      }
+      if (cnt <= BIN_CAP) {
+        for (int k = 0; k < cnt; ++k) {
+          const int s = UNI((int)bins[b][k]);
+          if (s >= CAR_KEY) {
+            const float4* r = &car8[(s - CAR_KEY) * 6];
+            bool a0, a1, b0, b1;
+            EDGE4_2PX(r[0], r[1], r[2], a0, a1); EDGE4_2PX(r[3], r[4], r[5], b0, b1);
+            const int key = (s << 5) | (int)(cinfo[s - CAR_KEY] & 31u);
+            if (a0 && b0 && key > best0) best0 = key;
+            if (a1 && b1 && key > best1) best1 = key;
+          } else if (s < VIS_LDS) {
+            const int key = (int)qinfo[s] << 2;                        // (q << 5) | colour << 2
+            bool a0, a1; EDGE4_2PX(qe[s][0], qe[s][1], qe[s][2], a0, a1);
+            if (!(dbg & 2)) { if (a0 && key > best0) best0 = key; if (a1 && key > best1) best1 = key; }
+          } else {
             const float4* d = (const float4*)(spill + (size_t)(s - VIS_LDS) * 16);
             const int key = (int)__float_as_uint(d[3].x) << 2;
-            if (inside4(d[0], d[1], d[2], cx, cy) && key > best) best = key;
-          }
-          for (int k = 0; k < ncar; ++k) {
-            const uint32_t ci2 = cinfo[k];
-            if (!ci2) continue;
-            const float4* r = &car8[k * 6];
-            const int key = ((CAR_KEY + k) << 5) | (int)(ci2 & 31u);
-            if (inside4(r[0], r[1], r[2], cx, cy) && inside4(r[3], r[4], r[5], cx, cy) && key > best) best = key;
+            bool a0, a1; EDGE4_2PX(d[0], d[1], d[2], a0, a1);
+            if (a0 && key > best0) best0 = key;
+            if (a1 && key > best1) best1 = key;
           }
         }
-        if (best >= 0) {
-          if (best >= (CAR_KEY << 5)) col = (uint32_t)best & 31u;
-          else {
-            const uint32_t bc = ((uint32_t)best >> 2) & 7u;
-            col = bc == MCR_COL_ROAD0 ? PAL_ROAD0 : bc == MCR_COL_ROAD1 ? PAL_ROAD1 : bc == MCR_COL_ROAD2 ? PAL_ROAD2 : bc == MCR_COL_KERB_WHITE ? PAL_WHITE : PAL_RED255;
-          }
+      } else {
+        for (int s = 0; s < nq_lds; ++s) {
+          const int key = (int)qinfo[s] << 2;
+          bool a0, a1; EDGE4_2PX(qe[s][0], qe[s][1], qe[s][2], a0, a1);
+          if (a0 && key > best0) best0 = key;
+          if (a1 && key > best1) best1 = key;
         }
-        if (byi == 1 && cy < 12.0f) col = PAL_BLACK;                   // the HUD bar (window y < 100) covers the scene
+        for (int s = VIS_LDS; s < nq; ++s) {
+          const float4* d = (const float4*)(spill + (size_t)(s - VIS_LDS) * 16);
+          const int key = (int)__float_as_uint(d[3].x) << 2;
+          bool a0, a1; EDGE4_2PX(d[0], d[1], d[2], a0, a1);
+          if (a0 && key > best0) best0 = key;
+          if (a1 && key > best1) best1 = key;
+        }
+        for (int k = 0; k < ncar; ++k) {
+          const uint32_t ci2 = cinfo[k];
+          if (!ci2) continue;
+          const float4* r = &car8[k * 6];
+          const int key = ((CAR_KEY + k) << 5) | (int)(ci2 & 31u);
+          bool a0, a1, b0, b1;
+          EDGE4_2PX(r[0], r[1], r[2], a0, a1); EDGE4_2PX(r[3], r[4], r[5], b0, b1);
+          if (a0 && b0 && key > best0) best0 = key;
+          if (a1 && b1 && key > best1) best1 = key;
+        }
       }
-      if (byi < hud_rows && cy < hud_top) {
-        // HUD (window space, drawn last): gauges in draw order (a tall gauge may poke above the bar), then the flag
+#undef EDGE4_2PX
+      if (best0 >= 0) {
+        if (best0 >= (CAR_KEY << 5)) col0 = (uint32_t)best0 & 31u;
+        else { const uint32_t bc = ((uint32_t)best0 >> 2) & 7u; col0 = bc == MCR_COL_ROAD0 ? PAL_ROAD0 : bc == MCR_COL_ROAD1 ? PAL_ROAD1 : bc == MCR_COL_ROAD2 ? PAL_ROAD2 : bc == MCR_COL_KERB_WHITE ? PAL_WHITE : PAL_RED255; }
+      }
+      if (best1 >= 0) {
+        if (best1 >= (CAR_KEY << 5)) col1 = (uint32_t)best1 & 31u;
+        else { const uint32_t bc = ((uint32_t)best1 >> 2) & 7u; col1 = bc == MCR_COL_ROAD0 ? PAL_ROAD0 : bc == MCR_COL_ROAD1 ? PAL_ROAD1 : bc == MCR_COL_ROAD2 ? PAL_ROAD2 : bc == MCR_COL_KERB_WHITE ? PAL_WHITE : PAL_RED255; }
+      }
+      if (byi < hud_rows) {
+        // the HUD bar (window y < 100) covers the scene; gauges in draw order (a tall gauge may poke above the
+        // bar), then the backwards flag — all in window space, drawn last
+        if (cy0 < 12.0f) col0 = PAL_BLACK;
+        if (cy1 < 12.0f) col1 = PAL_BLACK;
         const uint32_t ind_col[7] = {PAL_WHITE, PAL_BLUE255, PAL_BLUE255, PAL_PURPLE, PAL_PURPLE, PAL_GREEN255, PAL_RED255};
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
           const float x0 = hud[i * 4], x1 = hud[i * 4 + 1], y0 = hud[i * 4 + 2], y1 = hud[i * 4 + 3];
-          if (x1 > x0 && y1 > y0 && cx >= x0 && cx <= x1 && cy >= y0 && cy <= y1) col = ind_col[i];
+          const bool okx = x1 > x0 && y1 > y0 && cx >= x0 && cx <= x1;
+          if (okx && cy0 >= y0 && cy0 <= y1) col0 = ind_col[i];
+          if (okx && cy1 >= y0 && cy1 <= y1) col1 = ind_col[i];
         }
-        if (show_flag && (fe[0] * cx + fe[1] * cy + fe[2] >= 0.0f) && (fe[3] * cx + fe[4] * cy + fe[5] >= 0.0f) && (fe[6] * cx + fe[7] * cy + fe[8] >= 0.0f)) col = PAL_BLUE255;
+        if (show_flag) {
+          if ((fe[0] * cx + fe[1] * cy0 + fe[2] >= 0.0f) && (fe[3] * cx + fe[4] * cy0 + fe[5] >= 0.0f) && (fe[6] * cx + fe[7] * cy0 + fe[8] >= 0.0f)) col0 = PAL_BLUE255;
+          if ((fe[0] * cx + fe[1] * cy1 + fe[2] >= 0.0f) && (fe[3] * cx + fe[4] * cy1 + fe[5] >= 0.0f) && (fe[6] * cx + fe[7] * cy1 + fe[8] >= 0.0f)) col1 = PAL_BLUE255;
+        }
       }
-      fb[fb_lane - byi * 768 + bxi * 8] = (uint8_t)col;                 // arr[::-1] (:602)
+      const int fo = fb_lane - byi * (16 * 96) + bxi * 8;               // arr[::-1] (:602)
+      fb[fo] = (uint8_t)col0; fb[fo - 8 * 96] = (uint8_t)col1;
     }
   }
   PHASE_STAMP(7);

@@ -39,7 +39,7 @@ class VecMultiCarRacing:
         self.obs_enabled = bool(obs)
         self.auto_reset = bool(auto_reset)
         self.direction_mode = 2 if use_random_direction else _DIRECTION_MODE[direction]
-        self.gen_threads = gen_threads or max(1, (os.cpu_count() or 2) - 1)
+        self.gen_threads = gen_threads or max(1, _lib.effective_cpus() - 1)
         cfg = _lib.Config(self.B, self.N, self.device.index or 0, int(self.obs_enabled), int(self.auto_reset),
                           int(backwards_flag), int(use_ego_color), int(car_contacts), int(max_episode_steps), int(streams),
                           float(h_ratio))
