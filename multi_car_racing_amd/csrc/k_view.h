@@ -444,6 +444,9 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
   }
   if (!draw) return;
 
+  // Coverage tests use fused multiply-adds: pixel colours are compared against the ideal raster with an ambiguity
+  // band (tests/util.py), so the raster is free to evaluate edge functions MORE accurately than mul+add would.
+#define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
   // ---- shade: one wave per 8x16 bin, each lane owns the pixels (x, y) and (x, y+8) of the bin.  Bin ids, list
   // lengths and list entries are wave-uniform (scalar registers): list walking costs scalar branches and broadcast
   // LDS reads; the second pixel of a lane re-uses every edge value (e(y+8) = e(y) + 8*B).
@@ -465,10 +468,15 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
     const float dU8 = 8.0f * bU, dV8 = 8.0f * bV;
     const int fb_lane = (95 - ly) * 96 + lx;
     const int ncar = N * 12;
+    // list lengths of this wave's 18 bins, one per lane; a bin's list is fetched with ONE vector LDS read (lane k
+    // holds entry k) and handed out with v_readlane, so walking a list costs no LDS round trip per entry
+    int cnt_v = 0;
+    if (lane < NBINS / 4) { const int yy = lane / 3; cnt_v = bcnt[yy * 12 + ((wave - 2 * yy) & 3) + 4 * (lane - yy * 3)]; }
     for (int it = 0; it < NBINS / 4; ++it) {
       // wave w takes the bins with (bx + 2*by) % 4 == w: any 2x2 block of bins lands on four different waves
       const int byi = it / 3, bxi = ((wave - 2 * byi) & 3) + 4 * (it - byi * 3);   // scalar
       const int b = byi * 12 + bxi;
+      const int list_v = (int)bins[b][lane < BIN_CAP ? lane : 0];
       const float fbx = (float)(bxi * 8), fby = (float)(byi * 16);
       const float cx = fbx + flx, cy0 = fby + fly, cy1 = cy0 + 8.0f;    // pixel centres, GL coords (origin bottom-left)
       uint32_t col0 = PAL_BLACK, col1 = PAL_BLACK;
@@ -479,18 +487,18 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
         if (fabsf(U1) <= 10.0f && fabsf(V1) <= 10.0f) col1 = ((U1 - floorf(U1)) < 0.5f && (V1 - floorf(V1)) < 0.5f) ? PAL_GRASS1 : PAL_GRASS0;
       }
       // highest draw index covering the pixel wins (painter's order): road_poly index, then car polygons
-      const int cnt = UNI(bcnt[b]);
+      const int cnt = __builtin_amdgcn_readlane(cnt_v, it);
       int best0 = -1, best1 = -1;
 #define EDGE4_2PX(r0, r1, r2, in0, in1)                                                                                   \
       {                                                                                                                  \
-        const float e0 = r0.x * cx + r0.y * cy0 + r0.z, e1 = r0.w * cx + r1.x * cy0 + r1.y, e2 = r1.z * cx + r1.w * cy0 + r2.x,  \
-                    e3 = r2.y * cx + r2.z * cy0 + r2.w;                                                                  \
+        const float e0 = FMA(r0.x, cx, FMA(r0.y, cy0, r0.z)), e1 = FMA(r0.w, cx, FMA(r1.x, cy0, r1.y)),                  \
+                    e2 = FMA(r1.z, cx, FMA(r1.w, cy0, r2.x)), e3 = FMA(r2.y, cx, FMA(r2.z, cy0, r2.w));                  \
         in0 = fminf(fminf(e0, e1), fminf(e2, e3)) >= 0.0f;                                                               \
-        in1 = fminf(fminf(e0 + 8.0f * r0.y, e1 + 8.0f * r1.x), fminf(e2 + 8.0f * r1.w, e3 + 8.0f * r2.z)) >= 0.0f;       \
+        in1 = fminf(fminf(FMA(8.0f, r0.y, e0), FMA(8.0f, r1.x, e1)), fminf(FMA(8.0f, r1.w, e2), FMA(8.0f, r2.z, e3))) >= 0.0f; \
       }
       if (cnt <= BIN_CAP) {
         for (int k = 0; k < cnt; ++k) {
-          const int s = UNI((int)bins[b][k]);
+          const int s = __builtin_amdgcn_readlane(list_v, k);
           if (s >= CAR_KEY) {
             const float4* r = &car8[(s - CAR_KEY) * 6];
             bool a0, a1, b0, b1;
@@ -536,6 +544,7 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
         }
       }
 #undef EDGE4_2PX
+#undef FMA
       if (best0 >= 0) {
         if (best0 >= (CAR_KEY << 5)) col0 = (uint32_t)best0 & 31u;
         else { const uint32_t bc = ((uint32_t)best0 >> 2) & 7u; col0 = bc == MCR_COL_ROAD0 ? PAL_ROAD0 : bc == MCR_COL_ROAD1 ? PAL_ROAD1 : bc == MCR_COL_ROAD2 ? PAL_ROAD2 : bc == MCR_COL_KERB_WHITE ? PAL_WHITE : PAL_RED255; }
