@@ -191,7 +191,7 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
   extern __shared__ __attribute__((aligned(16))) float4 car8[];             // [N*12][6]
   __shared__ __attribute__((aligned(16))) uint8_t fb[96 * 96];
   __shared__ __attribute__((aligned(16))) float4 qe[VIS_LDS][3];          // 4 oriented edges (A,B,C) of each surviving quad
-  __shared__ uint32_t qinfo[VIS_LDS];                                       // quad index << 3 | colour
+  __shared__ uint32_t qinfo[VIS_LDS];                                       // quad index << 5 | palette index
   __shared__ uint16_t bins[NBINS][BIN_CAP];
   __shared__ int bcnt[NBINS];
   __shared__ uint16_t surv[MCR_QUAD_CAP];
@@ -369,7 +369,9 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
         const uint32_t w = ld_u32((const uint32_t*)tflags + ((tile1 - 1) >> 1));
         if ((w >> (((tile1 - 1) & 1u) * 16u)) & 0x100u) col = MCR_COL_ROAD0;
       }
-      const uint32_t info = ((uint32_t)q << 3) | col;
+      // draw-order key: quad index above the 5-bit palette index, so "highest key wins" also carries the colour
+      const uint32_t pal = col == MCR_COL_ROAD0 ? PAL_ROAD0 : col == MCR_COL_ROAD1 ? PAL_ROAD1 : col == MCR_COL_ROAD2 ? PAL_ROAD2 : col == MCR_COL_KERB_WHITE ? PAL_WHITE : PAL_RED255;
+      const uint32_t info = ((uint32_t)q << 5) | pal;
       if (s < VIS_LDS) {
         qe[s][0] = make_float4(e[0], e[1], e[2], e[3]); qe[s][1] = make_float4(e[4], e[5], e[6], e[7]); qe[s][2] = make_float4(e[8], e[9], e[10], e[11]);
         qinfo[s] = info;
@@ -472,6 +474,25 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
     // holds entry k) and handed out with v_readlane, so walking a list costs no LDS round trip per entry
     int cnt_v = 0;
     if (lane < NBINS / 4) { const int yy = lane / 3; cnt_v = bcnt[yy * 12 + ((wave - 2 * yy) & 3) + 4 * (lane - yy * 3)]; }
+    // background class per bin, one bin per lane: when the (U,V) bounding box of a bin's pixel centres stays clear of
+    // every checker boundary (margin 1e-4 units >> f32 rounding of the per-pixel evaluation) the bin is one colour
+    int ucol_v = 0xff;
+    if (lane < NBINS / 4) {
+      const int yy = lane / 3, xx = ((wave - 2 * yy) & 3) + 4 * (lane - yy * 3);
+      const float X0 = (float)(xx * 8) + 0.5f, Y0 = (float)(yy * 16) + 0.5f;
+      const float u00 = aU * X0 + bU * Y0 + cU, v00 = aV * X0 + bV * Y0 + cV;
+      const float ux = 7.0f * aU, uy = 15.0f * bU, vx = 7.0f * aV, vy = 15.0f * bV;
+      const float umin = u00 + fminf(ux, 0.0f) + fminf(uy, 0.0f) - 1e-4f, umax = u00 + fmaxf(ux, 0.0f) + fmaxf(uy, 0.0f) + 1e-4f;
+      const float vmin = v00 + fminf(vx, 0.0f) + fminf(vy, 0.0f) - 1e-4f, vmax = v00 + fmaxf(vx, 0.0f) + fmaxf(vy, 0.0f) + 1e-4f;
+      if (umin > 10.0f || umax < -10.0f || vmin > 10.0f || vmax < -10.0f) ucol_v = PAL_BLACK;
+      else if (umin >= -10.0f && umax <= 10.0f && vmin >= -10.0f && vmax <= 10.0f) {
+        const float fu = floorf(umin), fv = floorf(vmin);
+        const bool u_dark = umin - fu > 0.5f && umax < fu + 1.0f, v_dark = vmin - fv > 0.5f && vmax < fv + 1.0f;
+        const bool u_light = umax < fu + 0.5f, v_light = vmax < fv + 0.5f;
+        if (u_dark || v_dark) ucol_v = PAL_GRASS0;
+        else if (u_light && v_light) ucol_v = PAL_GRASS1;
+      }
+    }
     for (int it = 0; it < NBINS / 4; ++it) {
       // wave w takes the bins with (bx + 2*by) % 4 == w: any 2x2 block of bins lands on four different waves
       const int byi = it / 3, bxi = ((wave - 2 * byi) & 3) + 4 * (it - byi * 3);   // scalar
@@ -480,7 +501,9 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
       const float fbx = (float)(bxi * 8), fby = (float)(byi * 16);
       const float cx = fbx + flx, cy0 = fby + fly, cy1 = cy0 + 8.0f;    // pixel centres, GL coords (origin bottom-left)
       uint32_t col0 = PAL_BLACK, col1 = PAL_BLACK;
-      {
+      const int ucol = __builtin_amdgcn_readlane(ucol_v, it);
+      if (ucol != 0xff) col0 = col1 = (uint32_t)ucol;
+      else {
         const float U0 = U_lane + aU * fbx + bU * fby, V0 = V_lane + aV * fbx + bV * fby;
         const float U1 = U0 + dU8, V1 = V0 + dV8;
         if (fabsf(U0) <= 10.0f && fabsf(V0) <= 10.0f) col0 = ((U0 - floorf(U0)) < 0.5f && (V0 - floorf(V0)) < 0.5f) ? PAL_GRASS1 : PAL_GRASS0;
@@ -507,12 +530,12 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
             if (a0 && b0 && key > best0) best0 = key;
             if (a1 && b1 && key > best1) best1 = key;
           } else if (s < VIS_LDS) {
-            const int key = (int)qinfo[s] << 2;                        // (q << 5) | colour << 2
+            const int key = (int)qinfo[s];
             bool a0, a1; EDGE4_2PX(qe[s][0], qe[s][1], qe[s][2], a0, a1);
             if (!(dbg & 2)) { if (a0 && key > best0) best0 = key; if (a1 && key > best1) best1 = key; }
           } else {
             const float4* d = (const float4*)(spill + (size_t)(s - VIS_LDS) * 16);
-            const int key = (int)__float_as_uint(d[3].x) << 2;
+            const int key = (int)__float_as_uint(d[3].x);
             bool a0, a1; EDGE4_2PX(d[0], d[1], d[2], a0, a1);
             if (a0 && key > best0) best0 = key;
             if (a1 && key > best1) best1 = key;
@@ -520,14 +543,14 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
         }
       } else {
         for (int s = 0; s < nq_lds; ++s) {
-          const int key = (int)qinfo[s] << 2;
+          const int key = (int)qinfo[s];
           bool a0, a1; EDGE4_2PX(qe[s][0], qe[s][1], qe[s][2], a0, a1);
           if (a0 && key > best0) best0 = key;
           if (a1 && key > best1) best1 = key;
         }
         for (int s = VIS_LDS; s < nq; ++s) {
           const float4* d = (const float4*)(spill + (size_t)(s - VIS_LDS) * 16);
-          const int key = (int)__float_as_uint(d[3].x) << 2;
+          const int key = (int)__float_as_uint(d[3].x);
           bool a0, a1; EDGE4_2PX(d[0], d[1], d[2], a0, a1);
           if (a0 && key > best0) best0 = key;
           if (a1 && key > best1) best1 = key;
@@ -545,14 +568,8 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
       }
 #undef EDGE4_2PX
 #undef FMA
-      if (best0 >= 0) {
-        if (best0 >= (CAR_KEY << 5)) col0 = (uint32_t)best0 & 31u;
-        else { const uint32_t bc = ((uint32_t)best0 >> 2) & 7u; col0 = bc == MCR_COL_ROAD0 ? PAL_ROAD0 : bc == MCR_COL_ROAD1 ? PAL_ROAD1 : bc == MCR_COL_ROAD2 ? PAL_ROAD2 : bc == MCR_COL_KERB_WHITE ? PAL_WHITE : PAL_RED255; }
-      }
-      if (best1 >= 0) {
-        if (best1 >= (CAR_KEY << 5)) col1 = (uint32_t)best1 & 31u;
-        else { const uint32_t bc = ((uint32_t)best1 >> 2) & 7u; col1 = bc == MCR_COL_ROAD0 ? PAL_ROAD0 : bc == MCR_COL_ROAD1 ? PAL_ROAD1 : bc == MCR_COL_ROAD2 ? PAL_ROAD2 : bc == MCR_COL_KERB_WHITE ? PAL_WHITE : PAL_RED255; }
-      }
+      if (best0 >= 0) col0 = (uint32_t)best0 & 31u;
+      if (best1 >= 0) col1 = (uint32_t)best1 & 31u;
       if (byi < hud_rows) {
         // the HUD bar (window y < 100) covers the scene; gauges in draw order (a tall gauge may poke above the
         // bar), then the backwards flag — all in window space, drawn last
