@@ -21,6 +21,7 @@ namespace col {
 // `i < n` predicate so that nothing is indexed dynamically (dynamic indexing would put it in scratch memory).
 struct TilePoly { int n; float vx[4], vy[4], nx[4], ny[4]; };
 
+#define CAND_CAP 128                 // (tile, car) candidate pairs buffered before the overlap pass runs
 #define TILE_FOR(i) _Pragma("unroll") for (int i = 0; i < 4; ++i)
 
 // max over A's edge normals of the min projection of B's vertices (A = car fixture in LDS, B = tile)
@@ -97,6 +98,8 @@ __global__ __launch_bounds__(64) void k_collide(McrParams p, int pass) {
   __shared__ float cbox[MCR_MAX_AGENTS][4];
   __shared__ float4 fxf[64], fbox[64];                 // per fixture: body transform (p.x p.y s c), world AABB +-0.05
   __shared__ uint32_t newrec[MCR_CC_MAX][16];
+  __shared__ uint32_t tres[MCR_TILE_CAP], tany[MCR_TILE_CAP / 32];
+  __shared__ uint32_t cand[CAND_CAP];
   {
     const int c = lane >> 3, fi = lane & 7;
     float lox = MCR_MAXFLT, loy = MCR_MAXFLT, hix = -MCR_MAXFLT, hiy = -MCR_MAXFLT;
@@ -138,32 +141,63 @@ __global__ __launch_bounds__(64) void k_collide(McrParams p, int pass) {
   const float4* TVA = (const float4*)(slot + MCR_OFF_TVA); const float4* TVB = (const float4*)(slot + MCR_OFF_TVB);
   const float4* TNA = (const float4*)(slot + MCR_OFF_TNA); const float4* TNB = (const float4*)(slot + MCR_OFF_TNB);
   const uint32_t* TCNT = (const uint32_t*)(slot + MCR_OFF_TCNT);
+  // ---- phase A/B: candidate (tile, car) pairs by AABB, compacted into LDS; the expensive overlap predicate then
+  // runs with one lane per (pair, fixture) item, so all 64 lanes work instead of the few whose tile is near a car.
+  // Result per tile in LDS: tres bit 4c+w = wheel w of car c touches; tany bit = some fixture (hull or wheel) touches.
+  for (int t = lane; t < T; t += 64) tres[t] = 0;
+  if (lane < MCR_TILE_CAP / 32) tany[lane] = 0;
+  __syncthreads();
+  int ncand = 0;                                                    // wave-uniform
+  auto flush = [&]() {
+    __syncthreads();                                               // cand[] writes -> reads (one wave per block)
+    const int items = ncand * 8;
+    for (int i0 = 0; i0 < items; i0 += 64) {
+      const int i = i0 + lane;
+      if (i < items) {
+        const uint32_t pc = cand[i >> 3]; const int fi = i & 7;
+        const int t = (int)(pc & 0xffffu), c = (int)(pc >> 16), f = c * 8 + fi;
+        const float4 bb = TAABB[t], fb = fbox[f];
+        if (!(bb.x > fb.z || bb.z < fb.x || bb.y > fb.w || bb.w < fb.y)) {
+          const float4 va = TVA[t], vb = TVB[t], na = TNA[t], nb = TNB[t];
+          TilePoly TP;
+          TP.n = (int)(TCNT[t] & 0xffu);
+          TP.vx[0] = va.x; TP.vy[0] = va.y; TP.vx[1] = va.z; TP.vy[1] = va.w; TP.vx[2] = vb.x; TP.vy[2] = vb.y; TP.vx[3] = vb.z; TP.vy[3] = vb.w;
+          TP.nx[0] = na.x; TP.ny[0] = na.y; TP.nx[1] = na.z; TP.ny[1] = na.w; TP.nx[2] = nb.x; TP.ny[2] = nb.y; TP.nx[3] = nb.z; TP.ny[3] = nb.w;
+          if (overlap(fvx[f], fvy[f], fnx[f], fny[f], fcnt[f], TP))
+          { if (fi >= 4) atomicOr(&tres[t], 1u << (c * 4 + (fi - 4))); atomicOr(&tany[t >> 5], 1u << (t & 31)); }
+        }
+      }
+    }
+    ncand = 0;
+    __syncthreads();
+  };
+  for (int base = 0; base < T; base += 64) {
+    const int t = base + lane;
+    float4 bb = make_float4(MCR_MAXFLT, MCR_MAXFLT, -MCR_MAXFLT, -MCR_MAXFLT);
+    if (t < T) bb = TAABB[t];
+    for (int c = 0; c < N; ++c) {
+      const bool hit = !(bb.x > cbox[c][2] || bb.z < cbox[c][0] || bb.y > cbox[c][3] || bb.w < cbox[c][1]);
+      const unsigned long long m = __ballot(hit);
+      if (!m) continue;
+      const int k = __popcll(m);
+      if (ncand + k > CAND_CAP) flush();
+      if (hit) cand[ncand + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)t | ((uint32_t)c << 16);
+      ncand += k;
+    }
+  }
+  flush();
+
+  // ---- phase C: per-tile contact state, begin events, reward replay (lane = tile)
   uint32_t or_bits = 0;
   for (int base = 0; base < T; base += 64) {
     const int t = base + lane;
     const bool valid = t < T;
-    uint32_t newbits = 0; bool touch_any = false;
+    uint32_t newbits = 0;
     uint32_t old = 0; uint32_t fl = 0;
     if (valid) {
       old = touch[t]; fl = tflags[t];
-      const float4 bb = TAABB[t];
-      bool loaded = false; TilePoly TP;
-      for (int c = 0; c < N; ++c) {
-        if (bb.x > cbox[c][2] || bb.z < cbox[c][0] || bb.y > cbox[c][3] || bb.w < cbox[c][1]) continue;
-        if (!loaded) {
-          float4 va = TVA[t], vb = TVB[t], na = TNA[t], nb = TNB[t];
-          TP.n = (int)(TCNT[t] & 0xffu);
-          TP.vx[0] = va.x; TP.vy[0] = va.y; TP.vx[1] = va.z; TP.vy[1] = va.w; TP.vx[2] = vb.x; TP.vy[2] = vb.y; TP.vx[3] = vb.z; TP.vy[3] = vb.w;
-          TP.nx[0] = na.x; TP.ny[0] = na.y; TP.nx[1] = na.z; TP.ny[1] = na.w; TP.nx[2] = nb.x; TP.ny[2] = nb.y; TP.nx[3] = nb.z; TP.ny[3] = nb.w;
-          loaded = true;
-        }
-        for (int fi = 0; fi < 8; ++fi) {
-          const int f = c * 8 + fi;
-          bool ov = overlap(fvx[f], fvy[f], fnx[f], fny[f], fcnt[f], TP);
-          if (ov) { touch_any = true; if (fi >= 4) newbits |= 1u << (c * 4 + (fi - 4)); }
-        }
-      }
-      if (touch_any || old != newbits) fl |= 0x100u;          // any Begin/End recolours the tile (:102-104)
+      newbits = tres[t];
+      if (((tany[t >> 5] >> (t & 31)) & 1u) || old != newbits) fl |= 0x100u;          // any Begin/End recolours the tile (:102-104)
     }
     const uint32_t begins = newbits & ~old;
     unsigned long long m = __ballot(valid && begins != 0);
