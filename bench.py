@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--agents", type=int, default=2)
     ap.add_argument("--obs", type=int, default=1)
     ap.add_argument("--streams", type=int, default=1, help="1: single stream (default); 2: experimental dynamics||raster overlap on CU-masked streams")
+    ap.add_argument("--stagger", type=int, default=1, help="1: spread the TimeLimit phases of the envs uniformly before timing (steady state); 0: all envs expire in the same step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event time all three kernels (adds overhead)")
     args = ap.parse_args()
@@ -93,6 +94,18 @@ def main():
     g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
     pool = torch.rand((64, B, N, 3), device=dev, generator=g)
     pool[..., 0] = pool[..., 0] * 2 - 1
+    # Steady state before anything is timed: a real rollout has its episodes ending at different steps, not all
+    # B TimeLimits expiring in the same step (which would put B host track generations into one burst).  One
+    # un-timed TimeLimit period in which env e is reset at step e*L/B leaves the episode phases uniformly spread;
+    # the timed region then sees the same number of resets (B per L steps), each with its host-side generation.
+    if args.stagger:
+        L = 1000
+        ids = torch.arange(B, device=dev)
+        for j in range(L):
+            env.step(pool[j % 64])
+            msk = ((ids * L) // B == j).to(torch.uint8)
+            if bool(msk.any()):
+                env.reset_envs(msk)
     for k in range(W):
         env.step(pool[k % 64])
     env.wait_refills()
@@ -150,7 +163,7 @@ def main():
             "ms_per_step": m["elapsed_s"] / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 rigid-body state / f64 tyre model / u8 pixels", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: num_agents=%d, batch=%d envs/GPU, %s, random-action rollout, "
-                                   "TimeLimit 1000 auto-reset incl. host track generation" % (N, B, "96x96 RGB obs" if args.obs else "obs=none"),
+                                   "TimeLimit 1000 auto-reset incl. host track generation%s" % (N, B, "96x96 RGB obs" if args.obs else "obs=none", ", episode phases staggered (steady state)" if args.stagger else ", all episodes in phase"),
                        "global_batch": B * world, "parallelism": "env-sharded dp%d (no data-path collective)" % world,
                        "episodes_reset_in_timed_region": m["episodes"]},
             "roofline": roofline,

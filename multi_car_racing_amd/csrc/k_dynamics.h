@@ -581,7 +581,28 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
   const float maxImpulse = h * (float)(180 * 900 * MCR_SIZE * MCR_SIZE);
   if (!wave_cc) {
     // hot loop of the common case: nothing but the four revolute joints, state in registers
-    if (run) {
+    if (mode == 1) {
+      // reset pass (step(None) on freshly spawned cars): the iteration map is a pure function of (velocities,
+      // accumulated impulses); once one sweep leaves all of them unchanged every later sweep does too, so the
+      // remaining sweeps are skipped — same final state as the full 180, a fraction of the serial chain.
+      for (int it = 0; it < 180; ++it) {
+        bool changed = false;
+        if (run) {
+          Body ob[5]; float oi[16];
+#pragma unroll
+          for (int k = 0; k < 5; ++k) ob[k] = b[k];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { oi[q * 4] = J[q].ix; oi[q * 4 + 1] = J[q].iy; oi[q * 4 + 2] = J[q].iz; oi[q * 4 + 3] = J[q].im; }
+#pragma unroll
+          for (int q = 3; q >= 0; --q) joint_velocity(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);
+#pragma unroll
+          for (int k = 0; k < 5; ++k) changed = changed || ob[k].vx != b[k].vx || ob[k].vy != b[k].vy || ob[k].w != b[k].w;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) changed = changed || oi[q * 4] != J[q].ix || oi[q * 4 + 1] != J[q].iy || oi[q * 4 + 2] != J[q].iz || oi[q * 4 + 3] != J[q].im;
+        }
+        if (!__any(changed)) break;
+      }
+    } else if (run) {
       for (int it = 0; it < 180; ++it) {
 #pragma unroll
         for (int q = 3; q >= 0; --q) joint_velocity(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);

@@ -60,6 +60,7 @@ class VecMultiCarRacing:
         self.slot_bytes = _lib.episode_bytes()
         self._blobs = torch.empty((self.B, self.slot_bytes), dtype=torch.uint8, pin_memory=True)
         self._blobs_np = self._blobs.numpy()
+        self._refill_pin = None       # pinned bounce buffer of the refill thread (grown on demand)
         self.episode_info = np.zeros((self.B, 12), np.int32)      # T, P, retries, cw, car_order[8] of the newest generated episode
         self._ids = np.zeros(self.B, np.int32)
         self.episodes_generated = 0
@@ -78,7 +79,12 @@ class VecMultiCarRacing:
         if n == 0:
             return
         mt_t = np.ascontiguousarray(self.mt_track[ids]); mt_d = np.ascontiguousarray(self.mt_draw[ids])
-        blobs = np.empty((n, self.slot_bytes), np.uint8) if n != self.B else self._blobs_np
+        if n != self.B:               # subset: generate into a contiguous pinned buffer so that staging is ONE call
+            if self._refill_pin is None or self._refill_pin.shape[0] < n:
+                self._refill_pin = torch.empty((max(n, 64), self.slot_bytes), dtype=torch.uint8, pin_memory=True)
+            blobs = self._refill_pin.numpy()[:n]
+        else:
+            blobs = self._blobs_np
         info = np.zeros((n, 12), np.int32)
         _lib.check(self.L.mcr_episodes_generate(_lib.ptr(mt_t), _lib.ptr(mt_d), n, self.N, self.direction_mode,
                                                 _lib.ptr(blobs), _lib.ptr(info), min(self.gen_threads, n)), "mcr_episodes_generate")
@@ -92,13 +98,11 @@ class VecMultiCarRacing:
         ids = np.ascontiguousarray(ids, np.int32)
         if len(ids) == 0:
             return
-        rows = self._blobs_np if len(ids) == self.B and np.array_equal(ids, np.arange(self.B)) else None
-        if rows is not None:
-            _lib.check(self.L.mcr_stage_episodes(self.h, _lib.ptr(ids), len(ids), _lib.ptr(rows), ctypes.c_void_p(stream.cuda_stream)), "mcr_stage_episodes")
-        else:
-            for e in ids:     # rows of the pinned pool are not contiguous for a subset: one call per env
-                one = np.array([e], np.int32)
-                _lib.check(self.L.mcr_stage_episodes(self.h, _lib.ptr(one), 1, _lib.ptr(self._blobs_np[e]), ctypes.c_void_p(stream.cuda_stream)), "mcr_stage_episodes")
+        if len(ids) == self.B and np.array_equal(ids, np.arange(self.B)):
+            rows = self._blobs_np
+        else:                         # rows generated by the matching _generate(ids) call
+            rows = self._refill_pin.numpy()[:len(ids)]
+        _lib.check(self.L.mcr_stage_episodes(self.h, _lib.ptr(ids), len(ids), _lib.ptr(rows), ctypes.c_void_p(stream.cuda_stream)), "mcr_stage_episodes")
 
     def _refill(self, ids):
         self._generate(ids)
@@ -111,8 +115,22 @@ class VecMultiCarRacing:
             ids = self._q.get()
             if ids is None:
                 return
-            self._refill(ids)
-            self._q.task_done()
+            batch, taken, stop = [ids], 1, False
+            while True:               # drain: everything queued meanwhile goes into the same generate + stage batch
+                try:
+                    more = self._q.get_nowait()
+                except queue.Empty:
+                    break
+                taken += 1
+                if more is None:
+                    stop = True
+                    break
+                batch.append(more)
+            self._refill(np.concatenate(batch))
+            for _ in range(taken):
+                self._q.task_done()
+            if stop:
+                return
 
     def _poll_and_refill(self):
         n = self.L.mcr_poll_consumed(self.h, _lib.ptr(self._ids), self.B, None)
@@ -149,6 +167,24 @@ class VecMultiCarRacing:
                                     ctypes.c_void_p(st.cuda_stream)), "mcr_reset")
         st.synchronize()
         self._has_reset = True
+        self._poll_and_refill()
+        return self.obs
+
+    def reset_envs(self, mask):
+        """Reset the envs whose byte in `mask` (uint8 device tensor [B]) is non-zero: each installs its staged
+        episode (reference reset(), :340-408) and gets its first observation written into `self.obs`."""
+        if not self._has_reset:
+            raise AttributeError("reset_envs() before reset()")
+        st = torch.cuda.current_stream(self.device)
+        if mask.dtype != torch.uint8 or mask.device != self.device or mask.numel() != self.B or not mask.is_contiguous():
+            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            if mask.numel() != self.B:
+                raise ValueError(f"mask must have {self.B} elements")
+        self.wait_refills()                   # a masked env must find its staged slot filled
+        _lib.check(self.L.mcr_reset(self.h, ctypes.c_void_p(mask.data_ptr()),
+                                    ctypes.c_void_p(self.obs.data_ptr()) if self.obs_enabled else None,
+                                    ctypes.c_void_p(st.cuda_stream)), "mcr_reset")
+        st.synchronize()
         self._poll_and_refill()
         return self.obs
 
