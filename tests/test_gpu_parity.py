@@ -179,6 +179,44 @@ def test_time_limit_and_auto_reset(torch_cuda, oracle):
     env.close()
 
 
+def test_masked_reset_matches_oracle(torch_cuda, oracle):
+    """reset_envs(mask): masked envs install their next episode (next draw of their own RNG streams) and get their
+    first observation; the others keep stepping undisturbed — all bit-exact against per-env oracles."""
+    torch = torch_cuda
+    B, N, seed = 4, 2, 77
+    env = _make(B, N, seed, contacts=False, auto_reset=True, max_episode_steps=0, use_random_direction=True)
+    env.reset()
+    streams, orcs = [], []
+    for e in range(B):
+        s = (seed + e) % 2 ** 32
+        tr, gr = np.random.RandomState(s), np.random.RandomState((s + 2 ** 31) % 2 ** 32)
+        o = oracle.OracleEnv(N, car_contacts=False); o.reset(oracle.new_episode(N, tr, gr, use_random_direction=True))
+        streams.append((tr, gr)); orcs.append(o)
+    rng = np.random.RandomState(3)
+    for k in range(25):
+        a = random_actions(rng, B, N, 0.2)
+        env.step(torch.from_numpy(a).cuda())
+        for e, o in enumerate(orcs):
+            o.step(a[e], render=False)
+    mask = np.array([1, 0, 1, 0], np.uint8)
+    obs = env.reset_envs(torch.from_numpy(mask).cuda()).cpu().numpy()
+    env.wait_refills()
+    for e in (0, 2):
+        o2 = orcs[e].reset(oracle.new_episode(N, *streams[e], use_random_direction=True))
+        d = (o2 != obs[e]).any(-1)
+        assert (d & (orcs[e].last_amb == 0)).sum() == 0
+    _assert_state_equal(env, orcs, "after masked reset")
+    for k in range(25):
+        a = random_actions(rng, B, N, 0.2)
+        obs, rew, _, _ = env.step(torch.from_numpy(a).cuda())
+        rw = rew.cpu().numpy()
+        for e, o in enumerate(orcs):
+            _, r, _, _ = o.step(a[e], render=(k == 24))
+            assert np.array_equal(r, rw[e]), f"step {k} env {e}"
+    _assert_state_equal(env, orcs, "25 steps after masked reset"); _assert_pixels(obs.cpu().numpy(), orcs)
+    env.close()
+
+
 def test_device_sincos_bit_exact_with_host_spec(torch_cuda, lib):
     torch = torch_cuda
     env = _make(1, 1, 0)
