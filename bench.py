@@ -66,8 +66,9 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--agents", type=int, default=2)
     ap.add_argument("--obs", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=1, help="1: single stream (default); 2: experimental dynamics||raster overlap on CU-masked streams")
+    ap.add_argument("--streams", type=int, default=2, help="2 (default): contact side stream (envs in car<->car contact run their chain concurrently); 1: single stream")
     ap.add_argument("--stagger", type=int, default=1, help="1: spread the TimeLimit phases of the envs uniformly before timing (steady state); 0: all envs expire in the same step")
+    ap.add_argument("--debug-bits", type=int, default=0, help="mcr_debug_set value for timing experiments (results are WRONG when non-zero)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event time all three kernels (adds overhead)")
     args = ap.parse_args()
@@ -96,11 +97,12 @@ def main():
     pool[..., 0] = pool[..., 0] * 2 - 1
     # Steady state before anything is timed: a real rollout has its episodes ending at different steps, not all
     # B TimeLimits expiring in the same step (which would put B host track generations into one burst).  One
-    # un-timed TimeLimit period in which env e is reset at step e*L/B leaves the episode phases uniformly spread;
+    # un-timed TimeLimit period in which every env is reset once, at a step drawn without replacement, leaves the
+    # episode phases uniformly spread (and not correlated with the env index);
     # the timed region then sees the same number of resets (B per L steps), each with its host-side generation.
     if args.stagger:
         L = 1000
-        ids = torch.arange(B, device=dev)
+        ids = torch.randperm(B, device=dev, generator=g)      # which env gets which phase: random, as in a real rollout
         for j in range(L):
             env.step(pool[j % 64])
             msk = ((ids * L) // B == j).to(torch.uint8)
@@ -109,7 +111,10 @@ def main():
     for k in range(W):
         env.step(pool[k % 64])
     env.wait_refills()
-    env.timing(31 if args.time_all_kernels else 4)
+    if args.debug_bits:
+        from multi_car_racing_amd import _lib as _L
+        _L.check(env.env.L.mcr_debug_set(env.env.h, args.debug_bits))
+    env.timing(255 if args.time_all_kernels else 4)
     gen0 = env.env.episodes_generated
     torch.cuda.synchronize()
     if world > 1:
@@ -170,7 +175,8 @@ def main():
         }
         if args.time_all_kernels:
             out["kernel_ms"] = {"collide": ms[0] / max(nl[0], 1), "dynamics": ms[1] / max(nl[1], 1), "view": ms[2] / max(nl[2], 1),
-                                "collide_reset_pass": ms[3] / max(nl[3], 1), "dynamics_reset_pass": ms[4] / max(nl[4], 1)}
+                                "collide_reset_pass": ms[3] / max(nl[3], 1), "dynamics_reset_pass": ms[4] / max(nl[4], 1),
+                                "side_dynamics": ms[5] / max(nl[5], 1), "side_view": ms[6] / max(nl[6], 1), "side_reset_pass_kernel": ms[7] / max(nl[7], 1)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, bool(args.obs))
         print(json.dumps(out))

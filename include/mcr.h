@@ -45,7 +45,7 @@ typedef struct mcr_config {
   int32_t use_ego_color;     /* :160 */
   int32_t car_contacts;      /* 1: car<->car rigid contacts (Box2D default); 0: ghost cars (debug) */
   int32_t max_episode_steps; /* gym TimeLimit from __init__.py:8 (1000); 0 disables */
-  int32_t num_streams;       /* 0/1 (default): every kernel on the caller's stream; 2: experimental dynamics||raster overlap on CU-masked streams */
+  int32_t num_streams;       /* 0/1: every kernel on the caller's stream; 2: envs holding a touching car<->car pair run their (2-3x longer) dynamics chain + raster on an internal side stream, concurrently with the others */
   double h_ratio;            /* :159 */
 } mcr_config;
 
@@ -120,8 +120,8 @@ void mcr_sincos_host(float a, float* s, float* c);
 int mcr_sincos_device(mcr_env* h, const float* d_in, float* d_sin, float* d_cos, int n, void* stream);
 
 /* ---- instrumentation for bench.py: HIP-event timing of the kernels enqueued by mcr_step, recorded on the
- * launch stream.  `mask` bit k enables kernel id k (0 collide, 1 dynamics, 2 view, 3/4 = collide/dynamics of
- * the auto-reset pass; 31 = all, 0 = off).
+ * launch stream.  `mask` bit k enables timing slot k: 0 collide, 1 dynamics, 2 view, 3/4 = collide/dynamics of
+ * the auto-reset pass, 5/6 = dynamics/view of the contact side stream, 7 = its reset pass (255 = all, 0 = off).
  * mcr_timing_read synchronises the device and drains accumulated milliseconds + launch counts. */
 int mcr_timing_enable(mcr_env* h, int mask);
 /* profiling ablations of the raster kernel (bit 0 skip flags block, 1 skip road shading, 2 skip cars, 3 skip
@@ -129,7 +129,12 @@ int mcr_timing_enable(mcr_env* h, int mask);
 int mcr_debug_set(mcr_env* h, int value);
 /* debug bit 5 (32): the raster kernel stamps s_memtime per phase; read the 64-float tail of a view's scratch */
 int mcr_debug_read_view_scratch(mcr_env* h, int view, void* out, int nbytes);
-int mcr_timing_read(mcr_env* h, double* ms_out /*[5]*/, int64_t* launches_out /*[5]*/);
+/* debug bit 8 (256): k_dynamics stamps the clock per phase, [2 roles][blocks][8]; read n_u64 words of it */
+int mcr_debug_read_dynamics_stamps(mcr_env* h, uint64_t* out, int n_u64);
+/* number of touching car<->car fixture pairs (stored manifolds) per env after the last collide pass */
+int mcr_debug_read_contact_counts(mcr_env* h, int32_t* out /*[num_envs]*/);
+#define MCR_TIMING_SLOTS 8
+int mcr_timing_read(mcr_env* h, double* ms_out /*[MCR_TIMING_SLOTS]*/, int64_t* launches_out /*[MCR_TIMING_SLOTS]*/);
 
 #ifdef __cplusplus
 }

@@ -82,7 +82,10 @@ __device__ __forceinline__ bool overlap(const float* avx, const float* avy, cons
 // pass 0: every active env.  pass 1: only envs with `resetting` set (their per-tile state is cleared first).
 __global__ __launch_bounds__(64) void k_collide(McrParams p, int pass) {
   using namespace col;
-  const int env = p.env0 + blockIdx.x, lane = threadIdx.x;
+  const int env = mcr_env_of_slot(p, blockIdx.x), lane = threadIdx.x;
+  if (pass == 0 && blockIdx.x == 0 && lane == 0) { p.vcount[0] = 0; p.vcount[1] = 0; }     // refilled by k_dynamics
+  if (env >= p.env0 + p.nenv) return;
+  if (pass == 0 && p.split && lane == 0) p.part[env] = 0;
   const McrEnvState es = p.env[env];
   if (!es.active) return;
   if (pass == 1 && !es.resetting) return;
@@ -243,6 +246,7 @@ __global__ __launch_bounds__(64) void k_collide(McrParams p, int pass) {
     for (int a = 0; a < N - 1; ++a) for (int b = a + 1; b < N; ++b)
       any_pair = any_pair || !(cbox[a][0] > cbox[b][2] || cbox[a][2] < cbox[b][0] || cbox[a][1] > cbox[b][3] || cbox[a][3] < cbox[b][1]);
   }
+  int nn_final = 0;                                            // touching car<->car pairs of this env (wave-uniform)
   if (p.car_contacts && N > 1 && !any_pair) {
     if (lane == 0) { store[0] = 0; store[1] = 0; }
   } else if (p.car_contacts && N > 1) {
@@ -305,5 +309,8 @@ __global__ __launch_bounds__(64) void k_collide(McrParams p, int pass) {
     const int nn = base < MCR_CC_MAX ? base : MCR_CC_MAX;
     for (int i = lane; i < nn * 16; i += 64) store[4 + (i >> 4) * MCR_CC_WORDS + (i & 15)] = newrec[i >> 4][i & 15];
     if (lane == 0) { store[0] = (uint32_t)nn; store[1] = base > MCR_CC_MAX ? 1u : 0u; }
+    nn_final = nn;
   } else if (lane == 0 && pass == 1) store[0] = 0;
+  // side-stream partition: envs whose dynamics chain is going to be long (a touching car<->car pair)
+  if (pass == 0 && p.split && lane == 0 && nn_final > 0) { p.part[env] = 1; p.clist[1 + atomicAdd(&p.clist[0], 1)] = env; }
 }

@@ -385,15 +385,19 @@ __device__ inline float cc_position(const McrShapes& S, const uint32_t* rec, int
 
 // mode 0: regular step (bookkeeping, TimeLimit, auto-reset install)
 // mode 1: the action-less step of reset() (:408) for envs whose `resetting` flag is set
+// debug bit 8 (256): lane 0 of every wavefront stamps the clock per phase (0 start, 1 state loaded + Car.step +
+// velocity integration, 2 velocity sweeps done, 3 position loop done, 4 end) into p.dbg_stamps[role==2][block][8]
+#define DYN_STAMP(i) do { if ((p.debug & 256) && mode == 0 && threadIdx.x == 0) p.dbg_stamps[((p.role == 2 ? gridDim.x : 0) + blockIdx.x) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
   using namespace dyn;
+  DYN_STAMP(0);
   // LDS used only by waves that contain a touching car<->car pair
   __shared__ float xv[15][64], xp[15][64];            // body exchange: (vx,vy,w) / (cx,cy,a) x 5 bodies per lane
   __shared__ __attribute__((aligned(16))) float vcpool[DYN_VC_POOL][cc::VC_SIZE];
   __shared__ int xisl[64], xact[64], xjok[64], xcok[64];
   __shared__ float xms[64];
   const int g = blockIdx.x * 64 + threadIdx.x;
-  const int env = p.env0 + g / p.G, agent = g % p.G;
+  const int env = mcr_env_of_slot(p, g / p.G), agent = g % p.G;
   const int env_end = p.env0 + p.nenv;
   const bool lane_ok = env < env_end && agent < p.N;
   const int ci = lane_ok ? env * p.N + agent : 0;
@@ -512,6 +516,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
   int ccn = 0;
   if (run && p.car_contacts && p.N > 1) ccn = (int)store[0];
   const bool wave_cc = __any(ccn > 0) != 0;
+  DYN_STAMP(1);
   int pool_base = 0;
   int isl = agent;                        // island id of this car = lowest car id linked to it by touching contacts
   if (wave_cc) {
@@ -609,7 +614,8 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
       }
     }
   } else {
-    for (int it = 0; it < 180; ++it) {
+    const int vel_iters = (p.debug & 128) ? 2 : 180;          // debug bit 7: timing experiments only
+    for (int it = 0; it < vel_iters; ++it) {
       if (run) {
 #pragma unroll
         for (int q = 3; q >= 0; --q) joint_velocity(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);
@@ -635,6 +641,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
       for (int j = 0; j < n; ++j) { const float* q = vc + (j == 0 ? cc::VC_P0 : cc::VC_P1); rec[6 + j * 5 + 2] = __float_as_uint(q[4]); rec[6 + j * 5 + 3] = __float_as_uint(q[5]); }
     }
   }
+  DYN_STAMP(2);
   if (run) {
     // integrate positions
 #pragma unroll
@@ -654,6 +661,9 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
     if (run) {
       const int pos_iters = (p.debug & 64) ? 2 : 60;          // debug bit 6: cap the position iterations (timing experiments only)
       for (int it = 0; it < pos_iters; ++it) {
+        float ox[5], oy[5], oa[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { ox[k] = b[k].cx; oy[k] = b[k].cy; oa[k] = b[k].a; }
         bool ok = true;
 #pragma unroll
         for (int q = 3; q >= 0; --q) {
@@ -661,13 +671,24 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
           ok = ok && jo;
         }
         if (ok) { positionSolved = true; break; }
+        // A sweep is a pure function of the 15 position values.  One that fails AND moves nothing (the marginal
+        // case: an error one ulp above its slop whose correction rounds away) would repeat identically up to
+        // iteration 60 — stop here with the same outcome (positionSolved stays false, positions as they are).
+        bool moved = false;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) moved = moved || ox[k] != b[k].cx || oy[k] != b[k].cy || oa[k] != b[k].a;
+        if (!moved) break;
       }
     }
   } else {
     bool active = run;
-    for (int it = 0; it < 60; ++it) {
+    const int pos_iters_cc = (p.debug & 64) ? 2 : 60;
+    for (int it = 0; it < pos_iters_cc; ++it) {
       if (!__any(active)) break;
       const bool in_cc = active && ccn > 0;
+      float ox[5], oy[5], oa[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) { ox[k] = b[k].cx; oy[k] = b[k].cy; oa[k] = b[k].a; }
       if (in_cc) {
 #pragma unroll
         for (int k = 0; k < 5; ++k) { xp[0 * 5 + k][lane] = b[k].cx; xp[1 * 5 + k][lane] = b[k].cy; xp[2 * 5 + k][lane] = b[k].a; }
@@ -704,19 +725,26 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
           jointsOk = jointsOk && jo;
         }
       }
-      xjok[lane] = jointsOk ? 1 : 0;
+      // fixed point: an island whose sweep failed without moving any of its bodies would repeat that sweep
+      // identically up to iteration 60 — it stops here with the same outcome (see the contact-free loop above)
+      bool moved = false;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) moved = moved || ox[k] != b[k].cx || oy[k] != b[k].cy || oa[k] != b[k].a;
+      xjok[lane] = (jointsOk ? 1 : 0) | (moved ? 2 : 0);
       __syncthreads();
       if (active) {
-        bool ok = jointsOk;
+        bool ok = jointsOk, mv = moved;
         if (ccn > 0) {
           ok = xcok[leader_lane + isl] != 0;
-          for (int c = 0; c < p.N; ++c) if (xisl[leader_lane + c] == isl) ok = ok && (xjok[leader_lane + c] != 0);
+          for (int c = 0; c < p.N; ++c) if (xisl[leader_lane + c] == isl) { ok = ok && ((xjok[leader_lane + c] & 1) != 0); mv = mv || ((xjok[leader_lane + c] & 2) != 0); }
         }
         if (ok) { positionSolved = true; active = false; }
+        else if (!mv) active = false;
       }
       __syncthreads();
     }
   }
+  DYN_STAMP(3);
   float minSleep = MCR_MAXFLT;
   if (run) {
     // sleep (b2Island::Solve tail).  Car.step re-wakes every body next step, so "asleep" reduces to:
@@ -789,6 +817,13 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
         if (p.actions) E->steps = es.steps + 1;
         E->just_reset = 0;
         if (done && p.auto_reset) E->active = 0;      // no staged episode: freeze until mcr_reset
+      }
+      // raster launch order: zoomed-out frames (first second of an episode, :540-542) cost several times a normal
+      // one, so their workgroups go FIRST (front of vorder) and cannot end up as the launch's tail
+      if (p.role != 2 && (respawn || !(done && p.auto_reset))) {
+        const bool heavy = respawn || es.t + 1.0 / MCR_FPS < 1.0;
+        if (heavy) p.vorder[atomicAdd(&p.vcount[0], 1)] = env;
+        else p.vorder[p.B - 1 - atomicAdd(&p.vcount[1], 1)] = env;
       }
     } else {
       E->t = es.t + 1.0 / MCR_FPS;
@@ -918,24 +953,15 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
     }
   }
   }   // run
+  DYN_STAMP(4);
 
-  // ---- publish: when the raster kernel runs concurrently (disjoint CUs) it gates each view on ready[env].
-  // Plain stores above -> wave barrier -> ONE agent-scope release -> relaxed agent-scope flag stores
-  // (cdna_hip_programming.md G16).  A re-spawned env is published by the reset pass (mode 1) instead.
-  if (p.wait_ready) {
-    __syncthreads();
-    if (threadIdx.x == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    __syncthreads();
-    const bool publish = lane_ok && agent == 0 && ((mode == 0 && !respawn) || (mode == 1 && es.active && es.resetting));
-    if (publish) __hip_atomic_store(&p.ready[env], p.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
 }
 
 // Explicit reset(): install the staged episode for masked envs and spawn the cars; the caller then
 // runs collide(pass 1) -> dynamics(mode 1) -> view to complete `return self.step(None)[0]` (:408).
 __global__ __launch_bounds__(64) void k_install(McrParams p) {
   const int g = blockIdx.x * 64 + threadIdx.x;
-  const int env = p.env0 + g / p.G, agent = g % p.G;
+  const int env = mcr_env_of_slot(p, g / p.G), agent = g % p.G;
   if (env >= p.env0 + p.nenv || agent >= p.N) return;
   if (p.reset_mask && !p.reset_mask[env]) return;
   McrEnvState es = p.env[env];

@@ -107,13 +107,6 @@ __device__ __forceinline__ bool box_may_touch(const float* e, int n, float X0, f
   return !out;
 }
 #define UNI(x) __builtin_amdgcn_readfirstlane(x)
-// Loads of data that k_dynamics / the reset-pass collide may have produced CONCURRENTLY with this kernel (overlap
-// mode): agent-scope relaxed atomic loads compile to `global_load ... sc1`, which bypass this CU's vector L1, so
-// no per-workgroup L1 invalidate (agent acquire, ~2-7 us each at this occupancy) is needed after the ready poll.
-__device__ __forceinline__ uint32_t ld_u32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int32_t ld_i32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_f32(const float* p) { return __uint_as_float(__hip_atomic_load((const uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
-__device__ __forceinline__ double ld_f64(const double* p) { return __longlong_as_double(__hip_atomic_load((const long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
 // per-phase s_memtime stamps of thread 0 (debug bit 32) into the tail of the view's spill area
 #define PHASE_STAMP(i) do { if ((dbg & 32) && tid == 0) ((unsigned long long*)(spill + VIEW_SCRATCH_FLOATS - 64))[i] = __builtin_readcyclecounter(); } while (0)
 
@@ -157,30 +150,28 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
   // XCD-aware mapping: workgroup b runs on XCD b % 8, so hand the N views of one env to workgroups b, b+8,
   // b+16, ... — they share that XCD's L2 for the env's road_poly instead of fetching it once per XCD.
   int vw;
-  {
+  if (p.role == 2) {                 // side stream: views of the envs in clist
+    const int s = blockIdx.x / N;
+    if (s >= p.clist[0]) return;
+    vw = p.clist[1 + s] * N + (int)(blockIdx.x % N);
+  } else if (p.use_vorder) {         // step path: heavy (zoomed-out) envs first, see k_dynamics
+    const int b = blockIdx.x, grp = b / (8 * N), r = b - grp * 8 * N;
+    const int idx = grp * 8 + (r & 7), nh = p.vcount[0], nn = p.vcount[1];
+    if (idx >= nh + nn) return;
+    vw = p.vorder[idx < nh ? idx : p.B - 1 - (idx - nh)] * N + (r >> 3);
+  } else {
     const int b = blockIdx.x, full = (p.nenv / 8) * 8 * N;
     if (b < full) { const int grp = b / (8 * N), r = b - grp * 8 * N; vw = (p.env0 + grp * 8 + (r & 7)) * N + (r >> 3); }
     else vw = p.env0 * N + b;
+    if (vw >= (p.env0 + p.nenv) * N) return;     // grids are rounded up to whole groups of 8 envs
   }
   const int env = vw / N, agent = vw % N;
-  if (p.wait_ready) {
-    // Overlapped with k_dynamics: wait until this env's post-step state has been published.  One lane polls one
-    // word (relaxed, agent scope), ONE acquire drops this CU's stale lines, then the workgroup reads plainly.
-    if (tid == 0) {
-      const uint32_t want = p.serial;
-      int spins = 0;
-      while (__hip_atomic_load(&p.ready[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want && spins < (1 << 20)) { __builtin_amdgcn_s_sleep(16); ++spins; }
-    }
-    __syncthreads();
-  }
-  McrEnvState es;
-  {
-    const McrEnvState* E = &p.env[env];
-    es.t = ld_f64(&E->t); es.steps = ld_i32(&E->steps); es.slot = ld_i32(&E->slot); es.staged_ready = 0; es.consumed = 0;
-    es.active = ld_i32(&E->active); es.resetting = 0; es.just_reset = ld_i32(&E->just_reset);
-  }
+  if (p.role == 1 && p.part[env]) return;
+  const McrEnvState es = p.env[env];
   if (!es.active) return;
   if (only_just_reset && !es.just_reset) return;
+  // side-stream raster: a contact env re-spawned by this step's dynamics is drawn after its (late) reset pass
+  if (p.role == 2 && !only_just_reset && es.resetting) return;
   const uint8_t* __restrict__ slot = p.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES;
   const McrSlotHeader* H = (const McrSlotHeader*)slot;
   const int T = H->T, P = H->P;
@@ -205,18 +196,18 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
   if (tid == 0) { nsurv = 0; ncand = 0; any_inside = 0; }
   if (tid < 32) pal[tid] = palette_rgb(tid);
   if (tid < NBINS) bcnt[tid] = 0;
-  if (p.obs != nullptr && tid >= 64 && tid < 64 + 29) hud[tid - 64] = ld_f32(&p.viewp[(size_t)(vw) * MCR_VIEWP_FLOATS + VP_IND + (tid - 64)]);
-  const uint32_t old_flags = ld_u32(&p.caru[CU_FLAGS * BN + ci]);
-  const float hvx = ld_f32(&p.carf[(CF_VX + 0) * BN + ci]), hvy = ld_f32(&p.carf[(CF_VY + 0) * BN + ci]), ha = ld_f32(&p.carf[(CF_A + 0) * BN + ci]);
+  if (p.obs != nullptr && tid >= 64 && tid < 64 + 29) hud[tid - 64] = p.viewp[(size_t)vw * MCR_VIEWP_FLOATS + VP_IND + (tid - 64)];
+  const uint32_t old_flags = p.caru[CU_FLAGS * BN + ci];
+  const float hvx = p.carf[(CF_VX + 0) * BN + ci], hvy = p.carf[(CF_VY + 0) * BN + ci], ha = p.carf[(CF_A + 0) * BN + ci];
   const bool draw = p.obs != nullptr;
   const bool do_flags = flags_mode && !es.just_reset && !(dbg & 1);      // reset() -> step(None) skips the block (:435)
   const float* __restrict__ vp = p.viewp + (size_t)ci * MCR_VIEWP_FLOATS;
   float m00 = 0, m01 = 0, m10 = 0, m11 = 0, ctx = 0, cty = 0;
-  if (draw) { m00 = ld_f32(vp + VP_CAM + 0); m01 = ld_f32(vp + VP_CAM + 1); m10 = ld_f32(vp + VP_CAM + 2); m11 = ld_f32(vp + VP_CAM + 3); ctx = ld_f32(vp + VP_CAM + 4); cty = ld_f32(vp + VP_CAM + 5); }
+  if (draw) { m00 = vp[VP_CAM + 0]; m01 = vp[VP_CAM + 1]; m10 = vp[VP_CAM + 2]; m11 = vp[VP_CAM + 3]; ctx = vp[VP_CAM + 4]; cty = vp[VP_CAM + 5]; }
   float* __restrict__ spill = scratch + (size_t)vw * VIEW_SCRATCH_FLOATS;
   // hull.position (body origin) for the bookkeeping block
   float fpx = 0.0f, fpy = 0.0f;
-  if (do_flags) { const Xf hxf = xf_of(v2(ld_f32(&p.carf[(CF_CX + 0) * BN + ci]), ld_f32(&p.carf[(CF_CY + 0) * BN + ci])), ha, v2(S.hull_lcx, S.hull_lcy)); fpx = hxf.p.x; fpy = hxf.p.y; }
+  if (do_flags) { const Xf hxf = xf_of(v2(p.carf[(CF_CX + 0) * BN + ci], p.carf[(CF_CY + 0) * BN + ci]), ha, v2(S.hull_lcx, S.hull_lcy)); fpx = hxf.p.x; fpy = hxf.p.y; }
   const double dpx = (double)fpx, dpy = (double)fpy;
   PHASE_STAMP(0);
   __syncthreads();
@@ -282,12 +273,8 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
     const float* __restrict__ cp = p.carpoly + (size_t)(env * N + c) * MCR_CARPOLY_FLOATS;
     // one burst: 8 vertices (4 x float4) + the vertex count, all issued before anything is consumed
     const float* cv = cp + j * 16;
-    float4 v01, v23, v45, v67;
-    v01.x = ld_f32(cv + 0); v01.y = ld_f32(cv + 1); v01.z = ld_f32(cv + 2); v01.w = ld_f32(cv + 3);
-    v23.x = ld_f32(cv + 4); v23.y = ld_f32(cv + 5); v23.z = ld_f32(cv + 6); v23.w = ld_f32(cv + 7);
-    v45.x = ld_f32(cv + 8); v45.y = ld_f32(cv + 9); v45.z = ld_f32(cv + 10); v45.w = ld_f32(cv + 11);
-    v67.x = ld_f32(cv + 12); v67.y = ld_f32(cv + 13); v67.z = ld_f32(cv + 14); v67.w = ld_f32(cv + 15);
-    const int n = __float_as_int(ld_f32(cp + MCR_CARPOLY_NOFF + j));
+    const float4 v01 = ((const float4*)cv)[0], v23 = ((const float4*)cv)[1], v45 = ((const float4*)cv)[2], v67 = ((const float4*)cv)[3];
+    const int n = __float_as_int(cp[MCR_CARPOLY_NOFF + j]);
     uint32_t info = 0;
     if (n > 0 && !(dbg & 4)) {
       uint32_t colr;
@@ -366,7 +353,7 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
       const uint32_t meta = QM[q];
       uint32_t col = meta & 0xffu; const uint32_t tile1 = (meta >> 8) & 0x3ffu;
       if (tile1) {                                                              // touched tile -> ROAD_COLOR (:102-104)
-        const uint32_t w = ld_u32((const uint32_t*)tflags + ((tile1 - 1) >> 1));
+        const uint32_t w = ((const uint32_t*)tflags)[(tile1 - 1) >> 1];
         if ((w >> (((tile1 - 1) & 1u) * 16u)) & 0x100u) col = MCR_COL_ROAD0;
       }
       // draw-order key: quad index above the 5-bit palette index, so "highest key wins" also carries the colour
@@ -464,8 +451,8 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
     // background in "checker units": U = world.x / (2k), V = world.y / (2k) with k = PLAYFIELD/20;
     // playfield <=> |U|,|V| <= 10; light square <=> frac(U) < .5 and frac(V) < .5 (:615-627)
     const float hk = 0.5f / (float)(MCR_PLAYFIELD / 20.0);
-    const float aU = ld_f32(vp + VP_INV + 0) * hk, bU = ld_f32(vp + VP_INV + 1) * hk, cU = ld_f32(vp + VP_INV + 2) * hk;
-    const float aV = ld_f32(vp + VP_INV + 3) * hk, bV = ld_f32(vp + VP_INV + 4) * hk, cV = ld_f32(vp + VP_INV + 5) * hk;
+    const float aU = vp[VP_INV + 0] * hk, bU = vp[VP_INV + 1] * hk, cU = vp[VP_INV + 2] * hk;
+    const float aV = vp[VP_INV + 3] * hk, bV = vp[VP_INV + 4] * hk, cV = vp[VP_INV + 5] * hk;
     const float U_lane = aU * flx + bU * fly + cU, V_lane = aV * flx + bV * fly + cV;
     const float dU8 = 8.0f * bU, dV8 = 8.0f * bV;
     const int fb_lane = (95 - ly) * 96 + lx;

@@ -39,12 +39,11 @@ struct mcr_env {
   int timing;                 // bit mask of kernel ids to time with HIP events
   std::vector<TimedLaunch> pending;
   std::vector<hipEvent_t> free_events;
-  double t_ms[5]; int64_t t_n[5];
+  double t_ms[MCR_TIMING_SLOTS]; int64_t t_n[MCR_TIMING_SLOTS];
   bool any_reset;
-  bool overlap;               // dynamics (latency bound, 128 waves) and raster (throughput bound) on disjoint CU sets
-  hipStream_t s_phys, s_view; // CU-masked internal streams
-  hipEvent_t ev_collide, ev_phys, ev_view;
-  uint32_t serial;
+  bool split;                 // contact side stream enabled (cfg.num_streams == 2)
+  hipStream_t s_side;         // internal stream of the contact envs' chain
+  hipEvent_t ev_fork, ev_join;
   float* view_scratch;        // per-view spill area of the rasteriser (zoomed-out frames only)
 };
 
@@ -56,7 +55,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   HIPCHK(hipSetDevice(cfg->device));
   mcr_env* h = new mcr_env();
   h->cfg = *cfg; h->timing = 0; h->any_reset = false;
-  for (int i = 0; i < 5; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
+  for (int i = 0; i < MCR_TIMING_SLOTS; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
   const int B = cfg->num_envs, N = cfg->num_agents;
   int G = 1; while (G < N) G <<= 1;
   const size_t BN = (size_t)B * N;
@@ -69,7 +68,10 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   const size_t o_touch = carve(sizeof(uint32_t) * MCR_TILE_CAP * (size_t)B);
   const size_t o_tflags = carve(sizeof(uint16_t) * MCR_TILE_CAP * (size_t)B);
   const size_t o_cc = carve(sizeof(uint32_t) * (size_t)B * (MCR_CC_MAX * MCR_CC_WORDS + 4));
-  const size_t o_ready = carve(sizeof(uint32_t) * B);
+  const size_t o_part = carve(B);
+  const size_t o_vorder = carve(sizeof(int32_t) * ((size_t)B + 2));
+  const size_t o_stamps = carve(sizeof(unsigned long long) * 2 * 8 * (((size_t)B * G + 63) / 64));
+  const size_t o_clist = carve(sizeof(int32_t) * ((size_t)B + 1));
   const size_t o_shapes = carve(sizeof(McrShapes));
   const size_t o_viewp = carve(sizeof(float) * MCR_VIEWP_FLOATS * BN);
   const size_t o_carpoly = carve(sizeof(float) * MCR_CARPOLY_FLOATS * BN);
@@ -87,7 +89,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   P.cc_store = (uint32_t*)(base + o_cc); P.shapes = (const McrShapes*)(base + o_shapes); P.slots = base + o_slots;
   h->view_scratch = (float*)(base + o_vscratch);
   P.viewp = (float*)(base + o_viewp);
-  P.ready = (uint32_t*)(base + o_ready);
+  P.part = base + o_part; P.vcount = (int32_t*)(base + o_vorder); P.vorder = P.vcount + 2; P.dbg_stamps = (unsigned long long*)(base + o_stamps); P.clist = (int32_t*)(base + o_clist);
   P.carpoly = (float*)(base + o_carpoly);
   P.auto_reset = cfg->auto_reset; P.max_steps = cfg->max_episode_steps; P.car_contacts = cfg->car_contacts;
   P.backwards_flag = cfg->backwards_flag; P.use_ego_color = cfg->use_ego_color; P.h_ratio = cfg->h_ratio;
@@ -99,28 +101,21 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   (void)hipHostGetDevicePointer(&dptr, h->consumed_host, 0);
   P.consumed_host = (int32_t*)dptr;
   h->consumed_seen = new int32_t[B]();
-  // Kernel-level overlap.  k_dynamics is a long serial dependency chain on B*N/64 wavefronts (1 per SIMD on 32
-  // CUs) whose duration is set by its slowest lane, k_view is throughput bound: give them disjoint CU sets
-  // (CU-masked streams) and let every view start as soon as its own env has been published (ready[env]).
-  // Disjoint CU sets make the wait deadlock-free: the raster can never occupy the CUs the physics needs.
-  P.env0 = 0; P.nenv = B; P.wait_ready = 0; P.serial = 0;
-  h->serial = 0; h->overlap = false;
-  if (cfg->num_streams == 2 && cfg->obs_enabled) {
-    int ncu = 0; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device);
-    const int phys_cus = 32;
-    if (ncu >= 128) {
-      uint32_t mphys[16] = {0}, mview[16] = {0};
-      for (int c = 0; c < ncu && c < 512; ++c) { if (c < phys_cus) mphys[c >> 5] |= 1u << (c & 31); else mview[c >> 5] |= 1u << (c & 31); }
-      const uint32_t words = (uint32_t)((ncu + 31) / 32);
-      if (hipExtStreamCreateWithCUMask(&h->s_phys, words, mphys) == hipSuccess) {
-        if (hipExtStreamCreateWithCUMask(&h->s_view, words, mview) == hipSuccess) {
-          (void)hipEventCreateWithFlags(&h->ev_collide, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_phys, hipEventDisableTiming);
-          (void)hipEventCreateWithFlags(&h->ev_view, hipEventDisableTiming);
-          h->overlap = true;
-        } else (void)hipStreamDestroy(h->s_phys);
-      }
-      (void)hipGetLastError();
+  // Contact side stream.  k_dynamics is a serial dependency chain whose duration is set by its slowest wavefront,
+  // and a wavefront holding a touching car<->car pair takes 2-3x as long as the others (sequential Gauss-Seidel
+  // over the contacts).  With num_streams == 2 those envs (a handful per step) run dynamics -> reset pass ->
+  // raster on an internal stream, concurrently with the same chain of all the other envs on the caller's stream;
+  // the two event hops are off the critical path because the side chain is the shorter one.
+  P.env0 = 0; P.nenv = B; P.split = 0; P.role = 0;
+  h->split = false;
+  if (cfg->num_streams == 2) {
+    // highest priority: its few workgroups must not queue behind the main stream's saturating raster launch
+    int prio_lo = 0, prio_hi = 0; (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&h->s_side, hipStreamNonBlocking, prio_hi) == hipSuccess) {
+      (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
+      h->split = true;
     }
+    (void)hipGetLastError();
   }
   (void)hipDeviceSynchronize();
   *out = h;
@@ -133,7 +128,7 @@ extern "C" int mcr_destroy(mcr_env* h) {
   (void)hipDeviceSynchronize();
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : h->free_events) (void)hipEventDestroy(e);
-  if (h->overlap) { (void)hipStreamDestroy(h->s_phys); (void)hipStreamDestroy(h->s_view); (void)hipEventDestroy(h->ev_collide); (void)hipEventDestroy(h->ev_phys); (void)hipEventDestroy(h->ev_view); }
+  if (h->split) { (void)hipStreamDestroy(h->s_side); (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); }
   (void)hipFree(h->slab);
   (void)hipHostFree(h->consumed_host);
   delete[] h->consumed_seen;
@@ -176,43 +171,53 @@ static hipEvent_t get_event(mcr_env* h) {
 // reset(): install -> collide(1) -> dynamics(1) -> view, in order on one stream
 static void launch_reset(mcr_env* h, McrParams P, hipStream_t st) {
   const int B = P.B, N = P.N;
-  // (in overlap mode every step already joined s_phys/s_view into st, so st is ordered after them; the next
-  // step's physics waits for ev_collide recorded on st after this reset)
   const int dyn_blocks = (B * P.G + 63) / 64;
-  P.wait_ready = 0;
+  P.split = 0; P.role = 0; P.use_vorder = 0;
   hipLaunchKernelGGL(k_install, dim3(dyn_blocks), dim3(64), 0, st, P);
   LAUNCH(3, k_collide, B, 64, st, P, 1);
   LAUNCH(4, k_dynamics, dyn_blocks, 64, st, P, 1);
   if (P.obs) LAUNCH_LDS(2, k_view, B * N, VIEW_THREADS, (size_t)N * 12 * 6 * 16, st, P, h->view_scratch, 0, 1);
 }
 
-// step(): collide -> dynamics [-> auto-reset pass] -> view, all on the caller's stream by default.
-// Optional overlap (cfg.num_streams == 2): the dynamics chain (latency bound, B*N/64 wavefronts) and the raster
-// (throughput bound) run concurrently on CU-masked internal streams with disjoint CU sets; each view is gated IN
-// THE KERNEL on its env's ready word, so the spin can never starve the physics of CUs.  MEASURED on MI355X /
-// ROCm 7.0 runtime: every cross-stream event hop costs ~60-70 us here, which eats the overlap (0.72 ms/step vs
-// 0.65 ms/step serial at B=4096,N=2) — so it stays off until launches are replayed from a hipGraph.
+// step(): collide -> dynamics [-> auto-reset pass] -> view on the caller's stream `st`.
+// With the contact side stream, the envs that k_collide found in car<->car contact run dynamics -> view on
+// h->s_side concurrently with the chain of all the others on `st` (grids are sized for the worst case, surplus
+// workgroups exit on their first load).  A contact env that ended its episode in this very step (rare) is finished
+// on `st` after the join: its reset pass + first frame, three launches that exit at once in every other step.
 static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags) {
   const int B = P.B, N = P.N;
   const int dyn_blocks = (B * P.G + 63) / 64;
-  const bool ov = h->overlap && P.obs != nullptr;
-  P.serial = ++h->serial; P.wait_ready = ov ? 1 : 0;
+  const size_t view_lds = (size_t)N * 12 * 6 * 16;
+  const bool draw = P.obs || view_flags;
+  P.role = 0; P.split = h->split ? 1 : 0;
+  if (h->split) (void)hipMemsetAsync(P.clist, 0, sizeof(int32_t), st);
   LAUNCH(0, k_collide, B, 64, st, P, 0);
-  hipStream_t sp = st, sv = st;
-  if (ov) {
-    sp = h->s_phys; sv = h->s_view;
-    (void)hipEventRecord(h->ev_collide, st);
-    (void)hipStreamWaitEvent(sp, h->ev_collide, 0); (void)hipStreamWaitEvent(sv, h->ev_collide, 0);
+  P.split = 0;
+  if (h->split) {
+    (void)hipEventRecord(h->ev_fork, st);
+    (void)hipStreamWaitEvent(h->s_side, h->ev_fork, 0);
+    P.role = 2;
+    LAUNCH(5, k_dynamics, dyn_blocks, 64, h->s_side, P, 0);
+    if (draw) LAUNCH_LDS(6, k_view, B * N, VIEW_THREADS, view_lds, h->s_side, P, h->view_scratch, view_flags, 0);
+    (void)hipEventRecord(h->ev_join, h->s_side);
+    P.role = 1;
   }
-  LAUNCH(1, k_dynamics, dyn_blocks, 64, sp, P, 0);
+  LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 0);
   if (P.auto_reset) {   // envs re-spawned by pass 0 take the action-less first step of their new episode (:408)
-    LAUNCH(3, k_collide, B, 64, sp, P, 1);
-    LAUNCH(4, k_dynamics, dyn_blocks, 64, sp, P, 1);
+    LAUNCH(3, k_collide, B, 64, st, P, 1);
+    LAUNCH(4, k_dynamics, dyn_blocks, 64, st, P, 1);
   }
-  if (P.obs || view_flags) LAUNCH_LDS(2, k_view, B * N, VIEW_THREADS, (size_t)N * 12 * 6 * 16, sv, P, h->view_scratch, view_flags, 0);
-  if (ov) {
-    (void)hipEventRecord(h->ev_phys, sp); (void)hipEventRecord(h->ev_view, sv);
-    (void)hipStreamWaitEvent(st, h->ev_phys, 0); (void)hipStreamWaitEvent(st, h->ev_view, 0);
+  P.use_vorder = 1;
+  if (draw) LAUNCH_LDS(2, k_view, (B + 7) / 8 * 8 * N, VIEW_THREADS, view_lds, st, P, h->view_scratch, view_flags, 0);
+  P.use_vorder = 0;
+  if (h->split) {
+    (void)hipStreamWaitEvent(st, h->ev_join, 0);
+    if (P.auto_reset) {
+      P.role = 2;
+      LAUNCH(7, k_collide, B, 64, st, P, 1);
+      LAUNCH(7, k_dynamics, dyn_blocks, 64, st, P, 1);
+      if (draw) LAUNCH_LDS(7, k_view, B * N, VIEW_THREADS, view_lds, st, P, h->view_scratch, view_flags, 1);
+    }
   }
 }
 
@@ -359,6 +364,19 @@ extern "C" int mcr_debug_read_view_scratch(mcr_env* h, int view, void* out, int 
   HIPCHK(hipMemcpy(out, h->view_scratch + (size_t)(view + 1) * VIEW_SCRATCH_FLOATS - 64, nbytes, hipMemcpyDeviceToHost));
   return MCR_OK;
 }
+extern "C" int mcr_debug_read_contact_counts(mcr_env* h, int32_t* out) {
+  if (!h || !out) return MCR_ERR_ARG;
+  HIPCHK(hipDeviceSynchronize());
+  const size_t stride = MCR_CC_MAX * MCR_CC_WORDS + 4;
+  HIPCHK(hipMemcpy2D(out, sizeof(int32_t), h->P.cc_store, stride * sizeof(uint32_t), sizeof(int32_t), h->cfg.num_envs, hipMemcpyDeviceToHost));
+  return MCR_OK;
+}
+extern "C" int mcr_debug_read_dynamics_stamps(mcr_env* h, uint64_t* out, int n_u64) {
+  if (!h || !out) return MCR_ERR_ARG;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out, h->P.dbg_stamps, sizeof(uint64_t) * (size_t)n_u64, hipMemcpyDeviceToHost));
+  return MCR_OK;
+}
 extern "C" int mcr_debug_set(mcr_env* h, int value) { if (!h) return MCR_ERR_ARG; h->P.debug = value; return MCR_OK; }
 extern "C" int mcr_timing_enable(mcr_env* h, int enable) { if (!h) return MCR_ERR_ARG; h->timing = enable; return MCR_OK; }
 extern "C" int mcr_timing_read(mcr_env* h, double* ms_out, int64_t* launches_out) {
@@ -370,6 +388,6 @@ extern "C" int mcr_timing_read(mcr_env* h, double* ms_out, int64_t* launches_out
     h->free_events.push_back(t.a); h->free_events.push_back(t.b);
   }
   h->pending.clear();
-  for (int i = 0; i < 5; ++i) { if (ms_out) ms_out[i] = h->t_ms[i]; if (launches_out) launches_out[i] = h->t_n[i]; h->t_ms[i] = 0; h->t_n[i] = 0; }
+  for (int i = 0; i < MCR_TIMING_SLOTS; ++i) { if (ms_out) ms_out[i] = h->t_ms[i]; if (launches_out) launches_out[i] = h->t_n[i]; h->t_ms[i] = 0; h->t_n[i] = 0; }
   return MCR_OK;
 }

@@ -18,9 +18,15 @@ struct McrParams {
   float* viewp;                 // [BN][MCR_VIEWP_FLOATS] per-car camera + HUD geometry, written by k_dynamics, read by k_view
   float* carpoly;               // [BN][MCR_CARPOLY_FLOATS] world-space vertices of the car's 12 draw polygons (Car.draw)
   int32_t* consumed_host;       // [B] mapped host memory: episode counter of the last install
-  uint32_t* ready;              // [B] step serial published by k_dynamics once the env's post-step state is in HBM
-  uint32_t serial;              // serial of this mcr_step call (k_view waits for ready[env] == serial when overlapped)
-  int32_t wait_ready;           // 1: k_view runs concurrently with k_dynamics on disjoint CUs and gates each view on ready[env]
+  // contact side stream (mcr_config.num_streams == 2): envs holding a touching car<->car pair run their (much
+  // longer) dynamics chain, reset pass and raster on a second stream, concurrently with everyone else's.
+  uint8_t* part;                // [B] 1: env belongs to the side stream this step (written by k_collide pass 0)
+  int32_t* clist;               // [1+B] count, then the env ids of the side-stream envs (any order)
+  int32_t split;                // k_collide pass 0 fills part/clist
+  int32_t* vorder;              // [B] raster order of the main launch: heavy envs from the front, the others from the back
+  int32_t* vcount;              // [2] number of heavy / other envs in vorder (zeroed by k_collide pass 0)
+  int32_t use_vorder;           // k_view maps workgroups to envs through vorder (step path, roles 0/1)
+  int32_t role;                 // 0: every env; 1: main stream (skips part envs); 2: side stream (walks clist)
   // step I/O
   const float* actions;         // [B,N,3] or null
   uint8_t* obs;                 // [B,N,96,96,3] or null
@@ -30,6 +36,7 @@ struct McrParams {
   const uint8_t* reset_mask;    // [B] or null (k_install)
   int32_t auto_reset, max_steps, car_contacts, backwards_flag, use_ego_color;
   int32_t debug;                // ablation switches for profiling (0 in production)
+  unsigned long long* dbg_stamps; // [2][dyn_blocks][8] phase clocks of k_dynamics (debug bit 8)
   double h_ratio;
 };
 
@@ -41,5 +48,14 @@ enum { VP_CAM = 0 /*m00 m01 m10 m11 tx ty*/, VP_INV = 6 /*ax bx cx0 ay by cy0*/,
 // 8 vertices (x0 y0 .. x7 y7) and slot header words live in carpoly_n: vertex count (0 = not drawn)
 #define MCR_CARPOLY_FLOATS (12 * 16 + 16)
 #define MCR_CARPOLY_NOFF (12 * 16)
+// Env handled by work slot `s` of a launch (slot = env index for roles 0/1, clist position for role 2); returns
+// p.env0 + p.nenv ("no env") for slots that are not this launch's business.
+__device__ __forceinline__ int mcr_env_of_slot(const McrParams& p, int s) {
+  const int end = p.env0 + p.nenv;
+  if (p.role == 2) return s < p.clist[0] ? p.clist[1 + s] : end;
+  const int env = p.env0 + s;
+  if (env >= end) return end;
+  return (p.role == 1 && p.part[env]) ? end : env;
+}
 #define MCR_CC_MAX 24           // touching car<->car fixture pairs kept per env (warm start)
 #define MCR_CC_WORDS 20         // u32 words per stored manifold

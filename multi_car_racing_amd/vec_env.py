@@ -29,7 +29,7 @@ class VecMultiCarRacing:
     def __init__(self, num_envs, num_agents=2, device=None, seed=0, env_offset=0, direction="CCW",
                  use_random_direction=True, backwards_flag=True, h_ratio=0.25, use_ego_color=False,
                  obs=True, auto_reset=True, max_episode_steps=1000, car_contacts=True,
-                 gen_threads=None, async_refill=True, streams=1):
+                 gen_threads=None, async_refill=True, streams=None):
         if not torch.cuda.is_available():
             raise _lib.McrError("VecMultiCarRacing needs a HIP device: the step path has no CPU fallback")
         self.L = _lib.load()
@@ -37,6 +37,8 @@ class VecMultiCarRacing:
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         torch.cuda.set_device(self.device)
         self.obs_enabled = bool(obs)
+        if streams is None:           # contact side stream (include/mcr.h: num_streams) pays as soon as there is a batch
+            streams = 2 if int(num_envs) >= 64 and int(num_agents) > 1 and car_contacts else 1
         self.auto_reset = bool(auto_reset)
         self.direction_mode = 2 if use_random_direction else _DIRECTION_MODE[direction]
         self.gen_threads = gen_threads or max(1, _lib.effective_cpus() - 1)
@@ -240,11 +242,12 @@ class VecMultiCarRacing:
         return _lib.unpack_episode(np.ascontiguousarray(self._blobs_np[e]))
 
     def timing(self, mask):
-        """HIP-event kernel timing; mask bit 0 collide, 1 dynamics, 2 view, 3/4 reset-pass collide/dynamics."""
+        """HIP-event kernel timing; mask bit 0 collide, 1 dynamics, 2 view, 3/4 reset-pass collide/dynamics,
+        5/6 dynamics/view of the contact side stream, 7 its reset pass."""
         _lib.check(self.L.mcr_timing_enable(self.h, int(mask)))
 
     def timing_read(self):
-        ms = np.zeros(5); n = np.zeros(5, np.int64)
+        ms = np.zeros(8); n = np.zeros(8, np.int64)
         _lib.check(self.L.mcr_timing_read(self.h, _lib.ptr(ms), _lib.ptr(n)))
         return ms, n
 

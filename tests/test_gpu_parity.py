@@ -6,6 +6,7 @@ pixels are compared exactly outside the oracle's "ambiguous" mask (pixel centres
 edge, where real GL is implementation-defined too), with a small budget inside it."""
 import ctypes
 
+import os
 import numpy as np
 import pytest
 
@@ -24,6 +25,7 @@ def torch_cuda():
 def _make(B, N, seed, contacts=True, **kw):
     from multi_car_racing_amd.vec_env import VecMultiCarRacing
     kw.setdefault("use_random_direction", False); kw.setdefault("auto_reset", False); kw.setdefault("max_episode_steps", 0)
+    kw.setdefault("streams", int(os.environ.get("MCR_TEST_STREAMS", "1")))     # 2: whole suite with the contact side stream
     return VecMultiCarRacing(B, N, seed=seed, car_contacts=contacts, async_refill=False, **kw)
 
 
@@ -316,13 +318,13 @@ def _rear_end_setup(env, orcs, gap=5.2):
             o.set_body(1, k, st[e, 1, k])
 
 
-@pytest.mark.parametrize("N", [2, 4])
-def test_car_car_contacts_bit_exact(torch_cuda, oracle, N):
+@pytest.mark.parametrize("N,streams", [(2, 1), (4, 1), (2, 2), (4, 2)])
+def test_car_car_contacts_bit_exact(torch_cuda, oracle, N, streams):
     """Rigid car<->car contacts (b2CollidePolygons + b2ContactSolver + merged islands): rear-end collisions,
     compared bit-exact with the oracle, including warm-started impulses across steps."""
     torch = torch_cuda
     B, seed = 5, 60 + N
-    env = _make(B, N, seed, contacts=True); env.reset()
+    env = _make(B, N, seed, contacts=True, streams=streams); env.reset()      # streams=2: contact side stream
     orcs = _oracles(oracle, B, N, seed, contacts=True)
     _rear_end_setup(env, orcs)
     rng = np.random.RandomState(4)
@@ -344,11 +346,12 @@ def test_car_car_contacts_bit_exact(torch_cuda, oracle, N):
     env.close()
 
 
-def test_random_rollout_with_contacts_enabled(torch_cuda, oracle):
+@pytest.mark.parametrize("streams", [1, 2])
+def test_random_rollout_with_contacts_enabled(torch_cuda, oracle, streams):
     """Default configuration (contacts on), N=8 crowded start: whatever happens, HIP == oracle."""
     torch = torch_cuda
     B, N, seed = 3, 8, 300
-    env = _make(B, N, seed, contacts=True); env.reset()
+    env = _make(B, N, seed, contacts=True, streams=streams); env.reset()
     orcs = _oracles(oracle, B, N, seed, contacts=True)
     rng = np.random.RandomState(8)
     for k in range(150):

@@ -1,0 +1,38 @@
+"""Per-phase clock stamps of k_dynamics wavefronts (debug bit 8) in a steady-state rollout with the contact side
+stream: where does the slowest wavefront of each launch spend its time?  GPU only, diagnostics."""
+import sys, os, torch, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multi_car_racing_amd.vec_env import VecMultiCarRacing
+from multi_car_racing_amd import _lib
+B, N = 4096, 2
+env = VecMultiCarRacing(B, N, seed=0, auto_reset=True, streams=2)
+env.reset()
+g = torch.Generator(device="cuda"); g.manual_seed(1)
+pool = torch.rand((64, B, N, 3), device="cuda", generator=g); pool[..., 0] = pool[..., 0] * 2 - 1
+nb = (B * 2 + 63) // 64
+buf = np.zeros(2 * nb * 8, np.uint64)
+_lib.check(env.L.mcr_debug_set(env.h, 256))
+names = ["load+Car.step+contact init", "velocity sweeps", "position loop", "sleep+bookkeeping+epilogue"]
+acc = {0: [], 1: []}
+for k in range(900):
+    env.step(pool[k % 64])
+    if k >= 300 and k % 10 == 0:
+        _lib.check(env.L.mcr_debug_read_dynamics_stamps(env.h, _lib.ptr(buf), len(buf)))
+        st = buf.reshape(2, nb, 8).astype(np.int64)
+        for role in (0, 1):
+            d = np.diff(st[role][:, :5], axis=1)
+            tot = st[role][:, 4] - st[role][:, 0]
+            if role == 1:
+                ok = tot > 0
+                if not ok.any(): continue
+            w = int(np.argmax(tot))
+            acc[role].append(np.concatenate([d[w], [tot[w]]]))
+        buf[:] = 0
+for role, nm in ((0, "main stream (slowest wavefront per launch)"), (1, "side stream (slowest wavefront per launch)")):
+    a = np.array(acc[role], float)
+    if len(a) == 0: continue
+    print(nm, "- 100 MHz ticks x10 = ns; n =", len(a))
+    for i, n_ in enumerate(names):
+        print(f"   {n_:32s} mean {a[:, i].mean() / 100:8.1f} us   max {a[:, i].max() / 100:8.1f} us")
+    print(f"   {'total':32s} mean {a[:, 4].mean() / 100:8.1f} us   max {a[:, 4].max() / 100:8.1f} us")
+env.close()
