@@ -128,9 +128,13 @@ __device__ __forceinline__ void joint_velocity(Joint& J, Body& A, Body& B, float
   A.vx = vAx; A.vy = vAy; A.w = wA; B.vx = vBx; B.vy = vBy; B.w = wB;
 }
 
+// sin/cos of the hull angle, remembered across joint_position calls: the hull is ~100x heavier than a wheel, so its
+// angle is bit-identical from one joint to the next most of the time (always, in the long marginal position loops)
+// and the f64 sincos — the bulk of a position sweep — is only re-evaluated when the argument actually changed.
+struct RotCache { float a; Rot q; };
 // b2RevoluteJoint::SolvePositionConstraints
 __device__ __forceinline__ bool joint_position(const Joint& J, Body& A, Body& B, float anchx, float anchy, float lcx, float lcy,
-                                               float mA, float iA, float mB, float iB) {
+                                               float mA, float iA, float mB, float iB, RotCache& rc) {
   float cAx = A.cx, cAy = A.cy, aA = A.a, cBx = B.cx, cBy = B.cy, aB = B.a;
   float angularError = 0.0f, positionError = 0.0f;
   if (J.limit != 0) {
@@ -148,7 +152,8 @@ __device__ __forceinline__ bool joint_position(const Joint& J, Body& A, Body& B,
     aA -= iA * limitImpulse; aB += iB * limitImpulse;
   }
   {
-    Rot qA = rot_of(aA);
+    if (__float_as_int(aA) != __float_as_int(rc.a)) { rc.q = rot_of(aA); rc.a = aA; }   // bit compare; rc.a starts as a NaN
+    const Rot qA = rc.q;
     V2 rA = rmul(qA, v2(anchx, anchy) - v2(lcx, lcy));
     float Cx = (cBx - cAx) - rA.x, Cy = (cBy - cAy) - rA.y;
     positionError = sqrtf(Cx * Cx + Cy * Cy);
@@ -170,7 +175,7 @@ __device__ __forceinline__ double np_sign(double x) { return x > 0.0 ? 1.0 : (x 
 // ---------------------------------------------------------------------------------------------------------
 // car<->car contact constraints, executed by the env's leader lane on LDS-resident body state.
 // xs[comp*5 + body][lane]: comp 0..2 = (vx, vy, w) or (cx, cy, a) of `body` of the car owned by `lane`.
-#define DYN_VC_POOL 48
+#define DYN_VC_POOL (MCR_SIDE_ENVS_PER_WAVE * MCR_CC_MAX)
 __device__ __forceinline__ void cc_masses(const McrShapes& S, int body, float& m, float& i, V2& lc) {
   if (body == 0) { m = S.hull_invMass; i = S.hull_invI; lc = v2(S.hull_lcx, S.hull_lcy); }
   else { m = S.wheel_invMass; i = S.wheel_invI; lc = v2(0.0f, 0.0f); }
@@ -387,7 +392,7 @@ __device__ inline float cc_position(const McrShapes& S, const uint32_t* rec, int
 // mode 1: the action-less step of reset() (:408) for envs whose `resetting` flag is set
 // debug bit 8 (256): lane 0 of every wavefront stamps the clock per phase (0 start, 1 state loaded + Car.step +
 // velocity integration, 2 velocity sweeps done, 3 position loop done, 4 end) into p.dbg_stamps[role==2][block][8]
-#define DYN_STAMP(i) do { if ((p.debug & 256) && mode == 0 && threadIdx.x == 0) p.dbg_stamps[((p.role == 2 ? gridDim.x : 0) + blockIdx.x) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define DYN_STAMP(i) do { if ((p.debug & 256) && mode == 0 && threadIdx.x == 0) p.dbg_stamps[((p.role == 2 ? (p.B * p.G + 63) / 64 : 0) + blockIdx.x) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
   using namespace dyn;
   DYN_STAMP(0);
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
   __shared__ int xisl[64], xact[64], xjok[64], xcok[64];
   __shared__ float xms[64];
   const int g = blockIdx.x * 64 + threadIdx.x;
-  const int env = mcr_env_of_slot(p, g / p.G), agent = g % p.G;
+  const int env = mcr_env_of_slot(p, mcr_dyn_slot(p)), agent = g % p.G;
   const int env_end = p.env0 + p.nenv;
   const bool lane_ok = env < env_end && agent < p.N;
   const int ci = lane_ok ? env * p.N + agent : 0;
@@ -657,6 +662,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
     }
   }
   // position iterations with the per-island early exit
+  RotCache hull_rot; hull_rot.a = __int_as_float(0x7fc00000); hull_rot.q.s = 0.0f; hull_rot.q.c = 1.0f;
   if (!wave_cc) {
     if (run) {
       const int pos_iters = (p.debug & 64) ? 2 : 60;          // debug bit 6: cap the position iterations (timing experiments only)
@@ -667,7 +673,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
         bool ok = true;
 #pragma unroll
         for (int q = 3; q >= 0; --q) {
-          bool jo = joint_position(J[q], b[0], b[q + 1], S.anchor_x[q], S.anchor_y[q], lcx, lcy, mH, iH, mW, iW);
+          bool jo = joint_position(J[q], b[0], b[q + 1], S.anchor_x[q], S.anchor_y[q], lcx, lcy, mH, iH, mW, iW, hull_rot);
           ok = ok && jo;
         }
         if (ok) { positionSolved = true; break; }
@@ -721,7 +727,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
         }
 #pragma unroll
         for (int q = 3; q >= 0; --q) {
-          bool jo = joint_position(J[q], b[0], b[q + 1], S.anchor_x[q], S.anchor_y[q], lcx, lcy, mH, iH, mW, iW);
+          bool jo = joint_position(J[q], b[0], b[q + 1], S.anchor_x[q], S.anchor_y[q], lcx, lcy, mH, iH, mW, iW, hull_rot);
           jointsOk = jointsOk && jo;
         }
       }

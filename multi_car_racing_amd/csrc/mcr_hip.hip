@@ -70,7 +70,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   const size_t o_cc = carve(sizeof(uint32_t) * (size_t)B * (MCR_CC_MAX * MCR_CC_WORDS + 4));
   const size_t o_part = carve(B);
   const size_t o_vorder = carve(sizeof(int32_t) * ((size_t)B + 2));
-  const size_t o_stamps = carve(sizeof(unsigned long long) * 2 * 8 * (((size_t)B * G + 63) / 64));
+  const size_t o_stamps = carve(sizeof(unsigned long long) * 8 * ((((size_t)B * G + 63) / 64) + (size_t)B));
   const size_t o_clist = carve(sizeof(int32_t) * ((size_t)B + 1));
   const size_t o_shapes = carve(sizeof(McrShapes));
   const size_t o_viewp = carve(sizeof(float) * MCR_VIEWP_FLOATS * BN);
@@ -187,6 +187,7 @@ static void launch_reset(mcr_env* h, McrParams P, hipStream_t st) {
 static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags) {
   const int B = P.B, N = P.N;
   const int dyn_blocks = (B * P.G + 63) / 64;
+  const int side_blocks = (B + MCR_SIDE_ENVS_PER_WAVE - 1) / MCR_SIDE_ENVS_PER_WAVE;   // role 2: few envs per wavefront
   const size_t view_lds = (size_t)N * 12 * 6 * 16;
   const bool draw = P.obs || view_flags;
   P.role = 0; P.split = h->split ? 1 : 0;
@@ -197,7 +198,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     (void)hipEventRecord(h->ev_fork, st);
     (void)hipStreamWaitEvent(h->s_side, h->ev_fork, 0);
     P.role = 2;
-    LAUNCH(5, k_dynamics, dyn_blocks, 64, h->s_side, P, 0);
+    LAUNCH(5, k_dynamics, side_blocks, 64, h->s_side, P, 0);
     if (draw) LAUNCH_LDS(6, k_view, B * N, VIEW_THREADS, view_lds, h->s_side, P, h->view_scratch, view_flags, 0);
     (void)hipEventRecord(h->ev_join, h->s_side);
     P.role = 1;
@@ -215,7 +216,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     if (P.auto_reset) {
       P.role = 2;
       LAUNCH(7, k_collide, B, 64, st, P, 1);
-      LAUNCH(7, k_dynamics, dyn_blocks, 64, st, P, 1);
+      LAUNCH(7, k_dynamics, side_blocks, 64, st, P, 1);
       if (draw) LAUNCH_LDS(7, k_view, B * N, VIEW_THREADS, view_lds, st, P, h->view_scratch, view_flags, 1);
     }
   }

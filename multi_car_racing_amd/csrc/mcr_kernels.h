@@ -52,10 +52,20 @@ enum { VP_CAM = 0 /*m00 m01 m10 m11 tx ty*/, VP_INV = 6 /*ax bx cx0 ay by cy0*/,
 // p.env0 + p.nenv ("no env") for slots that are not this launch's business.
 __device__ __forceinline__ int mcr_env_of_slot(const McrParams& p, int s) {
   const int end = p.env0 + p.nenv;
+  if (s < 0) return end;
   if (p.role == 2) return s < p.clist[0] ? p.clist[1 + s] : end;
   const int env = p.env0 + s;
   if (env >= end) return end;
   return (p.role == 1 && p.part[env]) ? end : env;
+}
+// Work slot of a k_dynamics lane.  Roles 0/1: 64/G consecutive envs per wavefront.  Role 2 (side stream, every env
+// holds car<->car contacts): MCR_SIDE_ENVS_PER_WAVE envs per wavefront, so that the wavefront's LDS pool of contact
+// constraints (DYN_VC_POOL = MCR_SIDE_ENVS_PER_WAVE * MCR_CC_MAX) can never overflow, however the envs are packed.
+#define MCR_SIDE_ENVS_PER_WAVE 2
+__device__ __forceinline__ int mcr_dyn_slot(const McrParams& p) {
+  const int grp = (int)threadIdx.x / p.G;
+  if (p.role == 2) return grp < MCR_SIDE_ENVS_PER_WAVE ? (int)blockIdx.x * MCR_SIDE_ENVS_PER_WAVE + grp : -1;
+  return ((int)blockIdx.x * 64 + (int)threadIdx.x) / p.G;
 }
 #define MCR_CC_MAX 24           // touching car<->car fixture pairs kept per env (warm start)
 #define MCR_CC_WORDS 20         // u32 words per stored manifold

@@ -268,6 +268,37 @@ def test_full_size_properties_and_batch_independence(torch_cuda, oracle):
     big.close(); small.close()
 
 
+def test_side_stream_is_bit_identical_to_single_stream(torch_cuda):
+    """The contact side stream only changes WHERE an env's chain runs: a 1024-env rollout with auto-resets (short
+    TimeLimit) and car<->car contacts must give identical rewards, dones, observations and state in both modes."""
+    torch = torch_cuda
+    B, N, seed = 1024, 2, 11
+    a1 = _make(B, N, seed, contacts=True, auto_reset=True, max_episode_steps=120, use_random_direction=True, streams=1)
+    a2 = _make(B, N, seed, contacts=True, auto_reset=True, max_episode_steps=120, use_random_direction=True, streams=2)
+    o1 = a1.reset(); o2 = a2.reset()
+    assert torch.equal(o1, o2)
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    ncontact = 0
+    cnt = np.zeros(B, np.int32)
+    from multi_car_racing_amd import _lib
+    for k in range(300):
+        a = torch.rand((B, N, 3), device="cuda", generator=g); a[..., 0] = a[..., 0] * 2 - 1; a[..., 2] *= 0.3
+        a[:, 1, 1] = 1.0                                              # car 1 floors it: rear-ends happen
+        o1, r1, d1, _ = a1.step(a); o2, r2, d2, _ = a2.step(a)
+        if not (torch.equal(r1, r2) and torch.equal(d1, d2)):
+            bad = torch.nonzero((r1 != r2).any(1) | (d1 != d2)).flatten().tolist()
+            _lib.check(a2.L.mcr_debug_read_contact_counts(a2.h, _lib.ptr(cnt)))
+            raise AssertionError(f"step {k}: envs {bad[:8]} differ; r1 {r1[bad[0]].tolist()} r2 {r2[bad[0]].tolist()} done {int(d1[bad[0]])}/{int(d2[bad[0]])} manifolds {cnt[bad[:8]].tolist()}")
+        if k % 25 == 24:
+            assert torch.equal(o1, o2), f"obs step {k}"
+            _lib.check(a2.L.mcr_debug_read_contact_counts(a2.h, _lib.ptr(cnt))); ncontact += int((cnt > 0).sum())
+    s1, s2 = a1.get_state(), a2.get_state()
+    for key in s1:
+        assert np.array_equal(s1[key], s2[key]), key
+    assert ncontact > 0, "rollout never exercised the side stream"
+    a1.close(); a2.close()
+
+
 def test_facade_matches_reference_surface(torch_cuda, oracle):
     import multi_car_racing_amd as M
     np.random.seed(5)
