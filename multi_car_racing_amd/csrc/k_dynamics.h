@@ -886,7 +886,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
   // evaluation per raster thread there.  Camera (:540-556): f64 exactly as CPython evaluates it, then the f32
   // values gym's Transform hands to glTranslatef/glRotatef/glScalef; HUD rectangles (:634-674).
   if (p.obs != nullptr && !respawn) {
-    const McrSoA<float> vp{p.viewp + ci, (size_t)BN};
+    float* vp = p.viewp + (size_t)ci * MCR_VIEWP_FLOATS;
     const Xf hxf = xf_of(v2(b[0].cx, b[0].cy), b[0].a, v2(lcx, lcy));
     const double t = es.t + 1.0 / MCR_FPS;
     const double zoom = 0.1 * MCR_SCALE * fmax(1 - t, 0.0) + MCR_ZOOM * MCR_SCALE * fmin(t, 1.0);
@@ -930,11 +930,11 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
     }
     vp[VP_HUDTOP] = hud_top;
     // world-space vertices of the 12 Car.draw polygons (trans*v in f32, as pybox2d hands them to the viewer)
-    const McrSoA<float> cp{p.carpoly + ci, (size_t)BN};
+    float* cp = p.carpoly + (size_t)ci * MCR_CARPOLY_FLOATS;   // AoS on purpose: the raster reads a car's record as one 832-byte run
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const Xf wxf = xf_of(v2(b[k + 1].cx, b[k + 1].cy), b[k + 1].a, v2(0.0f, 0.0f));
-      const McrSoA<float> box = cp + (2 * k) * 16, stripe = cp + (2 * k + 1) * 16;
+      float* box = cp + (2 * k) * 16; float* stripe = cp + (2 * k + 1) * 16;
       for (int i = 0; i < 8; ++i) { const int ii = i < 4 ? i : 3; const V2 w = xmul(wxf, v2(S.wheel.vx[ii], S.wheel.vy[ii])); box[i * 2] = w.x; box[i * 2 + 1] = w.y; }   // padded to 8 by repeating the last vertex
       cp[MCR_CARPOLY_NOFF + 2 * k] = __int_as_float(S.wheel.n);
       const double a1 = phase[k], a2 = phase[k] + 1.2;
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const McrSoA<float> hp = cp + (8 + k) * 16;
+      float* hp = cp + (8 + k) * 16;
       const int n = S.hull[k].n;
       for (int i = 0; i < 8; ++i) { const int ii = i < n ? i : n - 1; const V2 w = xmul(hxf, v2(S.hull[k].vx[ii], S.hull[k].vy[ii])); hp[i * 2] = w.x; hp[i * 2 + 1] = w.y; }
       cp[MCR_CARPOLY_NOFF + 8 + k] = __int_as_float(n);

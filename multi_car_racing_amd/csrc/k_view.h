@@ -196,12 +196,12 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
   if (tid == 0) { nsurv = 0; ncand = 0; any_inside = 0; }
   if (tid < 32) pal[tid] = palette_rgb(tid);
   if (tid < NBINS) bcnt[tid] = 0;
-  if (p.obs != nullptr && tid >= 64 && tid < 64 + 29) hud[tid - 64] = p.viewp[(size_t)(VP_IND + (tid - 64)) * BN + vw];
+  if (p.obs != nullptr && tid >= 64 && tid < 64 + 29) hud[tid - 64] = p.viewp[(size_t)vw * MCR_VIEWP_FLOATS + VP_IND + (tid - 64)];
   const uint32_t old_flags = p.caru[CU_FLAGS * BN + ci];
   const float hvx = p.carf[(CF_VX + 0) * BN + ci], hvy = p.carf[(CF_VY + 0) * BN + ci], ha = p.carf[(CF_A + 0) * BN + ci];
   const bool draw = p.obs != nullptr;
   const bool do_flags = flags_mode && !es.just_reset && !(dbg & 1);      // reset() -> step(None) skips the block (:435)
-  const McrSoA<const float> vp{p.viewp + ci, (size_t)BN};
+  const float* __restrict__ vp = p.viewp + (size_t)ci * MCR_VIEWP_FLOATS;
   float m00 = 0, m01 = 0, m10 = 0, m11 = 0, ctx = 0, cty = 0;
   if (draw) { m00 = vp[VP_CAM + 0]; m01 = vp[VP_CAM + 1]; m10 = vp[VP_CAM + 2]; m11 = vp[VP_CAM + 3]; ctx = vp[VP_CAM + 4]; cty = vp[VP_CAM + 5]; }
   float* __restrict__ spill = scratch + (size_t)vw * VIEW_SCRATCH_FLOATS;
@@ -270,11 +270,10 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
   // ---- car polygons (Car.draw): world vertices come from k_dynamics; threads 0..12N-1 set one polygon up each
   if (draw && tid < N * 12) {
     const int k = tid, c = k / 12, j = k % 12;
-    const McrSoA<const float> cp{p.carpoly + (env * N + c), (size_t)BN};
-    // one burst: 8 vertices + the vertex count (field-major records), all issued before anything is consumed
-    const McrSoA<const float> cv = cp + j * 16;
-    const float4 v01 = make_float4(cv[0], cv[1], cv[2], cv[3]), v23 = make_float4(cv[4], cv[5], cv[6], cv[7]);
-    const float4 v45 = make_float4(cv[8], cv[9], cv[10], cv[11]), v67 = make_float4(cv[12], cv[13], cv[14], cv[15]);
+    const float* __restrict__ cp = p.carpoly + (size_t)(env * N + c) * MCR_CARPOLY_FLOATS;
+    // one burst: 8 vertices (4 x float4) + the vertex count, all issued before anything is consumed
+    const float* cv = cp + j * 16;
+    const float4 v01 = ((const float4*)cv)[0], v23 = ((const float4*)cv)[1], v45 = ((const float4*)cv)[2], v67 = ((const float4*)cv)[3];
     const int n = __float_as_int(cp[MCR_CARPOLY_NOFF + j]);
     uint32_t info = 0;
     if (n > 0 && !(dbg & 4)) {

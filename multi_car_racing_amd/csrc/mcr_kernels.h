@@ -15,8 +15,8 @@ struct McrParams {
   uint16_t* tile_flags;         // [B][TILE_CAP]  bits 0..7 road_visited[car], bit 8 recoloured
   uint32_t* cc_store;           // [B][...] car<->car manifold store (warm starting)
   const McrShapes* shapes;
-  float* viewp;                 // [MCR_VIEWP_FLOATS][BN] per-car camera + HUD geometry, written by k_dynamics, read by k_view
-  float* carpoly;               // [MCR_CARPOLY_FLOATS][BN] world-space vertices of the car's 12 draw polygons (Car.draw)
+  float* viewp;                 // [BN][MCR_VIEWP_FLOATS] per-car camera + HUD geometry, written by k_dynamics, read by k_view
+  float* carpoly;               // [BN][MCR_CARPOLY_FLOATS] world-space vertices of the car's 12 draw polygons (Car.draw)
   int32_t* consumed_host;       // [B] mapped host memory: episode counter of the last install
   // contact side stream (mcr_config.num_streams == 2): envs holding a touching car<->car pair run their (much
   // longer) dynamics chain, reset pass and raster on a second stream, concurrently with everyone else's.
@@ -38,14 +38,6 @@ struct McrParams {
   int32_t debug;                // ablation switches for profiling (0 in production)
   unsigned long long* dbg_stamps; // [2][dyn_blocks][8] phase clocks of k_dynamics (debug bit 8)
   double h_ratio;
-};
-
-// Field-major (SoA) view of a per-car record: element i of car `ci` lives at base[i * BN + ci], so that the 64 lanes of a
-// k_dynamics wavefront (one car each) write every field as ONE coalesced 256-byte store.
-template <typename T> struct McrSoA {
-  T* base; size_t stride;
-  __device__ __forceinline__ T& operator[](int i) const { return base[(size_t)i * stride]; }
-  __device__ __forceinline__ McrSoA operator+(int off) const { return McrSoA{base + (size_t)off * stride, stride}; }
 };
 
 // per-car view parameters (f32): camera (:540-556) and HUD rectangles (:634-674) in pixel units

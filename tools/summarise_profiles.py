@@ -1,59 +1,98 @@
-"""Summarise gpurun_out/prof_<round>/ into profiles/<round>_*.md|json (tracked)."""
+"""Summarise gpurun_out/prof_<round>/ into profiles/<round>_*.md|json (tracked).
+
+A step of the default configuration issues several launches of the same kernel (main chain, contact side stream,
+reset passes), so launches are labelled by their position in the step: on the caller's queue the order is
+fill(clist) collide dynamics collide(reset) dynamics(reset) view [collide dynamics view](late reset of contact envs);
+on the side queue dynamics view."""
 import json, os, sys
 import pandas as pd
 
 R = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = f"gpurun_out/prof_{R}"
 os.makedirs("profiles", exist_ok=True)
-lines = [f"# {R}: rocprofv3 summary of `python bench.py --no-cpu-baseline` (default: 1000 timed steps after 64 warm-up steps and the steady-state pre-roll) (B=4096, N=2, 1x MI355X)\n"]
+STEPS = 1000
+lines = [f"# {R}: rocprofv3 summary of `python bench.py --no-cpu-baseline` (default configuration: contact side stream on, 1000 timed steps after 64 warm-up steps and the steady-state pre-roll; B=4096, N=2, 1x MI355X)\n"]
 try:
     b = json.loads(open(f"{src}/bench_plain.json").read().strip().splitlines()[-1])
     lines.append("Un-profiled bench line of the same command:\n\n```json\n" + json.dumps(b) + "\n```\n")
 except Exception as e:
+    b = {}
     lines.append(f"(bench_plain missing: {e})\n")
 
 def kname(s):
-    for k in ("k_collide", "k_dynamics", "k_view", "k_install", "k_positions", "k_sincos"):
+    for k in ("k_collide", "k_dynamics", "k_view", "k_install", "fillBuffer", "copyBuffer"):
         if k in s: return k
     return s[:60]
 
+MAIN_ORDER = {"k_collide": ["collide", "collide (reset pass)", "collide (late reset, contact envs)"],
+              "k_dynamics": ["dynamics (main envs)", "dynamics (reset pass)", "dynamics (late reset, contact envs)"],
+              "k_view": ["view (main envs)", "view (late reset, contact envs)"]}
+SIDE_ORDER = {"k_dynamics": ["dynamics (contact envs, side stream)"], "k_view": ["view (contact envs, side stream)"]}
+
+def label(df, order_col):
+    """adds column Label for the launches of the last STEPS steps (delimited by the clist memset on the main queue)"""
+    df = df.sort_values(order_col).reset_index(drop=True)
+    df["K"] = df["Kernel_Name"].map(kname)
+    fills = df.index[df.K == "fillBuffer"].tolist()
+    df["Label"] = None
+    if len(fills) < STEPS + 1:
+        return df
+    main_q = df.loc[fills[-1], "Queue_Id"]
+    starts = fills[-STEPS - 1:]            # the run ends with a step; take the STEPS complete steps before the last fill
+    for a, e in zip(starts[:-1], starts[1:]):
+        seen = {}
+        for i in range(a, e):
+            k = df.at[i, "K"]
+            if k not in ("k_collide", "k_dynamics", "k_view"): continue
+            on_main = df.at[i, "Queue_Id"] == main_q
+            key = (k, on_main); n = seen.get(key, 0); seen[key] = n + 1
+            names = (MAIN_ORDER if on_main else SIDE_ORDER).get(k, [])
+            df.at[i, "Label"] = names[n] if n < len(names) else f"{k} #{n}"
+    return df
+
 st = pd.read_csv(f"{src}/stats/s_kernel_stats.csv")
 st["Kernel"] = st["Name"].map(kname)
-lines.append("## `--kernel-trace --stats` (kernel_stats.csv)\n")
-lines.append(st[["Kernel", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"]].to_markdown(index=False) + "\n")
-kt = pd.read_csv(f"{src}/stats/s_kernel_trace.csv")
-kt["Kernel"] = kt["Kernel_Name"].map(kname); kt["us"] = (kt["End_Timestamp"] - kt["Start_Timestamp"]) / 1e3
-# timed region = last 1000 steps: split the two collide/dynamics passes by order within a step
-v = kt[kt.Kernel == "k_view"].tail(1000)
-lines.append(f"\nk_view over the timed region (last 1000 launches): mean {v.us.mean():.1f} us, median {v.us.median():.1f} us, min {v.us.min():.1f}, max {v.us.max():.1f}\n")
-for k in ("k_collide", "k_dynamics"):
-    g = kt[kt.Kernel == k].tail(2000)
-    p0, p1 = g.iloc[0::2], g.iloc[1::2]
-    lines.append(f"{k}: step pass mean {max(p0.us.mean(), p1.us.mean()):.1f} us, auto-reset pass mean {min(p0.us.mean(), p1.us.mean()):.1f} us\n")
+lines.append("## `--kernel-trace --stats` (kernel_stats.csv, whole process incl. pre-roll; every launch of a kernel pooled)\n")
+lines.append(st[["Kernel", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"]].head(8).to_markdown(index=False) + "\n")
+kt = label(pd.read_csv(f"{src}/stats/s_kernel_trace.csv"), "Start_Timestamp")
+kt["us"] = (kt["End_Timestamp"] - kt["Start_Timestamp"]) / 1e3
+g = kt[kt.Label.notna()].groupby("Label").us.agg(["count", "mean", "median", "min", "max"]).round(1)
+lines.append("## Kernel trace over the timed region (last 1000 steps), launches labelled by their role in the step\n")
+lines.append(g.to_markdown() + "\n")
+vmain = kt[kt.Label == "view (main envs)"].us
+lines.append(f"\nDominant kernel for the roofline: `k_view (main envs)` mean {vmain.mean():.1f} us per launch (bench.py's HIP-event figure: {b.get('roofline', {}).get('avg_launch_ms', float('nan')) * 1e3:.1f} us)\n")
+
 traffic = {}
 for name, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    c = pd.read_csv(f"{src}/{name}/p_counter_collection.csv")
-    c["Kernel"] = c["Kernel_Name"].map(kname)
-    g = c[(c.Kernel == "k_view") & (c.Counter_Name == ctr)].tail(1000)
-    traffic[ctr] = float(g.Counter_Value.mean())
+    c = label(pd.read_csv(f"{src}/{name}/p_counter_collection.csv"), "Dispatch_Id")
+    gsel = c[(c.Label == "view (main envs)") & (c.Counter_Name == ctr)]
+    traffic[ctr] = float(gsel.Counter_Value.mean())
+    side = c[(c.Label == "view (contact envs, side stream)") & (c.Counter_Name == ctr)]
+    traffic[ctr + "_side"] = float(side.Counter_Value.mean()) if len(side) else 0.0
 # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB; MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reads exactly 1/2 of
 # the bytes of a wide coalesced stream -> x2; WRITE_SIZE is taken as reported (uncalibrated).
-fetch_b = traffic["FETCH_SIZE"] * 1024 * 2
-write_b = traffic["WRITE_SIZE"] * 1024
-lines.append("\n## HBM traffic of k_view (PMC, separate passes)\n")
-lines.append(f"FETCH_SIZE mean {traffic['FETCH_SIZE']:.0f} KB/launch (x2 gfx950 correction -> {fetch_b/1e6:.1f} MB), WRITE_SIZE mean {traffic['WRITE_SIZE']:.0f} KB/launch ({write_b/1e6:.1f} MB)\n")
-alg = b["roofline"]["algorithmic_bytes_per_launch"] if "roofline" in b and b["roofline"] else None
-lines.append(f"HBM bytes per launch ~ {(fetch_b+write_b)/1e6:.1f} MB vs algorithmic {alg/1e6 if alg else float('nan'):.1f} MB\n")
+fetch_b = (traffic["FETCH_SIZE"] + traffic["FETCH_SIZE_side"]) * 1024 * 2
+write_b = (traffic["WRITE_SIZE"] + traffic["WRITE_SIZE_side"]) * 1024
+lines.append("\n## HBM traffic of the raster (PMC, separate passes; main launch + the side stream's launch for the contact envs)\n")
+lines.append(f"FETCH_SIZE mean {traffic['FETCH_SIZE']:.0f} + {traffic['FETCH_SIZE_side']:.0f} KB/step (x2 gfx950 correction -> {fetch_b/1e6:.1f} MB), WRITE_SIZE mean {traffic['WRITE_SIZE']:.0f} + {traffic['WRITE_SIZE_side']:.0f} KB/step ({write_b/1e6:.1f} MB)\n")
+alg = b.get("roofline", {}).get("algorithmic_bytes_per_launch")
+lines.append(f"HBM bytes per step ~ {(fetch_b+write_b)/1e6:.1f} MB vs algorithmic {alg/1e6 if alg else float('nan'):.1f} MB\n")
 json.dump({"hbm_bytes_per_launch": fetch_b + write_b, "fetch_bytes_corrected": fetch_b, "write_bytes": write_b,
-           "raw_kb": traffic, "round": R, "note": "FETCH_SIZE x2 (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported"},
+           "raw_kb": traffic, "round": R, "note": "FETCH_SIZE x2 (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; main raster launch + side-stream raster launch of a step"},
           open("profiles/view_traffic.json", "w"))
-sq = pd.read_csv(f"{src}/pmc_sq/p_counter_collection.csv"); sq["Kernel"] = sq["Kernel_Name"].map(kname)
-piv = sq.pivot_table(index=["Dispatch_Id", "Kernel"], columns="Counter_Name", values="Counter_Value", aggfunc="sum").reset_index()
-lines.append("\n## SQ counters per launch (mean over the last 1000 launches of each kernel)\n")
-rows = []
-for k, g in piv.groupby("Kernel"):
-    g = g.sort_values("Dispatch_Id").tail(1000); m = g.drop(columns=["Dispatch_Id", "Kernel"]).mean()
-    m["Kernel"] = k; rows.append(m)
-lines.append(pd.DataFrame(rows).set_index("Kernel").round(0).to_markdown() + "\n")
+sq = label(pd.read_csv(f"{src}/pmc_sq/p_counter_collection.csv"), "Dispatch_Id")
+sq = sq[sq.Label.notna()]
+# counters are summed over ALL launches of a kernel inside a step (main + side + reset passes): with several counters
+# rocprofv3 serialises and may reorder the queues, so only the per-kernel totals are robust here
+# (with more counters than the hardware has slots rocprofv3 rotates counter groups over the dispatches, so each
+# counter is a SAMPLE of the launches: mean per sampled launch x launches of that kernel per step)
+per_launch = sq.pivot_table(index="K", columns="Counter_Name", values="Counter_Value", aggfunc="mean")
+launches_per_step = kt[kt.Label.notna()].groupby("K").size() / STEPS
+tot = per_launch.mul(launches_per_step, axis=0)
+lines.append("\n## SQ counters per step, all launches of a kernel pooled (mean over the timed region)\n")
+lines.append(tot.round(0).to_markdown() + "\n")
+if "k_view" in tot.index:
+    nviews = 4096 * 2
+    lines.append(f"\nk_view per agent view: {tot.loc['k_view', 'SQ_INSTS_VALU'] / nviews:.0f} VALU, {tot.loc['k_view', 'SQ_INSTS_SALU'] / nviews:.0f} SALU, {tot.loc['k_view', 'SQ_INSTS_LDS'] / nviews:.0f} LDS instructions\n")
 open(f"profiles/{R}_rocprof_summary.md", "w").write("\n".join(lines))
 print("\n".join(lines))
