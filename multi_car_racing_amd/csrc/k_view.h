@@ -231,7 +231,7 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
         const float wx[4] = {a.x, a.z, b.x, b.z}, wy[4] = {a.y, a.w, b.y, b.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float px = m00 * wx[i] + m01 * wy[i] + ctx, py = m10 * wx[i] + m11 * wy[i] + cty;
+          const float px = __builtin_fmaf(m00, wx[i], __builtin_fmaf(m01, wy[i], ctx)), py = __builtin_fmaf(m10, wx[i], __builtin_fmaf(m11, wy[i], cty));
           x0 = fminf(x0, px); x1 = fmaxf(x1, px); y0 = fminf(y0, py); y1 = fmaxf(y1, py);
         }
         int i0, i1, j0, j1;
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
       float x0 = MCR_MAXFLT, x1 = -MCR_MAXFLT, y0 = MCR_MAXFLT, y1 = -MCR_MAXFLT;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        px[i] = m00 * wxs[i] + m01 * wys[i] + ctx; py[i] = m10 * wxs[i] + m11 * wys[i] + cty;
+        px[i] = __builtin_fmaf(m00, wxs[i], __builtin_fmaf(m01, wys[i], ctx)); py[i] = __builtin_fmaf(m10, wxs[i], __builtin_fmaf(m11, wys[i], cty));
         x0 = fminf(x0, px[i]); x1 = fmaxf(x1, px[i]); y0 = fminf(y0, py[i]); y1 = fmaxf(y1, py[i]);
       }
       float e[24];
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
       float x0 = MCR_MAXFLT, x1 = -MCR_MAXFLT, y0 = MCR_MAXFLT, y1 = -MCR_MAXFLT;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        px[i] = m00 * wx[i] + m01 * wy[i] + ctx; py[i] = m10 * wx[i] + m11 * wy[i] + cty;
+        px[i] = __builtin_fmaf(m00, wx[i], __builtin_fmaf(m01, wy[i], ctx)); py[i] = __builtin_fmaf(m10, wx[i], __builtin_fmaf(m11, wy[i], cty));
         x0 = fminf(x0, px[i]); x1 = fmaxf(x1, px[i]); y0 = fminf(y0, py[i]); y1 = fmaxf(y1, py[i]);
       }
       int ix0, ix1, iy0, iy1;
@@ -446,6 +446,14 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
     { const float fx[3] = {900.0f * kx, 925.0f * kx, 950.0f * kx}, fy[3] = {30.0f * ky, 70.0f * ky, 30.0f * ky}; edge_setup(fx, fy, 3, fe); }
     const float hud_top = hud[VP_HUDTOP - VP_IND];
     const int hud_rows = UNI((int)ceilf(hud_top * 0.0625f));             // bin rows that can contain HUD pixels
+    int hbx0[7], hbx1[7];                                                // bin columns each gauge can touch (scalar); empty: 1..0
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const float x0 = hud[i * 4], x1 = hud[i * 4 + 1], y0 = hud[i * 4 + 2], y1 = hud[i * 4 + 3];
+      const bool live = x1 > x0 && y1 > y0;
+      hbx0[i] = UNI(live ? max(0, (int)floorf(x0 * 0.125f)) : 1);
+      hbx1[i] = UNI(live ? min(11, (int)floorf(x1 * 0.125f)) : 0);
+    }
     const int lx = lane & 7, ly = lane >> 3;
     const float flx = (float)lx + 0.5f, fly = (float)ly + 0.5f;
     // background in "checker units": U = world.x / (2k), V = world.y / (2k) with k = PLAYFIELD/20;
@@ -565,12 +573,13 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
         const uint32_t ind_col[7] = {PAL_WHITE, PAL_BLUE255, PAL_BLUE255, PAL_PURPLE, PAL_PURPLE, PAL_GREEN255, PAL_RED255};
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
+          if (bxi < hbx0[i] || bxi > hbx1[i]) continue;                // scalar: a gauge is 2.4 px wide, 1-2 bin columns
           const float x0 = hud[i * 4], x1 = hud[i * 4 + 1], y0 = hud[i * 4 + 2], y1 = hud[i * 4 + 3];
-          const bool okx = x1 > x0 && y1 > y0 && cx >= x0 && cx <= x1;
+          const bool okx = cx >= x0 && cx <= x1;
           if (okx && cy0 >= y0 && cy0 <= y1) col0 = ind_col[i];
           if (okx && cy1 >= y0 && cy1 <= y1) col1 = ind_col[i];
         }
-        if (show_flag) {
+        if (show_flag && byi == 0 && bxi >= 10) {                      // the flag triangle spans x 86.4..91.2, y 3.6..8.4
           if ((fe[0] * cx + fe[1] * cy0 + fe[2] >= 0.0f) && (fe[3] * cx + fe[4] * cy0 + fe[5] >= 0.0f) && (fe[6] * cx + fe[7] * cy0 + fe[8] >= 0.0f)) col0 = PAL_BLUE255;
           if ((fe[0] * cx + fe[1] * cy1 + fe[2] >= 0.0f) && (fe[3] * cx + fe[4] * cy1 + fe[5] >= 0.0f) && (fe[6] * cx + fe[7] * cy1 + fe[8] >= 0.0f)) col1 = PAL_BLUE255;
         }
