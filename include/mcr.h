@@ -98,6 +98,10 @@ int mcr_step(mcr_env* h, const float* d_actions, uint8_t* d_obs, double* d_rewar
              uint8_t* d_trunc, void* stream);
 /* Envs whose staged episode was consumed since the last poll (host must stage a fresh one).
  * Synchronises `stream` only for a B-byte readback. Returns count (>=0) or error. */
+/* Episode statistics (what gym's RecordEpisodeStatistics would add): in the step that ends an env's
+ * episode (done), mcr_step writes the sum of the step rewards of that episode per agent into d_ep_return[B,N] and
+ * its length in steps into d_ep_len[B]; other rows are left untouched.  NULL disables either. */
+int mcr_set_episode_stats(mcr_env* h, double* d_ep_return, int32_t* d_ep_len);
 int mcr_poll_consumed(mcr_env* h, int32_t* env_ids_out, int cap, void* stream);
 
 /* ---- state access for differential tests / facade attributes (synchronous) */

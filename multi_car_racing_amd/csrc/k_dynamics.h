@@ -776,7 +776,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
 
   // ---- env bookkeeping (:433-443, :497-507) + TimeLimit, across the env's lane group
   bool done = false, trunc = false, respawn = false;
-  double step_reward = 0.0, reward = 0.0, prev_reward = 0.0;
+  double step_reward = 0.0, reward = 0.0, prev_reward = 0.0, epret = 0.0;
   uint32_t tvc = 0, flags = 0;
   if (run) { reward = p.card[CD_REWARD * BN + ci]; prev_reward = p.card[CD_PREV_REWARD * BN + ci]; tvc = p.caru[CU_TVC * BN + ci]; flags = p.caru[CU_FLAGS * BN + ci]; }
   int T = 0;
@@ -799,6 +799,13 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
     if (run && has_action) {
       int steps = es.steps + 1;
       if (p.max_steps > 0 && steps >= p.max_steps) { trunc = !done; done = true; }
+    }
+    if (run && has_action) {   // episode statistics: what a RecordEpisodeStatistics wrapper would report at `done`
+      epret = p.card[CD_EPRET * BN + ci] + step_reward;
+      if (done) {
+        if (p.ep_return_out) p.ep_return_out[ci] = epret;
+        if (p.ep_len_out && agent == 0) p.ep_len_out[env] = es.steps + 1;
+      }
     }
     if (lane_ok && es.active) {
       p.reward_out[ci] = step_reward;
@@ -856,7 +863,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) { J[k].ix = J[k].iy = J[k].iz = J[k].im = 0.0f; J[k].limit = 0; omega[k] = 0; phase[k] = 0; }
     gas[0] = gas[1] = 0; steer = 0; brake = 0; onroad = 0;
-    reward = 0; prev_reward = 0; tvc = 0; flags = 0;
+    reward = 0; prev_reward = 0; tvc = 0; flags = 0; epret = 0;
     p.caru[CU_ONROAD * BN + ci] = 0;
     p.caru[CU_TVC * BN + ci] = 0;
   }
@@ -880,6 +887,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
   p.card[CD_STEER * BN + ci] = steer; p.card[CD_BRAKE * BN + ci] = brake;
   if (mode == 0) {
     p.card[CD_REWARD * BN + ci] = reward; p.card[CD_PREV_REWARD * BN + ci] = prev_reward;
+    if (p.actions != nullptr || respawn) p.card[CD_EPRET * BN + ci] = epret;
     if (respawn) p.caru[CU_FLAGS * BN + ci] = 0;
   }
   // ---- per-car view parameters for the rasteriser: one lane per agent view here instead of one redundant
@@ -995,7 +1003,7 @@ __global__ __launch_bounds__(64) void k_install(McrParams p) {
     p.card[(CD_OMEGA + k) * BN + ci] = 0.0; p.card[(CD_PHASE + k) * BN + ci] = 0.0;
   }
   p.card[(CD_GAS + 0) * BN + ci] = 0.0; p.card[(CD_GAS + 1) * BN + ci] = 0.0; p.card[CD_STEER * BN + ci] = 0.0; p.card[CD_BRAKE * BN + ci] = 0.0;
-  p.card[CD_REWARD * BN + ci] = 0.0; p.card[CD_PREV_REWARD * BN + ci] = 0.0;
+  p.card[CD_REWARD * BN + ci] = 0.0; p.card[CD_PREV_REWARD * BN + ci] = 0.0; p.card[CD_EPRET * BN + ci] = 0.0;
   p.caru[CU_LIMIT * BN + ci] = 0; p.caru[CU_ONROAD * BN + ci] = 0; p.caru[CU_TVC * BN + ci] = 0; p.caru[CU_FLAGS * BN + ci] = 0;
   if (agent == 0) {
     McrEnvState* E = &p.env[env];

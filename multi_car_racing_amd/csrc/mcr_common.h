@@ -94,7 +94,8 @@ enum {
   CD_OMEGA = 4,  // +wheel
   CD_PHASE = 8,  // +wheel
   CD_REWARD = 12, CD_PREV_REWARD = 13,
-  CD_COUNT = 14
+  CD_EPRET = 14,                 // sum of the step rewards handed out in the running episode (episode statistics)
+  CD_COUNT = 15
 };
 // u32 fields  caru[field][B*N]
 enum {

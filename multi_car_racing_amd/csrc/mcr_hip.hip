@@ -247,6 +247,12 @@ extern "C" int mcr_step(mcr_env* h, const float* d_actions, uint8_t* d_obs, doub
   return MCR_OK;
 }
 
+extern "C" int mcr_set_episode_stats(mcr_env* h, double* d_ep_return, int32_t* d_ep_len) {
+  if (!h) { g_err = "null handle"; return MCR_ERR_ARG; }
+  h->P.ep_return_out = d_ep_return; h->P.ep_len_out = d_ep_len;
+  return MCR_OK;
+}
+
 extern "C" int mcr_poll_consumed(mcr_env* h, int32_t* env_ids_out, int cap, void* stream) {
   if (!h) return MCR_ERR_ARG;
   (void)stream;   // counters live in mapped host memory: no device synchronisation needed

@@ -33,6 +33,8 @@ struct McrParams {
   double* reward_out;           // [B,N]
   uint8_t* done_out;            // [B]
   uint8_t* trunc_out;           // [B] or null
+  double* ep_return_out;        // [B,N] or null: episode return per agent, written in the step that ends an episode
+  int32_t* ep_len_out;          // [B] or null: episode length in steps, written in the step that ends an episode
   const uint8_t* reset_mask;    // [B] or null (k_install)
   int32_t auto_reset, max_steps, car_contacts, backwards_flag, use_ego_color;
   int32_t debug;                // ablation switches for profiling (0 in production)

@@ -52,6 +52,10 @@ class VecMultiCarRacing:
         self.reward = torch.zeros((self.B, self.N), dtype=torch.float64, device=self.device)
         self.done = torch.zeros((self.B,), dtype=torch.uint8, device=self.device)
         self.truncated = torch.zeros((self.B,), dtype=torch.uint8, device=self.device)
+        # episode statistics, valid in the rows where `done` is set (overwritten when that env's next episode ends)
+        self.episode_return = torch.zeros((self.B, self.N), dtype=torch.float64, device=self.device)
+        self.episode_length = torch.zeros((self.B,), dtype=torch.int32, device=self.device)
+        _lib.check(self.L.mcr_set_episode_stats(self.h, ctypes.c_void_p(self.episode_return.data_ptr()), ctypes.c_void_p(self.episode_length.data_ptr())), "mcr_set_episode_stats")
         # RNG streams
         self.mt_track = np.zeros((self.B, _lib.MT_WORDS), np.uint32)
         self.mt_draw = np.zeros((self.B, _lib.MT_WORDS), np.uint32)
@@ -205,7 +209,8 @@ class VecMultiCarRacing:
                                    ctypes.c_void_p(self.truncated.data_ptr()), ctypes.c_void_p(st.cuda_stream)), "mcr_step")
         if self.auto_reset:
             self._poll_and_refill()
-        return self.obs, self.reward, self.done, {"TimeLimit.truncated": self.truncated}
+        return self.obs, self.reward, self.done, {"TimeLimit.truncated": self.truncated, "episode_return": self.episode_return,
+                                                   "episode_length": self.episode_length}
 
     # ------------------------------------------------------------------ introspection (synchronous; tests / debugging)
     def get_state(self):

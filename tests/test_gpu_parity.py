@@ -155,12 +155,16 @@ def test_time_limit_and_auto_reset(torch_cuda, oracle):
     env = _make(B, N, seed, contacts=False, auto_reset=True, max_episode_steps=L, use_random_direction=True)
     env.reset()
     rng = np.random.RandomState(0)
+    ret = np.zeros((B, N))
     for k in range(L):
         a = random_actions(rng, B, N, 0.2)
         obs, rew, done, info = env.step(torch.from_numpy(a).cuda())
+        ret += rew.cpu().numpy()
         if k < L - 1:
             assert not done.any().item()
     assert done.all().item() and info["TimeLimit.truncated"].all().item()
+    # episode statistics written in the done step: return = sum of the step rewards in summation order, length = L
+    assert np.array_equal(info["episode_return"].cpu().numpy(), ret) and (info["episode_length"].cpu().numpy() == L).all()
     env.wait_refills()
     # oracle: second episode of every env = second draw of its streams
     for e in range(B):
