@@ -396,6 +396,7 @@ __device__ inline float cc_position(const McrShapes& S, const uint32_t* rec, int
 __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
   using namespace dyn;
   DYN_STAMP(0);
+  if (p.role == 1 && mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) p.clist_next[0] = 0;   // every reader of it finished last step
   // LDS used only by waves that contain a touching car<->car pair
   __shared__ float xv[15][64], xp[15][64];            // body exchange: (vx,vy,w) / (cx,cy,a) x 5 bodies per lane
   __shared__ __attribute__((aligned(16))) float vcpool[DYN_VC_POOL][cc::VC_SIZE];

@@ -42,6 +42,7 @@ struct mcr_env {
   double t_ms[MCR_TIMING_SLOTS]; int64_t t_n[MCR_TIMING_SLOTS];
   bool any_reset;
   bool split;                 // contact side stream enabled (cfg.num_streams == 2)
+  int step_parity;            // which contact-list buffer the next step fills
   hipStream_t s_side;         // internal stream of the contact envs' chain
   hipEvent_t ev_fork, ev_join;
   float* view_scratch;        // per-view spill area of the rasteriser (zoomed-out frames only)
@@ -71,7 +72,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   const size_t o_part = carve(B);
   const size_t o_vorder = carve(sizeof(int32_t) * ((size_t)B + 2));
   const size_t o_stamps = carve(sizeof(unsigned long long) * 8 * ((((size_t)B * G + 63) / 64) + (size_t)B));
-  const size_t o_clist = carve(sizeof(int32_t) * ((size_t)B + 1));
+  const size_t o_clist = carve(sizeof(int32_t) * 2 * ((size_t)B + 1));
   const size_t o_shapes = carve(sizeof(McrShapes));
   const size_t o_viewp = carve(sizeof(float) * MCR_VIEWP_FLOATS * BN);
   const size_t o_carpoly = carve(sizeof(float) * MCR_CARPOLY_FLOATS * BN);
@@ -107,7 +108,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   // raster on an internal stream, concurrently with the same chain of all the other envs on the caller's stream;
   // the two event hops are off the critical path because the side chain is the shorter one.
   P.env0 = 0; P.nenv = B; P.split = 0; P.role = 0;
-  h->split = false;
+  h->split = false; h->step_parity = 0;
   if (cfg->num_streams == 2) {
     // highest priority: its few workgroups must not queue behind the main stream's saturating raster launch
     int prio_lo = 0, prio_hi = 0; (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
@@ -191,7 +192,11 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   const size_t view_lds = (size_t)N * 12 * 6 * 16;
   const bool draw = P.obs || view_flags;
   P.role = 0; P.split = h->split ? 1 : 0;
-  if (h->split) (void)hipMemsetAsync(P.clist, 0, sizeof(int32_t), st);
+  if (h->split) {      // the contact list is double-buffered by step parity; no memset on the critical path
+    int32_t* base = h->P.clist;
+    P.clist = base + (size_t)(h->step_parity) * (B + 1); P.clist_next = base + (size_t)(h->step_parity ^ 1) * (B + 1);
+    h->step_parity ^= 1;
+  }
   LAUNCH(0, k_collide, B, 64, st, P, 0);
   P.split = 0;
   if (h->split) {

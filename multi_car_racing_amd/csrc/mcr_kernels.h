@@ -21,7 +21,8 @@ struct McrParams {
   // contact side stream (mcr_config.num_streams == 2): envs holding a touching car<->car pair run their (much
   // longer) dynamics chain, reset pass and raster on a second stream, concurrently with everyone else's.
   uint8_t* part;                // [B] 1: env belongs to the side stream this step (written by k_collide pass 0)
-  int32_t* clist;               // [1+B] count, then the env ids of the side-stream envs (any order)
+  int32_t* clist;               // [1+B] count, then the env ids of the side-stream envs (any order); this step's buffer
+  int32_t* clist_next;          // the other buffer (steps alternate): its count is zeroed by this step's main k_dynamics
   int32_t split;                // k_collide pass 0 fills part/clist
   int32_t* vorder;              // [B] raster order of the main launch: heavy envs from the front, the others from the back
   int32_t* vcount;              // [2] number of heavy / other envs in vorder (zeroed by k_collide pass 0)

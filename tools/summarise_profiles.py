@@ -2,7 +2,7 @@
 
 A step of the default configuration issues several launches of the same kernel (main chain, contact side stream,
 reset passes), so launches are labelled by their position in the step: on the caller's queue the order is
-fill(clist) collide dynamics collide(reset) dynamics(reset) view [collide dynamics view](late reset of contact envs);
+collide dynamics collide(reset) dynamics(reset) view [collide dynamics view](late reset of contact envs);
 on the side queue dynamics view."""
 import json, os, sys
 import pandas as pd
@@ -30,15 +30,21 @@ MAIN_ORDER = {"k_collide": ["collide", "collide (reset pass)", "collide (late re
 SIDE_ORDER = {"k_dynamics": ["dynamics (contact envs, side stream)"], "k_view": ["view (contact envs, side stream)"]}
 
 def label(df, order_col):
-    """adds column Label for the launches of the last STEPS steps (delimited by the clist memset on the main queue)"""
+    """adds column Label for the launches of the last STEPS steps.  A step is three k_collide launches on the caller's
+    queue (pass 0, reset pass, late reset pass of the contact envs); steps are counted back from the end of the run
+    (the pre-roll's masked resets add launches of their own further up)."""
     df = df.sort_values(order_col).reset_index(drop=True)
     df["K"] = df["Kernel_Name"].map(kname)
-    fills = df.index[df.K == "fillBuffer"].tolist()
     df["Label"] = None
-    if len(fills) < STEPS + 1:
+    col = df.index[df.K == "k_collide"].tolist()
+    if not col:
         return df
-    main_q = df.loc[fills[-1], "Queue_Id"]
-    starts = fills[-STEPS - 1:]            # the run ends with a step; take the STEPS complete steps before the last fill
+    qcount = df.loc[col, "Queue_Id"].value_counts()
+    main_q = qcount.index[0]
+    col = [i for i in col if df.at[i, "Queue_Id"] == main_q]
+    if len(col) < 3 * STEPS:
+        return df
+    starts = col[-3 * STEPS::3] + [len(df)]
     for a, e in zip(starts[:-1], starts[1:]):
         seen = {}
         for i in range(a, e):
