@@ -98,6 +98,10 @@ int mcr_step(mcr_env* h, const float* d_actions, uint8_t* d_obs, double* d_rewar
              uint8_t* d_trunc, void* stream);
 /* Envs whose staged episode was consumed since the last poll (host must stage a fresh one).
  * Synchronises `stream` only for a B-byte readback. Returns count (>=0) or error. */
+/* render(mode) at another viewport (multi_car_racing.py:511-604 with VP_W x VP_H of :573-586; 'rgb_array' = 600 x 400):
+ * the CURRENT state of env `env` as seen by each of its agents, d_out [N, height, width, 3] u8 (device), rows top-down.
+ * Skid particles and the score label are not drawn.  Needs obs_enabled. */
+int mcr_render(mcr_env* h, int env, int width, int height, uint8_t* d_out, void* stream);
 /* Episode statistics (what gym's RecordEpisodeStatistics would add): in the step that ends an env's
  * episode (done), mcr_step writes the sum of the step rewards of that episode per agent into d_ep_return[B,N] and
  * its length in steps into d_ep_len[B]; other rows are left untouched.  NULL disables either. */

@@ -5,6 +5,7 @@
 #include "k_dynamics.h"
 #include "k_collide.h"
 #include "k_view.h"
+#include "k_render.h"
 #include <hip/hip_runtime.h>
 #include <string>
 #include <vector>
@@ -248,6 +249,18 @@ extern "C" int mcr_step(mcr_env* h, const float* d_actions, uint8_t* d_obs, doub
   // with auto_reset, finished envs are re-spawned on the device and take the action-less first step of their
   // new episode inside this call; the view kernel always runs (it also owns the backward/on-grass flags)
   launch_step(h, P, st, d_actions ? 1 : 0);
+  HIPCHK(hipGetLastError());
+  return MCR_OK;
+}
+
+extern "C" int mcr_render(mcr_env* h, int env, int width, int height, uint8_t* d_out, void* stream) {
+  if (!h || !d_out) { g_err = "null argument"; return MCR_ERR_ARG; }
+  if (env < 0 || env >= h->cfg.num_envs || width < 1 || height < 1 || width > 4096 || height > 4096) { g_err = "env / viewport out of range"; return MCR_ERR_ARG; }
+  if (!h->any_reset) { g_err = "render() before reset()"; return MCR_ERR_STATE; }
+  if (!h->cfg.obs_enabled) { g_err = "render() needs obs_enabled (the camera and car polygons are produced for the observation path)"; return MCR_ERR_STATE; }
+  McrParams P = h->P;
+  const dim3 grid((width + RENDER_TILE - 1) / RENDER_TILE, (height + RENDER_TILE - 1) / RENDER_TILE, P.N);
+  hipLaunchKernelGGL(k_render_frame, grid, dim3(256), 0, (hipStream_t)stream, P, env, width, height, d_out);
   HIPCHK(hipGetLastError());
   return MCR_OK;
 }

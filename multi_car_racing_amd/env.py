@@ -14,6 +14,7 @@ import numpy as np
 from . import _lib, seeding
 
 STATE_W = STATE_H = 96
+VIDEO_W, VIDEO_H = 600, 400          # multi_car_racing.py:45-46
 FPS = 50
 
 
@@ -155,8 +156,15 @@ class MultiCarRacing:
         assert mode in ["human", "state_pixels", "rgb_array"]
         if mode == "state_pixels":
             return self._obs[0].cpu().numpy()
-        raise NotImplementedError("only mode='state_pixels' is rasterised on the device in this round "
-                                  "(rgb_array/human are SURVEY §8(f) row 3)")
+        if mode == "rgb_array":                                            # VIDEO_W x VIDEO_H viewport (:573-575)
+            if not self._was_reset:
+                return None                                                # reference: "reset() not called yet" (:538)
+            out = self._torch.empty((self.num_agents, VIDEO_H, VIDEO_W, 3), dtype=self._torch.uint8, device=self._dev)
+            st = self._torch.cuda.current_stream(self._dev)
+            _lib.check(self.L.mcr_render(self._h, 0, VIDEO_W, VIDEO_H, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(st.cuda_stream)), "mcr_render")
+            return out.cpu().numpy()
+        raise NotImplementedError("mode='human' opens one window per agent in the reference; there is no display path here — "
+                                  "use 'rgb_array' (600x400 frames) or 'state_pixels'")
 
     def close(self):
         if getattr(self, "_h", None):

@@ -212,6 +212,16 @@ class VecMultiCarRacing:
         return self.obs, self.reward, self.done, {"TimeLimit.truncated": self.truncated, "episode_return": self.episode_return,
                                                    "episode_length": self.episode_length}
 
+    def render_rgb(self, e=0, width=600, height=400):
+        """render('rgb_array') of env e: uint8 device tensor [N, height, width, 3] of its CURRENT state (reference
+        :511-604 with the VIDEO_W x VIDEO_H viewport; no skid particles, no score label)."""
+        if not self._has_reset:
+            raise AttributeError("render before reset()")
+        out = torch.empty((self.N, int(height), int(width), 3), dtype=torch.uint8, device=self.device)
+        st = torch.cuda.current_stream(self.device)
+        _lib.check(self.L.mcr_render(self.h, int(e), int(width), int(height), ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(st.cuda_stream)), "mcr_render")
+        return out
+
     # ------------------------------------------------------------------ introspection (synchronous; tests / debugging)
     def get_state(self):
         B, N = self.B, self.N

@@ -216,6 +216,8 @@ def lib():
                      "orc_set_body", "orc_get_env", "orc_positions", "orc_contact_event", "orc_set_hull_pose",
                      "orc_bookkeeping", "orc_wheel_tile_counts", "orc_reset_nostep", "orc_step_masked", "orc_reset_masked"):
             getattr(L, name).restype = None
+        L.orc_render_size.restype = None
+        L.orc_render_size.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.orc_num_car_contacts.restype = ctypes.c_int
         L.orc_num_car_contacts.argtypes = [ctypes.c_void_p]
         _lib = L
@@ -310,6 +312,14 @@ class OracleEnv:
         obs = np.zeros((self.N, 96, 96, 3), np.uint8)
         amb = np.zeros((self.N, 96, 96), np.uint8)
         self.L.orc_render(self.h, _p(obs), _p(amb))
+        return obs, amb
+
+    def render_size(self, width, height):
+        """render('rgb_array')-style frame of the CURRENT state at width x height (no skid particles, no score label);
+        returns (frames [N,H,W,3], ambiguity mask [N,H,W])."""
+        obs = np.zeros((self.N, height, width, 3), np.uint8)
+        amb = np.zeros((self.N, height, width), np.uint8)
+        self.L.orc_render_size(self.h, int(width), int(height), _p(obs), _p(amb))
         return obs, amb
 
     def state(self):

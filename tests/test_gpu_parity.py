@@ -303,6 +303,36 @@ def test_side_stream_is_bit_identical_to_single_stream(torch_cuda):
     a1.close(); a2.close()
 
 
+def test_rgb_array_render_matches_oracle(torch_cuda, oracle):
+    """render('rgb_array') (:573-604, 600x400 viewport) and an odd-sized viewport: exact outside the oracle's ambiguity
+    mask during the zoom-in, mid-episode, with touched tiles, the backwards flag and ego colours."""
+    torch = torch_cuda
+    B, N, seed = 2, 3, 21
+    env = _make(B, N, seed, contacts=True, use_ego_color=True); env.reset()
+    orcs = _oracles(oracle, B, N, seed, contacts=True, use_ego_color=True)
+    rng = np.random.RandomState(12)
+    checked = 0
+    for k in range(75):
+        a = random_actions(rng, B, N, 0.1)
+        if k > 45:
+            a[..., 0] = 1.0; a[..., 1] = 0.3                              # hard lock: cars spin, backward flags come up
+        env.step(torch.from_numpy(a).cuda())
+        for e, o in enumerate(orcs):
+            o.step(a[e], render=False)
+        if k in (0, 7, 30, 60, 74):
+            for (w, h) in ((600, 400), (133, 77)):
+                for e, o in enumerate(orcs):
+                    got = env.render_rgb(e, w, h).cpu().numpy()
+                    want, amb = o.render_size(w, h)
+                    assert got.shape == (N, h, w, 3)
+                    bad = ((got != want).any(-1) & (amb == 0)).sum()
+                    assert bad == 0, f"step {k} env {e} {w}x{h}: {bad} unambiguous pixels differ"
+                    assert ((got != want).any(-1)).sum() <= 0.002 * N * w * h
+                    checked += 1
+    assert checked == 20
+    env.close()
+
+
 def test_facade_matches_reference_surface(torch_cuda, oracle):
     import multi_car_racing_amd as M
     np.random.seed(5)
@@ -331,6 +361,9 @@ def test_facade_matches_reference_surface(torch_cuda, oracle):
     with pytest.raises(AssertionError):
         env.render("bogus")
     assert np.array_equal(env.render("state_pixels"), ob)
+    frame = env.render("rgb_array")                                # (N, VIDEO_H, VIDEO_W, 3) like :518 stacks them
+    want, amb = o.render_size(600, 400)
+    assert frame.shape == (2, 400, 600, 3) and frame.dtype == np.uint8 and ((frame != want).any(-1) & (amb == 0)).sum() == 0
     env.close()
     e2 = M.MultiCarRacing(num_agents=1, verbose=0)
     with pytest.raises(AttributeError):
