@@ -22,6 +22,8 @@ namespace col {
 struct TilePoly { int n; float vx[4], vy[4], nx[4], ny[4]; };
 
 #define CAND_CAP 128                 // (tile, car) candidate pairs buffered before the overlap pass runs
+// dynamic LDS of k_collide: 8N fixtures x (2 float4 + 4 x 8 floats + count)
+__host__ __device__ inline size_t lds_bytes(int N) { return (size_t)8 * N * (2 * 16 + 4 * 8 * 4 + 4); }
 #define TILE_FOR(i) _Pragma("unroll") for (int i = 0; i < 4; ++i)
 
 // max over A's edge normals of the min projection of B's vertices (A = car fixture in LDS, B = tile)
@@ -96,10 +98,15 @@ __global__ __launch_bounds__(64) void k_collide(McrParams p, int pass) {
   uint16_t* tflags = p.tile_flags + (size_t)env * MCR_TILE_CAP;
   if (pass == 1) for (int t = lane; t < MCR_TILE_CAP; t += 64) { touch[t] = 0; tflags[t] = 0; }
 
-  __shared__ float fvx[64][8], fvy[64][8], fnx[64][8], fny[64][8];
-  __shared__ int fcnt[64];
+  // per-fixture arrays for the env's 8N car fixtures live in DYNAMIC LDS (col::lds_bytes(N)): at N=2 that is 2.6 KB
+  // instead of 10.5 KB, which lifts the LDS-limited occupancy from 11 to 16 wavefronts per CU — with one wavefront
+  // per env, all 4096 envs of the bench are then resident in a single round.
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  const int F = 8 * p.N;
+  float4* fxf = (float4*)dyn_lds; float4* fbox = fxf + F;           // body transform (p.x p.y s c), world AABB +-0.05
+  float (*fvx)[8] = (float (*)[8])(fbox + F); float (*fvy)[8] = fvx + F; float (*fnx)[8] = fvy + F; float (*fny)[8] = fnx + F;
+  int* fcnt = (int*)(fny + F);
   __shared__ float cbox[MCR_MAX_AGENTS][4];
-  __shared__ float4 fxf[64], fbox[64];                 // per fixture: body transform (p.x p.y s c), world AABB +-0.05
   __shared__ uint32_t newrec[MCR_CC_MAX][16];
   __shared__ uint32_t tres[MCR_TILE_CAP], tany[MCR_TILE_CAP / 32];
   __shared__ uint32_t cand[CAND_CAP];
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(64) void k_collide(McrParams p, int pass) {
         lox = mcr_min(lox, w.x); loy = mcr_min(loy, w.y); hix = mcr_max(hix, w.x); hiy = mcr_max(hiy, w.y);
       }
       fbox[lane] = make_float4(lox - 0.05f, loy - 0.05f, hix + 0.05f, hiy + 0.05f);
-    } else fcnt[lane] = 0;
+    }
     for (int o = 1; o < 8; o <<= 1) {
       lox = mcr_min(lox, __shfl_xor(lox, o)); loy = mcr_min(loy, __shfl_xor(loy, o));
       hix = mcr_max(hix, __shfl_xor(hix, o)); hiy = mcr_max(hiy, __shfl_xor(hiy, o));

@@ -176,7 +176,7 @@ static void launch_reset(mcr_env* h, McrParams P, hipStream_t st) {
   const int dyn_blocks = (B * P.G + 63) / 64;
   P.split = 0; P.role = 0; P.use_vorder = 0;
   hipLaunchKernelGGL(k_install, dim3(dyn_blocks), dim3(64), 0, st, P);
-  LAUNCH(3, k_collide, B, 64, st, P, 1);
+  LAUNCH_LDS(3, k_collide, B, 64, col::lds_bytes(N), st, P, 1);
   LAUNCH(4, k_dynamics, dyn_blocks, 64, st, P, 1);
   if (P.obs) LAUNCH_LDS(2, k_view, B * N, VIEW_THREADS, (size_t)N * 12 * 6 * 16, st, P, h->view_scratch, 0, 1);
 }
@@ -198,7 +198,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     P.clist = base + (size_t)(h->step_parity) * (B + 1); P.clist_next = base + (size_t)(h->step_parity ^ 1) * (B + 1);
     h->step_parity ^= 1;
   }
-  LAUNCH(0, k_collide, B, 64, st, P, 0);
+  LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), st, P, 0);
   P.split = 0;
   if (h->split) {
     (void)hipEventRecord(h->ev_fork, st);
@@ -211,7 +211,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   }
   LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 0);
   if (P.auto_reset) {   // envs re-spawned by pass 0 take the action-less first step of their new episode (:408)
-    LAUNCH(3, k_collide, B, 64, st, P, 1);
+    LAUNCH_LDS(3, k_collide, B, 64, col::lds_bytes(N), st, P, 1);
     LAUNCH(4, k_dynamics, dyn_blocks, 64, st, P, 1);
   }
   P.use_vorder = 1;
@@ -221,7 +221,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     (void)hipStreamWaitEvent(st, h->ev_join, 0);
     if (P.auto_reset) {
       P.role = 2;
-      LAUNCH(7, k_collide, B, 64, st, P, 1);
+      LAUNCH_LDS(7, k_collide, B, 64, col::lds_bytes(N), st, P, 1);
       LAUNCH(7, k_dynamics, side_blocks, 64, st, P, 1);
       if (draw) LAUNCH_LDS(7, k_view, B * N, VIEW_THREADS, view_lds, st, P, h->view_scratch, view_flags, 1);
     }
