@@ -85,7 +85,7 @@ __device__ __forceinline__ bool overlap(const float* avx, const float* avy, cons
 __global__ __launch_bounds__(64) void k_collide(McrParams p, int pass) {
   using namespace col;
   const int env = mcr_env_of_slot(p, blockIdx.x), lane = threadIdx.x;
-  if (pass == 0 && blockIdx.x == 0 && lane == 0) { p.vcount[0] = 0; p.vcount[1] = 0; }     // refilled by k_dynamics
+  if (pass == 0 && blockIdx.x == 0 && lane == 0) { p.vcount[0] = 0; p.vcount[1] = 0; p.dlist[0] = 0; }     // refilled by k_dynamics
   if (env >= p.env0 + p.nenv) return;
   if (pass == 0 && p.split && lane == 0) p.part[env] = 0;
   const McrEnvState es = p.env[env];
@@ -319,5 +319,5 @@ __global__ __launch_bounds__(64) void k_collide(McrParams p, int pass) {
     nn_final = nn;
   } else if (lane == 0 && pass == 1) store[0] = 0;
   // side-stream partition: envs whose dynamics chain is going to be long (a touching car<->car pair)
-  if (pass == 0 && p.split && lane == 0 && nn_final > 0) { p.part[env] = 1; p.clist[1 + atomicAdd(&p.clist[0], 1)] = env; }
+  if (pass == 0 && p.split && lane == 0 && nn_final > 0) { p.part[env] = 1; p.clist[1 + atomicAdd(&p.clist[0], 1)] = env; atomicAdd(&p.counters[2], 1ull); }
 }

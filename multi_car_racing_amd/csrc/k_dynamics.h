@@ -392,7 +392,7 @@ __device__ inline float cc_position(const McrShapes& S, const uint32_t* rec, int
 // mode 1: the action-less step of reset() (:408) for envs whose `resetting` flag is set
 // debug bit 8 (256): lane 0 of every wavefront stamps the clock per phase (0 start, 1 state loaded + Car.step +
 // velocity integration, 2 velocity sweeps done, 3 position loop done, 4 end) into p.dbg_stamps[role==2][block][8]
-#define DYN_STAMP(i) do { if ((p.debug & 256) && mode == 0 && threadIdx.x == 0) p.dbg_stamps[((p.role == 2 ? (p.B * p.G + 63) / 64 : 0) + blockIdx.x) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define DYN_STAMP(i) do { if ((p.debug & 256) && mode == 0 && threadIdx.x == 0) p.dbg_stamps[((p.role >= 2 ? (p.B * p.G + 63) / 64 : 0) + blockIdx.x) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
   using namespace dyn;
   DYN_STAMP(0);
@@ -405,9 +405,15 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
   const int g = blockIdx.x * 64 + threadIdx.x;
   const int env = mcr_env_of_slot(p, mcr_dyn_slot(p)), agent = g % p.G;
   const int env_end = p.env0 + p.nenv;
-  const bool lane_ok = env < env_end && agent < p.N;
+  bool lane_ok = env < env_end && agent < p.N;
   const int ci = lane_ok ? env * p.N + agent : 0;
   const int BN = p.BN;
+  // Deferral (contact side stream configuration): the main launch (role 1) gives the position loop p.defer_after
+  // sweeps; an env with a car that is still iterating then (a slow marginal crawl, ~0.06 % of the env-steps, which
+  // would otherwise hold the whole launch for up to 60 sweeps) parks its state and goes on the deferred list; the
+  // resume launch (role 3, own stream) reloads it, runs the remaining sweeps and the whole tail of the step.
+  const bool resume = p.role == 3 && mode == 0;
+  const int defer_cap = (p.role == 1 && mode == 0) ? p.defer_after : 0;
   McrEnvState es;
   if (env < env_end) es = p.env[env]; else { es.active = 0; es.resetting = 0; }
   bool run = lane_ok && es.active;
@@ -447,6 +453,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
     steer = p.card[CD_STEER * BN + ci]; brake = p.card[CD_BRAKE * BN + ci];
     onroad = p.caru[CU_ONROAD * BN + ci];
 
+    if (!resume) {
     // ---- controls (:418-424) — the reference negates the steering input
     if (mode == 0 && p.actions) {
       double a0 = (double)p.actions[ci * 3 + 0], a1 = (double)p.actions[ci * 3 + 1], a2 = (double)p.actions[ci * 3 + 2];
@@ -512,6 +519,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
       b[k + 1].vx = b[k + 1].vx + h * (mW * (0.0f + fx[k])); b[k + 1].vy = b[k + 1].vy + h * (mW * (0.0f + fy[k]));
       b[k + 1].w += h * iW * 0.0f;
     }
+    }   // !resume
   }
 
   // ---- car<->car contacts of this env (manifolds prepared by the collide kernel).  The common case — no
@@ -584,13 +592,20 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
   }
 
   bool positionSolved = false;
-  if (run) {
+  if (run && !resume) {
     // joints, island order 3,2,1,0
 #pragma unroll
     for (int q = 3; q >= 0; --q) joint_init(J[q], b[0], b[q + 1], S.anchor_x[q], S.anchor_y[q], lcx, lcy, mH, iH, mW, iW);
   }
+  if (resume && run && agent == 0) atomicAdd(&p.counters[1], 1ull);
+  if (resume) {   // the position solver needs nothing from InitVelocityConstraints but the motor mass (limit state is stored)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { float mm = iH + iW; if (mm > 0.0f) mm = 1.0f / mm; J[q].motorMass = mm; }
+  }
   const float maxImpulse = h * (float)(180 * 900 * MCR_SIZE * MCR_SIZE);
-  if (!wave_cc) {
+  if (resume) {
+    // velocity phase already done by the main launch
+  } else if (!wave_cc) {
     // hot loop of the common case: nothing but the four revolute joints, state in registers
     if (mode == 1) {
       // reset pass (step(None) on freshly spawned cars): the iteration map is a pure function of (velocities,
@@ -648,7 +663,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
     }
   }
   DYN_STAMP(2);
-  if (run) {
+  if (run && !resume) {
     // integrate positions
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -664,10 +679,19 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
   }
   // position iterations with the per-island early exit
   RotCache hull_rot; hull_rot.a = __int_as_float(0x7fc00000); hull_rot.q.s = 0.0f; hull_rot.q.c = 1.0f;
+  bool unfinished = false;                // deferral: this lane used up the main launch's sweeps without an outcome
   if (!wave_cc) {
     if (run) {
-      const int pos_iters = (p.debug & 64) ? 2 : 60;          // debug bit 6: cap the position iterations (timing experiments only)
-      for (int it = 0; it < pos_iters; ++it) {
+      int it0 = 0, pos_iters = (p.debug & 64) ? 2 : 60;       // debug bit 6: cap the position iterations (timing experiments only)
+      if (defer_cap > 0 && defer_cap < pos_iters) pos_iters = defer_cap;
+      bool stuck = false;
+      if (resume) {
+        const uint32_t stt = p.defer_state[ci];               // 0: keep iterating, 1: solved, 2: failed at a fixed point
+        it0 = (stt == 0u) ? p.defer_after : 60;
+        positionSolved = stt == 1u;
+      }
+      int it = it0;
+      for (; it < pos_iters; ++it) {
         float ox[5], oy[5], oa[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k) { ox[k] = b[k].cx; oy[k] = b[k].cy; oa[k] = b[k].a; }
@@ -684,8 +708,10 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
         bool moved = false;
 #pragma unroll
         for (int k = 0; k < 5; ++k) moved = moved || ox[k] != b[k].cx || oy[k] != b[k].cy || oa[k] != b[k].a;
-        if (!moved) break;
+        if (!moved) { stuck = true; break; }
       }
+      unfinished = defer_cap > 0 && defer_cap < 60 && !positionSolved && !stuck && it == pos_iters;
+      if (defer_cap > 0) p.defer_state[ci] = positionSolved ? 1u : (stuck ? 2u : 0u);
     }
   } else {
     bool active = run;
@@ -750,6 +776,31 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
       }
       __syncthreads();
     }
+  }
+  if (defer_cap > 0) {
+    int dfr = unfinished ? 1 : 0;
+    for (int o = 1; o < p.G; o <<= 1) dfr |= __shfl_xor(dfr, o);          // env-wide: its cars finish the step together
+    if (dfr && run) {
+      // park the post-velocity-phase state exactly as the resume launch's prologue reloads it
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        p.carf[(CF_CX + k) * BN + ci] = b[k].cx; p.carf[(CF_CY + k) * BN + ci] = b[k].cy; p.carf[(CF_A + k) * BN + ci] = b[k].a;
+        p.carf[(CF_VX + k) * BN + ci] = b[k].vx; p.carf[(CF_VY + k) * BN + ci] = b[k].vy; p.carf[(CF_W + k) * BN + ci] = b[k].w;
+      }
+      uint32_t lim = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        p.carf[(CF_JIX + k) * BN + ci] = J[k].ix; p.carf[(CF_JIY + k) * BN + ci] = J[k].iy;
+        p.carf[(CF_JIZ + k) * BN + ci] = J[k].iz; p.carf[(CF_JM + k) * BN + ci] = J[k].im;
+        lim |= (uint32_t)J[k].limit << (2 * k);
+        p.card[(CD_OMEGA + k) * BN + ci] = omega[k]; p.card[(CD_PHASE + k) * BN + ci] = phase[k];
+      }
+      p.caru[CU_LIMIT * BN + ci] = lim;
+      p.card[(CD_GAS + 0) * BN + ci] = gas[0]; p.card[(CD_GAS + 1) * BN + ci] = gas[1];
+      p.card[CD_STEER * BN + ci] = steer; p.card[CD_BRAKE * BN + ci] = brake;
+      if (agent == 0) { p.part[env] = 2; p.dlist[1 + atomicAdd(&p.dlist[0], 1)] = env; atomicAdd(&p.counters[0], 1ull); }   // main reset pass / raster skip it
+    }
+    if (dfr) { run = false; lane_ok = false; }                            // nothing below is this launch's business
   }
   DYN_STAMP(3);
   float minSleep = MCR_MAXFLT;

@@ -150,10 +150,10 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
   // XCD-aware mapping: workgroup b runs on XCD b % 8, so hand the N views of one env to workgroups b, b+8,
   // b+16, ... — they share that XCD's L2 for the env's road_poly instead of fetching it once per XCD.
   int vw;
-  if (p.role == 2) {                 // side stream: views of the envs in clist
-    const int s = blockIdx.x / N;
-    if (s >= p.clist[0]) return;
-    vw = p.clist[1 + s] * N + (int)(blockIdx.x % N);
+  if (p.role >= 2) {                 // side streams / late pass: views of the envs in the contact / deferred lists
+    const int e = mcr_env_of_slot(p, blockIdx.x / N);
+    if (e >= p.env0 + p.nenv) return;
+    vw = e * N + (int)(blockIdx.x % N);
   } else if (p.use_vorder) {         // step path: heavy (zoomed-out) envs first, see k_dynamics
     const int b = blockIdx.x, grp = b / (8 * N), r = b - grp * 8 * N;
     const int idx = grp * 8 + (r & 7), nh = p.vcount[0], nn = p.vcount[1];
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
   if (!es.active) return;
   if (only_just_reset && !es.just_reset) return;
   // side-stream raster: a contact env re-spawned by this step's dynamics is drawn after its (late) reset pass
-  if (p.role == 2 && !only_just_reset && es.resetting) return;
+  if (p.role >= 2 && !only_just_reset && es.resetting) return;
   const uint8_t* __restrict__ slot = p.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES;
   const McrSlotHeader* H = (const McrSlotHeader*)slot;
   const int T = H->T, P = H->P;

@@ -44,8 +44,8 @@ struct mcr_env {
   bool any_reset;
   bool split;                 // contact side stream enabled (cfg.num_streams == 2)
   int step_parity;            // which contact-list buffer the next step fills
-  hipStream_t s_side;         // internal stream of the contact envs' chain
-  hipEvent_t ev_fork, ev_join;
+  hipStream_t s_side, s_defer; // internal streams: the contact envs' chain, the deferred envs' chain
+  hipEvent_t ev_fork, ev_join, ev_fork2, ev_join2;
   float* view_scratch;        // per-view spill area of the rasteriser (zoomed-out frames only)
 };
 
@@ -71,6 +71,9 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   const size_t o_tflags = carve(sizeof(uint16_t) * MCR_TILE_CAP * (size_t)B);
   const size_t o_cc = carve(sizeof(uint32_t) * (size_t)B * (MCR_CC_MAX * MCR_CC_WORDS + 4));
   const size_t o_part = carve(B);
+  const size_t o_dlist = carve(sizeof(int32_t) * ((size_t)B + 1));
+  const size_t o_dstate = carve(BN);
+  const size_t o_counters = carve(sizeof(unsigned long long) * 4);
   const size_t o_vorder = carve(sizeof(int32_t) * ((size_t)B + 2));
   const size_t o_stamps = carve(sizeof(unsigned long long) * 8 * ((((size_t)B * G + 63) / 64) + (size_t)B));
   const size_t o_clist = carve(sizeof(int32_t) * 2 * ((size_t)B + 1));
@@ -91,7 +94,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   P.cc_store = (uint32_t*)(base + o_cc); P.shapes = (const McrShapes*)(base + o_shapes); P.slots = base + o_slots;
   h->view_scratch = (float*)(base + o_vscratch);
   P.viewp = (float*)(base + o_viewp);
-  P.part = base + o_part; P.vcount = (int32_t*)(base + o_vorder); P.vorder = P.vcount + 2; P.dbg_stamps = (unsigned long long*)(base + o_stamps); P.clist = (int32_t*)(base + o_clist);
+  P.part = base + o_part; P.dlist = (int32_t*)(base + o_dlist); P.defer_state = base + o_dstate; P.counters = (unsigned long long*)(base + o_counters); P.vcount = (int32_t*)(base + o_vorder); P.vorder = P.vcount + 2; P.dbg_stamps = (unsigned long long*)(base + o_stamps); P.clist = (int32_t*)(base + o_clist);
   P.carpoly = (float*)(base + o_carpoly);
   P.auto_reset = cfg->auto_reset; P.max_steps = cfg->max_episode_steps; P.car_contacts = cfg->car_contacts;
   P.backwards_flag = cfg->backwards_flag; P.use_ego_color = cfg->use_ego_color; P.h_ratio = cfg->h_ratio;
@@ -114,8 +117,11 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
     // highest priority: its few workgroups must not queue behind the main stream's saturating raster launch
     int prio_lo = 0, prio_hi = 0; (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     if (hipStreamCreateWithPriority(&h->s_side, hipStreamNonBlocking, prio_hi) == hipSuccess) {
-      (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
-      h->split = true;
+      if (hipStreamCreateWithPriority(&h->s_defer, hipStreamNonBlocking, prio_hi) == hipSuccess) {
+        (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming);
+        h->split = true;
+      } else (void)hipStreamDestroy(h->s_side);
     }
     (void)hipGetLastError();
   }
@@ -130,7 +136,10 @@ extern "C" int mcr_destroy(mcr_env* h) {
   (void)hipDeviceSynchronize();
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : h->free_events) (void)hipEventDestroy(e);
-  if (h->split) { (void)hipStreamDestroy(h->s_side); (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); }
+  if (h->split) {
+    (void)hipStreamDestroy(h->s_side); (void)hipStreamDestroy(h->s_defer);
+    (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_fork2); (void)hipEventDestroy(h->ev_join2);
+  }
   (void)hipFree(h->slab);
   (void)hipHostFree(h->consumed_host);
   delete[] h->consumed_seen;
@@ -182,17 +191,23 @@ static void launch_reset(mcr_env* h, McrParams P, hipStream_t st) {
 }
 
 // step(): collide -> dynamics [-> auto-reset pass] -> view on the caller's stream `st`.
-// With the contact side stream, the envs that k_collide found in car<->car contact run dynamics -> view on
-// h->s_side concurrently with the chain of all the others on `st` (grids are sized for the worst case, surplus
-// workgroups exit on their first load).  A contact env that ended its episode in this very step (rare) is finished
-// on `st` after the join: its reset pass + first frame, three launches that exit at once in every other step.
+// With num_streams == 2 the step forks into three chains that meet again at the end (grids are sized for the worst
+// case, surplus workgroups exit on their first load):
+//   st      : collide(all) -+-> dynamics(main envs, 6 position sweeps) -+-> reset pass -> view(main envs) -+-> late reset pass
+//   s_side  :               +-> dynamics(contact envs) -> view(contact envs) ------------------------------+
+//   s_defer :                                                          +-> dynamics(resume deferred envs) -> view(them) --+
+// Contact envs: a wavefront holding a touching car<->car pair takes 2-4x as long as the others.  Deferred envs: the
+// few whose position loop is still iterating after 6 sweeps (a slow marginal crawl that would hold the whole main
+// launch for up to 60).  s_defer's dynamics starts while the GPU is nearly idle (the reset pass), so it finds free
+// SIMDs at once.  An env of either list that ended its episode in this step (rare) gets its reset pass + first frame
+// in the "late" pass on `st`: three launches that exit at once in every other step.
 static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags) {
   const int B = P.B, N = P.N;
   const int dyn_blocks = (B * P.G + 63) / 64;
-  const int side_blocks = (B + MCR_SIDE_ENVS_PER_WAVE - 1) / MCR_SIDE_ENVS_PER_WAVE;   // role 2: few envs per wavefront
+  const int side_blocks = (B + MCR_SIDE_ENVS_PER_WAVE - 1) / MCR_SIDE_ENVS_PER_WAVE;   // list launches: few envs per wavefront
   const size_t view_lds = (size_t)N * 12 * 6 * 16;
   const bool draw = P.obs || view_flags;
-  P.role = 0; P.split = h->split ? 1 : 0;
+  P.role = 0; P.split = h->split ? 1 : 0; P.defer_after = 0;
   if (h->split) {      // the contact list is double-buffered by step parity; no memset on the critical path
     int32_t* base = h->P.clist;
     P.clist = base + (size_t)(h->step_parity) * (B + 1); P.clist_next = base + (size_t)(h->step_parity ^ 1) * (B + 1);
@@ -201,6 +216,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), st, P, 0);
   P.split = 0;
   if (h->split) {
+    P.defer_after = MCR_DEFER_AFTER;
     (void)hipEventRecord(h->ev_fork, st);
     (void)hipStreamWaitEvent(h->s_side, h->ev_fork, 0);
     P.role = 2;
@@ -210,6 +226,15 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     P.role = 1;
   }
   LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 0);
+  if (h->split) {
+    (void)hipEventRecord(h->ev_fork2, st);
+    (void)hipStreamWaitEvent(h->s_defer, h->ev_fork2, 0);
+    P.role = 3;
+    LAUNCH(7, k_dynamics, side_blocks, 64, h->s_defer, P, 0);
+    if (draw) LAUNCH_LDS(7, k_view, B * N, VIEW_THREADS, view_lds, h->s_defer, P, h->view_scratch, view_flags, 0);
+    (void)hipEventRecord(h->ev_join2, h->s_defer);
+    P.role = 1;
+  }
   if (P.auto_reset) {   // envs re-spawned by pass 0 take the action-less first step of their new episode (:408)
     LAUNCH_LDS(3, k_collide, B, 64, col::lds_bytes(N), st, P, 1);
     LAUNCH(4, k_dynamics, dyn_blocks, 64, st, P, 1);
@@ -219,8 +244,9 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   P.use_vorder = 0;
   if (h->split) {
     (void)hipStreamWaitEvent(st, h->ev_join, 0);
+    (void)hipStreamWaitEvent(st, h->ev_join2, 0);
     if (P.auto_reset) {
-      P.role = 2;
+      P.role = 4;
       LAUNCH_LDS(7, k_collide, B, 64, col::lds_bytes(N), st, P, 1);
       LAUNCH(7, k_dynamics, side_blocks, 64, st, P, 1);
       if (draw) LAUNCH_LDS(7, k_view, B * N, VIEW_THREADS, view_lds, st, P, h->view_scratch, view_flags, 1);
@@ -387,6 +413,12 @@ extern "C" int mcr_debug_read_view_scratch(mcr_env* h, int view, void* out, int 
   if (!h || !out) return MCR_ERR_ARG;
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(out, h->view_scratch + (size_t)(view + 1) * VIEW_SCRATCH_FLOATS - 64, nbytes, hipMemcpyDeviceToHost));
+  return MCR_OK;
+}
+extern "C" int mcr_debug_read_counters(mcr_env* h, uint64_t* out4) {
+  if (!h || !out4) return MCR_ERR_ARG;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out4, h->P.counters, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost));
   return MCR_OK;
 }
 extern "C" int mcr_debug_read_contact_counts(mcr_env* h, int32_t* out) {

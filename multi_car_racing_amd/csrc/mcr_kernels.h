@@ -24,10 +24,14 @@ struct McrParams {
   int32_t* clist;               // [1+B] count, then the env ids of the side-stream envs (any order); this step's buffer
   int32_t* clist_next;          // the other buffer (steps alternate): its count is zeroed by this step's main k_dynamics
   int32_t split;                // k_collide pass 0 fills part/clist
+  int32_t* dlist;               // [1+B] count + env ids deferred by the main k_dynamics (zeroed by k_collide pass 0)
+  uint8_t* defer_state;         // [BN] per car: 0 keep iterating, 1 position loop solved, 2 failed at a fixed point
+  unsigned long long* counters; // [4] diagnostics: 0 envs deferred, 1 envs resumed, 2 contact envs routed to the side stream
+  int32_t defer_after;          // position sweeps the main launch grants before it defers an env (0: never)
   int32_t* vorder;              // [B] raster order of the main launch: heavy envs from the front, the others from the back
   int32_t* vcount;              // [2] number of heavy / other envs in vorder (zeroed by k_collide pass 0)
   int32_t use_vorder;           // k_view maps workgroups to envs through vorder (step path, roles 0/1)
-  int32_t role;                 // 0: every env; 1: main stream (skips part envs); 2: side stream (walks clist)
+  int32_t role;                 // 0: every env; 1: main stream (skips part envs); 2: contact envs (clist); 3: deferred envs (dlist); 4: both lists
   // step I/O
   const float* actions;         // [B,N,3] or null
   uint8_t* obs;                 // [B,N,96,96,3] or null
@@ -57,6 +61,8 @@ __device__ __forceinline__ int mcr_env_of_slot(const McrParams& p, int s) {
   const int end = p.env0 + p.nenv;
   if (s < 0) return end;
   if (p.role == 2) return s < p.clist[0] ? p.clist[1 + s] : end;
+  if (p.role == 3) return s < p.dlist[0] ? p.dlist[1 + s] : end;
+  if (p.role == 4) { const int nc = p.clist[0]; return s < nc ? p.clist[1 + s] : (s - nc < p.dlist[0] ? p.dlist[1 + s - nc] : end); }
   const int env = p.env0 + s;
   if (env >= end) return end;
   return (p.role == 1 && p.part[env]) ? end : env;
@@ -65,9 +71,10 @@ __device__ __forceinline__ int mcr_env_of_slot(const McrParams& p, int s) {
 // holds car<->car contacts): MCR_SIDE_ENVS_PER_WAVE envs per wavefront, so that the wavefront's LDS pool of contact
 // constraints (DYN_VC_POOL = MCR_SIDE_ENVS_PER_WAVE * MCR_CC_MAX) can never overflow, however the envs are packed.
 #define MCR_SIDE_ENVS_PER_WAVE 2
+#define MCR_DEFER_AFTER 6          // position sweeps the main dynamics launch grants an env before deferring it (99.9 % need 1)
 __device__ __forceinline__ int mcr_dyn_slot(const McrParams& p) {
   const int grp = (int)threadIdx.x / p.G;
-  if (p.role == 2) return grp < MCR_SIDE_ENVS_PER_WAVE ? (int)blockIdx.x * MCR_SIDE_ENVS_PER_WAVE + grp : -1;
+  if (p.role >= 2) return grp < MCR_SIDE_ENVS_PER_WAVE ? (int)blockIdx.x * MCR_SIDE_ENVS_PER_WAVE + grp : -1;
   return ((int)blockIdx.x * 64 + (int)threadIdx.x) / p.G;
 }
 #define MCR_CC_MAX 24           // touching car<->car fixture pairs kept per env (warm start)
