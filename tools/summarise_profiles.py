@@ -3,7 +3,7 @@
 A step of the default configuration issues several launches of the same kernel (main chain, contact side stream,
 reset passes), so launches are labelled by their position in the step: on the caller's queue the order is
 collide dynamics collide(reset) dynamics(reset) view [collide dynamics view](late reset of contact envs);
-on the side queue dynamics view."""
+on the side queue dynamics view; on the third queue dynamics(resume) view."""
 import json, os, sys
 import pandas as pd
 
@@ -28,6 +28,7 @@ MAIN_ORDER = {"k_collide": ["collide", "collide (reset pass)", "collide (late re
               "k_dynamics": ["dynamics (main envs)", "dynamics (reset pass)", "dynamics (late reset, contact envs)"],
               "k_view": ["view (main envs)", "view (late reset, contact envs)"]}
 SIDE_ORDER = {"k_dynamics": ["dynamics (contact envs, side stream)"], "k_view": ["view (contact envs, side stream)"]}
+DEFER_ORDER = {"k_dynamics": ["dynamics (resume of deferred envs, third stream)"], "k_view": ["view (deferred envs, third stream)"]}
 
 def label(df, order_col):
     """adds column Label for the launches of the last STEPS steps.  A step is three k_collide launches on the caller's
@@ -41,6 +42,12 @@ def label(df, order_col):
         return df
     qcount = df.loc[col, "Queue_Id"].value_counts()
     main_q = qcount.index[0]
+    # of the two internal queues, the contact side stream is the one whose k_dynamics launches take longer in total
+    dq = df[(df.K == "k_dynamics") & (df.Queue_Id != main_q)]
+    side_q = None
+    if len(dq):
+        if "End_Timestamp" in dq.columns: side_q = (dq.End_Timestamp - dq.Start_Timestamp).groupby(dq.Queue_Id).sum().idxmax()
+        else: side_q = dq.Queue_Id.value_counts().index[0]
     col = [i for i in col if df.at[i, "Queue_Id"] == main_q]
     if len(col) < 3 * STEPS:
         return df
@@ -50,9 +57,10 @@ def label(df, order_col):
         for i in range(a, e):
             k = df.at[i, "K"]
             if k not in ("k_collide", "k_dynamics", "k_view"): continue
-            on_main = df.at[i, "Queue_Id"] == main_q
-            key = (k, on_main); n = seen.get(key, 0); seen[key] = n + 1
-            names = (MAIN_ORDER if on_main else SIDE_ORDER).get(k, [])
+            q = df.at[i, "Queue_Id"]
+            on_main = q == main_q
+            key = (k, q); n = seen.get(key, 0); seen[key] = n + 1
+            names = (MAIN_ORDER if on_main else (SIDE_ORDER if q == side_q else DEFER_ORDER)).get(k, [])
             df.at[i, "Label"] = names[n] if n < len(names) else f"{k} #{n}"
     return df
 
