@@ -7,9 +7,11 @@
 // Reference: multi_car_racing.py:418-429; gym car_dynamics.py Car.{steer,gas,brake,step};
 // Box2D 2.3 b2Island::Solve, b2RevoluteJoint::{Init,Solve}VelocityConstraints/SolvePositionConstraints.
 //
-// State lives in registers for the whole step (~110 VGPRs): the 180x4 joint iterations are a serial
-// dependency chain, so the kernel is VALU-latency bound, not HBM bound; loads/stores are one coalesced
-// 4- or 8-byte access per SoA field per lane.
+// State lives in registers for the whole step (256 VGPRs, one wavefront per SIMD): the 180x4 joint iterations are
+// a serial dependency chain, so the kernel is bound by the VALU issue of a single wave, not by HBM; loads/stores are
+// one coalesced 4- or 8-byte access per SoA field per lane.  The launch lasts as long as its slowest wavefront,
+// which is why envs with car<->car contacts (role 2) and envs with a crawling position loop (deferral, role 3)
+// run in launches of their own on other streams (mcr_hip.hip: launch_step).
 #pragma once
 #include "mcr_kernels.h"
 #include "k_carcontacts.h"

@@ -2,20 +2,22 @@
 // rasteriser that replaces pyglet/OpenGL (multi_car_racing.py:511-604, 613-674; gym Car.draw), plus the
 // per-agent backward/on-grass bookkeeping of :446-495 (its result only reaches pixels one step later).
 //
-// HBM traffic per view: read the env's road_poly once (2 x float4 + u32 per quad, coalesced), ~50 scalars of
-// car state, write 27,648 B of packed RGB with 16-byte-per-lane stores.  Everything else lives in ~30 KB of
-// LDS so that 5 workgroups (20 waves) share a CU:
-//   1. camera (:540-556) -> 2x3 world->pixel matrix (f32, like the GL pipeline);
-//   2. cull in two passes: every thread transforms its quads and rejects by pixel bbox (incl. "contains no
-//      pixel centre"), survivors are ballot-compacted; then consecutive threads set the survivors up (oriented
-//      edge equations -> LDS, rare overflow spills to a per-view HBM scratch).  Car polygons arrive as world
-//      vertices from k_dynamics (12 per car).  The backward/on-grass bookkeeping rides on the same quad pass:
-//      f32 prefilter on the quads already in registers, exact f64 only for the 1-3 candidates;
-//   3. bin: the thread that set a polygon up appends it to the lists of the 8x8-pixel bins it can touch
-//      (box-vs-convex test, LDS atomics; order is irrelevant because the highest draw index wins);
-//   4. shade: one wave per bin, lane = pixel; list walking is wave-uniform (LDS broadcast reads).  Background
-//      (playfield + checker) is analytic in world space; road/kerb: highest road_poly index wins (== painter's
-//      order); then cars; then the HUD in window space.  Result: one palette index per pixel (u8 framebuffer);
+// HBM traffic per view: read the env's road_poly once (2 x float4 + u32 per quad, coalesced), the camera / HUD record
+// and the car polygons k_dynamics prepared, write 27,648 B of packed RGB as dwordx3 stores.  Everything else lives
+// in ~25 KB of LDS so that 5 workgroups (20 waves) share a CU:
+//   1. workgroup -> view through the raster order list of k_dynamics (zoomed-out "heavy" envs first), XCD-aware so
+//      that the N views of an env share one XCD's L2;
+//   2. cull in two passes: every thread transforms its quads and rejects by pixel bbox (incl. "contains no pixel
+//      centre"), survivors are ballot-compacted; then consecutive threads set the survivors up (oriented edge
+//      equations -> LDS, rare overflow spills to a per-view HBM scratch).  Car polygons arrive as padded 8-gons in
+//      world space (12 per car).  The backward/on-grass bookkeeping rides on the same quad pass: f32 prefilter on
+//      the quads already in registers, exact f64 only for the 1-3 candidates;
+//   3. bin: the thread that set a polygon up appends it to the lists of the 8x16-pixel bins it can touch
+//      (box-vs-convex test, LDS atomics; order is irrelevant because the highest draw key wins);
+//   4. shade: one wave per bin, each lane two pixels (rows y, y+8 share every edge product); bin ids, list
+//      lengths and entries are wave-uniform (one vector LDS read per list + v_readlane).  Background (playfield +
+//      checker) is analytic and classified per bin; road/kerb: highest road_poly index wins (== painter's order);
+//      then cars; then the HUD in window space (scalar bin-column ranges).  Result: one palette index per pixel;
 //   5. write-out: 4 pixels (one aligned palette word) -> 12 packed RGB bytes per lane, contiguous across lanes.
 // Sampling rule: pixel centres; a pixel belongs to a convex polygon iff all oriented edge functions are >= 0.
 #pragma once
