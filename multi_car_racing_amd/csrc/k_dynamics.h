@@ -393,8 +393,8 @@ __device__ inline float cc_position(const McrShapes& S, const uint32_t* rec, int
 // mode 0: regular step (bookkeeping, TimeLimit, auto-reset install)
 // mode 1: the action-less step of reset() (:408) for envs whose `resetting` flag is set
 // debug bit 8 (256): lane 0 of every wavefront stamps the clock per phase (0 start, 1 state loaded + Car.step +
-// velocity integration, 2 velocity sweeps done, 3 position loop done, 4 end) into p.dbg_stamps[role==2][block][8]
-#define DYN_STAMP(i) do { if ((p.debug & 256) && mode == 0 && threadIdx.x == 0) p.dbg_stamps[((p.role >= 2 ? (p.B * p.G + 63) / 64 : 0) + blockIdx.x) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+// velocity integration, 2 velocity sweeps done, 3 position loop done, 4 end) into p.dbg_stamps[block][8] (main launch, then the launches of roles 2, 3, 4)
+#define DYN_STAMP(i) do { if ((p.debug & 256) && mode == 0 && threadIdx.x == 0) p.dbg_stamps[((p.role >= 2 ? (p.B * p.G + 63) / 64 + (p.role - 2) * ((p.B + 1) / 2) : 0) + blockIdx.x) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
   using namespace dyn;
   DYN_STAMP(0);
@@ -402,6 +402,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
   // LDS used only by waves that contain a touching car<->car pair
   __shared__ float xv[15][64], xp[15][64];            // body exchange: (vx,vy,w) / (cx,cy,a) x 5 bodies per lane
   __shared__ __attribute__((aligned(16))) float vcpool[DYN_VC_POOL][cc::VC_SIZE];
+  __shared__ uint32_t pcrec[DYN_VC_POOL][16];      // manifold records (key, type|n, local normal/point, 2 points) for the position sweeps
   __shared__ int xisl[64], xact[64], xjok[64], xcok[64];
   __shared__ float xms[64];
   const int g = blockIdx.x * 64 + threadIdx.x;
@@ -558,6 +559,8 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
       for (int i = 0; i < ccn; ++i) {
         const uint32_t* rec = store + 4 + i * MCR_CC_WORDS;
         cc_init(S, rec, i, leader_lane, xp, xv, vcpool[pool_base + i]);
+#pragma unroll
+        for (int w = 0; w < 16; ++w) pcrec[pool_base + i][w] = rec[w];      // once per step instead of one HBM round trip per sweep
         // union-find over cars (b2World::Solve island DFS through touching contacts)
         const int ca = rec[0] & 15, cb = (rec[0] >> 8) & 15;
         int ra = ca, rb = cb;
@@ -736,7 +739,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
 #pragma unroll
         for (int c = 0; c < MCR_MAX_AGENTS; ++c) minSep[c] = 0.0f;
         for (int i = 0; i < ccn; ++i) {
-          const uint32_t* rec = store + 4 + i * MCR_CC_WORDS;
+          const uint32_t* rec = pcrec[pool_base + i];
           const int ca = rec[0] & 15;
           const int r = xisl[leader_lane + ca];
           if (!xact[leader_lane + r]) continue;

@@ -75,7 +75,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   const size_t o_dstate = carve(BN);
   const size_t o_counters = carve(sizeof(unsigned long long) * 4);
   const size_t o_vorder = carve(sizeof(int32_t) * ((size_t)B + 2));
-  const size_t o_stamps = carve(sizeof(unsigned long long) * 8 * ((((size_t)B * G + 63) / 64) + (size_t)B));
+  const size_t o_stamps = carve(sizeof(unsigned long long) * 8 * ((((size_t)B * G + 63) / 64) + 2 * (size_t)B));
   const size_t o_clist = carve(sizeof(int32_t) * 2 * ((size_t)B + 1));
   const size_t o_shapes = carve(sizeof(McrShapes));
   const size_t o_viewp = carve(sizeof(float) * MCR_VIEWP_FLOATS * BN);

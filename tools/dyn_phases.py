@@ -11,26 +11,27 @@ g = torch.Generator(device="cuda"); g.manual_seed(1)
 pool = torch.rand((64, B, N, 3), device="cuda", generator=g); pool[..., 0] = pool[..., 0] * 2 - 1
 nb = (B * 2 + 63) // 64
 ns = (B + 1) // 2                      # side stream: 2 envs per wavefront
-buf = np.zeros((nb + ns) * 8, np.uint64)
+buf = np.zeros((nb + 2 * ns) * 8, np.uint64)
 _lib.check(env.L.mcr_debug_set(env.h, 256))
 names = ["load+Car.step+contact init", "velocity sweeps", "position loop", "sleep+bookkeeping+epilogue"]
-acc = {0: [], 1: []}
+acc = {0: [], 1: [], 2: []}
 for k in range(900):
     env.step(pool[k % 64])
     if k >= 300 and k % 10 == 0:
         _lib.check(env.L.mcr_debug_read_dynamics_stamps(env.h, _lib.ptr(buf), len(buf)))
-        allst = buf.reshape(nb + ns, 8).astype(np.int64)
-        for role in (0, 1):
-            st_r = allst[:nb] if role == 0 else allst[nb:]
+        allst = buf.reshape(nb + 2 * ns, 8).astype(np.int64)
+        for role in (0, 1, 2):
+            st_r = allst[:nb] if role == 0 else (allst[nb:nb + ns] if role == 1 else allst[nb + ns:])
             d = np.diff(st_r[:, :5], axis=1)
             tot = st_r[:, 4] - st_r[:, 0]
-            if role == 1:
-                ok = tot > 0
+            if role >= 1:
+                ok = (tot > 0) & (st_r[:, 0] > 0)
                 if not ok.any(): continue
+                tot = np.where(ok, tot, -1)
             w = int(np.argmax(tot))
             acc[role].append(np.concatenate([d[w], [tot[w]]]))
         buf[:] = 0
-for role, nm in ((0, "main stream (slowest wavefront per launch)"), (1, "side stream (slowest wavefront per launch)")):
+for role, nm in ((0, "main stream (slowest wavefront per launch)"), (1, "side stream: contact envs (slowest wavefront per launch)"), (2, "third stream: resumed envs (slowest wavefront per launch)")):
     a = np.array(acc[role], float)
     if len(a) == 0: continue
     print(nm, "- shader clocks at ~2.4 GHz shown as us; n =", len(a))
