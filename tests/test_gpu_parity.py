@@ -127,6 +127,35 @@ def test_backward_flag_and_grass_flags(torch_cuda, oracle):
     env.close()
 
 
+@pytest.mark.parametrize("streams", [1, 2])
+def test_physics_only_mode_matches_oracle(torch_cuda, oracle, streams):
+    """obs disabled (BASELINE config "obs=none"): no observation is written, but the physics, rewards, done and the
+    backward / on-grass bookkeeping the raster kernel owns (:446-495) must be exactly what the full mode computes."""
+    torch = torch_cuda
+    B, N, seed = 6, 2, 17
+    env = _make(B, N, seed, contacts=True, obs=False, streams=streams); assert env.reset() is None
+    orcs = _oracles(oracle, B, N, seed, contacts=True)
+    rng = np.random.RandomState(6)
+    seen = False
+    for k in range(110):
+        a = random_actions(rng, B, N, 0.1)
+        if k > 50:
+            a[..., 0] = 1.0; a[..., 1] = 0.4                              # spin: driving_backward comes up
+        obs, rew, done, _ = env.step(torch.from_numpy(a).cuda())
+        assert obs is None
+        rw, dn = rew.cpu().numpy(), done.cpu().numpy()
+        es = env.get_env_state()
+        for e, o in enumerate(orcs):
+            _, r, d, _ = o.step(a[e], render=False); eo = o.env_state()
+            assert np.array_equal(r, rw[e]) and bool(dn[e]) == d, f"step {k} env {e}"
+            assert np.array_equal(es["driving_backward"][e], eo["driving_backward"]) and np.array_equal(es["driving_on_grass"][e], eo["driving_on_grass"]), (k, e)
+            seen |= bool(eo["driving_backward"].any())
+        if k % 36 == 35:
+            _assert_state_equal(env, orcs, f"physics-only step {k}")
+    assert seen
+    env.close()
+
+
 def test_out_of_playfield_and_done(torch_cuda, oracle):
     """Teleport a car beyond PLAYFIELD: done and step_reward = -100 (:503-507), identical to the oracle."""
     torch = torch_cuda
