@@ -116,6 +116,7 @@ def main():
         _L.check(env.env.L.mcr_debug_set(env.env.h, args.debug_bits))
     env.timing(255 if args.time_all_kernels else 4)
     gen0 = env.env.episodes_generated
+    env.env.rollout_stats(reset=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -140,8 +141,9 @@ def main():
     ms, nl = env.timing_read()
     env.timing(0)
     env.wait_refills()
-    episodes = env.env.episodes_generated - gen0
-    m = reduce_metrics(B * K, elapsed, episodes=episodes)
+    generated = env.env.episodes_generated - gen0
+    episodes, return_sum = env.env.rollout_stats()            # counted on the device: episodes that ended in the timed region
+    m = reduce_metrics(B * K, elapsed, episodes=episodes, return_sum=return_sum)
 
     # roofline of the dominant kernel (view raster): algorithmic bytes per env-step:
     #   N*27648 (obs write) + 36*P (road quads read once per env) + 76*N (car transforms+phases) + 48*N (camera+HUD)
@@ -170,7 +172,8 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: num_agents=%d, batch=%d envs/GPU, %s, random-action rollout, "
                                    "TimeLimit 1000 auto-reset incl. host track generation%s" % (N, B, "96x96 RGB obs" if args.obs else "obs=none", ", episode phases staggered (steady state)" if args.stagger else ", all episodes in phase"),
                        "global_batch": B * world, "parallelism": "env-sharded dp%d (no data-path collective)" % world,
-                       "episodes_reset_in_timed_region": m["episodes"]},
+                       "episodes_reset_in_timed_region": m["episodes"], "mean_episode_return_per_env": (m["return_sum"] / m["episodes"]) if m["episodes"] else None,
+                       "tracks_generated_on_host_in_timed_region_rank0": generated},
             "roofline": roofline,
         }
         if args.time_all_kernels:

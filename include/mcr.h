@@ -108,6 +108,10 @@ int mcr_render(mcr_env* h, int env, int width, int height, uint8_t* d_out, void*
  * episode (done), mcr_step writes the sum of the step rewards of that episode per agent into d_ep_return[B,N] and
  * its length in steps into d_ep_len[B]; other rows are left untouched.  NULL disables either. */
 int mcr_set_episode_stats(mcr_env* h, double* d_ep_return, int32_t* d_ep_len);
+/* Rollout statistics accumulated on the device since creation / the last reset of the counters (synchronises):
+ * out2[0] = episodes finished, out2[1] = sum of their returns over all agents.  These are the per-rank inputs of the
+ * job-wide metric all-reduce. */
+int mcr_read_rollout_stats(mcr_env* h, double* out2, int reset);
 int mcr_poll_consumed(mcr_env* h, int32_t* env_ids_out, int cap, void* stream);
 
 /* ---- state access for differential tests / facade attributes (synchronous) */

@@ -862,6 +862,8 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
       if (done) {
         if (p.ep_return_out) p.ep_return_out[ci] = epret;
         if (p.ep_len_out && agent == 0) p.ep_len_out[env] = es.steps + 1;
+        if (agent == 0) atomicAdd(&p.stats[0], 1.0);
+        atomicAdd(&p.stats[1], epret);
       }
     }
     if (lane_ok && es.active) {

@@ -74,6 +74,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   const size_t o_dlist = carve(sizeof(int32_t) * ((size_t)B + 1));
   const size_t o_dstate = carve(BN);
   const size_t o_counters = carve(sizeof(unsigned long long) * 4);
+  const size_t o_stats = carve(sizeof(double) * 2);
   const size_t o_vorder = carve(sizeof(int32_t) * ((size_t)B + 2));
   const size_t o_stamps = carve(sizeof(unsigned long long) * 8 * ((((size_t)B * G + 63) / 64) + 2 * (size_t)B));
   const size_t o_clist = carve(sizeof(int32_t) * 2 * ((size_t)B + 1));
@@ -94,7 +95,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   P.cc_store = (uint32_t*)(base + o_cc); P.shapes = (const McrShapes*)(base + o_shapes); P.slots = base + o_slots;
   h->view_scratch = (float*)(base + o_vscratch);
   P.viewp = (float*)(base + o_viewp);
-  P.part = base + o_part; P.dlist = (int32_t*)(base + o_dlist); P.defer_state = base + o_dstate; P.counters = (unsigned long long*)(base + o_counters); P.vcount = (int32_t*)(base + o_vorder); P.vorder = P.vcount + 2; P.dbg_stamps = (unsigned long long*)(base + o_stamps); P.clist = (int32_t*)(base + o_clist);
+  P.part = base + o_part; P.dlist = (int32_t*)(base + o_dlist); P.defer_state = base + o_dstate; P.counters = (unsigned long long*)(base + o_counters); P.stats = (double*)(base + o_stats); P.vcount = (int32_t*)(base + o_vorder); P.vorder = P.vcount + 2; P.dbg_stamps = (unsigned long long*)(base + o_stamps); P.clist = (int32_t*)(base + o_clist);
   P.carpoly = (float*)(base + o_carpoly);
   P.auto_reset = cfg->auto_reset; P.max_steps = cfg->max_episode_steps; P.car_contacts = cfg->car_contacts;
   P.backwards_flag = cfg->backwards_flag; P.use_ego_color = cfg->use_ego_color; P.h_ratio = cfg->h_ratio;
@@ -288,6 +289,14 @@ extern "C" int mcr_render(mcr_env* h, int env, int width, int height, uint8_t* d
   const dim3 grid((width + RENDER_TILE - 1) / RENDER_TILE, (height + RENDER_TILE - 1) / RENDER_TILE, P.N);
   hipLaunchKernelGGL(k_render_frame, grid, dim3(256), 0, (hipStream_t)stream, P, env, width, height, d_out);
   HIPCHK(hipGetLastError());
+  return MCR_OK;
+}
+
+extern "C" int mcr_read_rollout_stats(mcr_env* h, double* out2, int reset) {
+  if (!h || !out2) { g_err = "null argument"; return MCR_ERR_ARG; }
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out2, h->P.stats, sizeof(double) * 2, hipMemcpyDeviceToHost));
+  if (reset) HIPCHK(hipMemset(h->P.stats, 0, sizeof(double) * 2));
   return MCR_OK;
 }
 

@@ -26,6 +26,7 @@ struct McrParams {
   int32_t split;                // k_collide pass 0 fills part/clist
   int32_t* dlist;               // [1+B] count + env ids deferred by the main k_dynamics (zeroed by k_collide pass 0)
   uint8_t* defer_state;         // [BN] per car: 0 keep iterating, 1 position loop solved, 2 failed at a fixed point
+  double* stats;                // [2] rollout statistics accumulated on the device: episodes finished, sum of their returns over all agents
   unsigned long long* counters; // [4] diagnostics: 0 envs deferred, 1 envs resumed, 2 contact envs routed to the side stream
   int32_t defer_after;          // position sweeps the main launch grants before it defers an env (0: never)
   int32_t* vorder;              // [B] raster order of the main launch: heavy envs from the front, the others from the back

@@ -212,6 +212,12 @@ class VecMultiCarRacing:
         return self.obs, self.reward, self.done, {"TimeLimit.truncated": self.truncated, "episode_return": self.episode_return,
                                                    "episode_length": self.episode_length}
 
+    def rollout_stats(self, reset=False):
+        """(episodes finished, sum of their returns over all agents) accumulated on the device; synchronises."""
+        out = np.zeros(2)
+        _lib.check(self.L.mcr_read_rollout_stats(self.h, _lib.ptr(out), int(bool(reset))), "mcr_read_rollout_stats")
+        return float(out[0]), float(out[1])
+
     def render_rgb(self, e=0, width=600, height=400):
         """render('rgb_array') of env e: uint8 device tensor [N, height, width, 3] of its CURRENT state (reference
         :511-604 with the VIDEO_W x VIDEO_H viewport; no skid particles, no score label)."""

@@ -194,6 +194,8 @@ def test_time_limit_and_auto_reset(torch_cuda, oracle):
     assert done.all().item() and info["TimeLimit.truncated"].all().item()
     # episode statistics written in the done step: return = sum of the step rewards in summation order, length = L
     assert np.array_equal(info["episode_return"].cpu().numpy(), ret) and (info["episode_length"].cpu().numpy() == L).all()
+    n_ep, ret_sum = env.rollout_stats()                                # device-side accumulators behind reduce_metrics
+    assert n_ep == B and abs(ret_sum - ret.sum()) < 1e-9
     env.wait_refills()
     # oracle: second episode of every env = second draw of its streams
     for e in range(B):
