@@ -26,21 +26,32 @@ struct Joint {
   float rAx, rAy, rBx, rBy;
   float exx, eyx, ezx, eyy, ezy, ezz;   // symmetric K (b2Mat33 m_mass): ex=(exx,eyx,ezx) ey=(eyx,eyy,ezy) ez=(ezx,ezy,ezz)
   float motorMass;
+  // pieces of b2Mat33::Solve33 / Solve22 that depend on K only: Box2D recomputes them in every call, here they are
+  // evaluated once per step with the same expressions (identical values, ~20 instructions less per joint sweep)
+  float cyz0, cyz1, cyz2, idet33, idet22;
 };
 
 __device__ __forceinline__ float d3(float ax, float ay, float az, float bx, float by, float bz) { return ax * bx + ay * by + az * bz; }
 
-// b2Mat33::Solve33 (det recomputed exactly as Box2D does; loop-invariant pieces are CSE'd by the compiler)
+// K-only parts of b2Mat33::Solve33 / Solve22: cross(ey, ez), 1/det (0 stays 0), same expression order as Box2D
+__device__ __forceinline__ void solve_prepare(Joint& J) {
+  const float ex0 = J.exx, ex1 = J.eyx, ex2 = J.ezx, ey0 = J.eyx, ey1 = J.eyy, ey2 = J.ezy, ez0 = J.ezx, ez1 = J.ezy, ez2 = J.ezz;
+  J.cyz0 = ey1 * ez2 - ey2 * ez1; J.cyz1 = ey2 * ez0 - ey0 * ez2; J.cyz2 = ey0 * ez1 - ey1 * ez0;
+  float det = d3(ex0, ex1, ex2, J.cyz0, J.cyz1, J.cyz2);
+  if (det != 0.0f) det = 1.0f / det;
+  J.idet33 = det;
+  float det2 = J.exx * J.eyy - J.eyx * J.eyx;
+  if (det2 != 0.0f) det2 = 1.0f / det2;
+  J.idet22 = det2;
+}
+// b2Mat33::Solve33
 __device__ __forceinline__ void solve33(const Joint& J, float bx, float by, float bz, float& x, float& y, float& z) {
   // ex=(exx,eyx,ezx)  ey=(eyx,eyy,ezy)  ez=(ezx,ezy,ezz)
-  float ex0 = J.exx, ex1 = J.eyx, ex2 = J.ezx;
-  float ey0 = J.eyx, ey1 = J.eyy, ey2 = J.ezy;
-  float ez0 = J.ezx, ez1 = J.ezy, ez2 = J.ezz;
-  // cross(ey, ez)
-  float c0 = ey1 * ez2 - ey2 * ez1, c1 = ey2 * ez0 - ey0 * ez2, c2 = ey0 * ez1 - ey1 * ez0;
-  float det = d3(ex0, ex1, ex2, c0, c1, c2);
-  if (det != 0.0f) det = 1.0f / det;
-  x = det * d3(bx, by, bz, c0, c1, c2);
+  const float ex0 = J.exx, ex1 = J.eyx, ex2 = J.ezx;
+  const float ey0 = J.eyx, ey1 = J.eyy, ey2 = J.ezy;
+  const float ez0 = J.ezx, ez1 = J.ezy, ez2 = J.ezz;
+  const float det = J.idet33;
+  x = det * d3(bx, by, bz, J.cyz0, J.cyz1, J.cyz2);
   // cross(b, ez)
   float p0 = by * ez2 - bz * ez1, p1 = bz * ez0 - bx * ez2, p2 = bx * ez1 - by * ez0;
   y = det * d3(ex0, ex1, ex2, p0, p1, p2);
@@ -50,9 +61,8 @@ __device__ __forceinline__ void solve33(const Joint& J, float bx, float by, floa
 }
 // b2Mat33::Solve22
 __device__ __forceinline__ void solve22(const Joint& J, float bx, float by, float& x, float& y) {
-  float a11 = J.exx, a12 = J.eyx, a21 = J.eyx, a22 = J.eyy;
-  float det = a11 * a22 - a12 * a21;
-  if (det != 0.0f) det = 1.0f / det;
+  const float a11 = J.exx, a12 = J.eyx, a21 = J.eyx, a22 = J.eyy;
+  const float det = J.idet22;
   x = det * (a22 * bx - a12 * by);
   y = det * (a11 * by - a21 * bx);
 }
@@ -78,6 +88,7 @@ __device__ __forceinline__ void joint_init(Joint& J, Body& A, Body& B, float anc
   J.ezz = iA + iB;
   J.motorMass = iA + iB;
   if (J.motorMass > 0.0f) J.motorMass = 1.0f / J.motorMass;
+  solve_prepare(J);
   float jointAngle = B.a - A.a;
   if (jointAngle <= -0.4f) { if (J.limit != 1) J.iz = 0.0f; J.limit = 1; }
   else if (jointAngle >= 0.4f) { if (J.limit != 2) J.iz = 0.0f; J.limit = 2; }
