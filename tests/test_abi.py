@@ -51,3 +51,19 @@ def test_step_path_refuses_cpu(lib):
     from multi_car_racing_amd.vec_env import VecMultiCarRacing
     with pytest.raises(McrError):
         VecMultiCarRacing(4, 2)
+
+
+def test_argument_validation_without_a_gpu(lib):
+    """The C layer never throws or exits: bad arguments come back as negative status codes with a message, before any
+    HIP call is made (so this runs on a CPU-only box)."""
+    L = lib.load()
+    h = ctypes.c_void_p()
+    for B, N in ((0, 2), (4, 0), (4, 9), (-1, 2)):
+        cfg = lib.Config(B, N, 0, 1, 1, 1, 0, 1, 1000, 1, 0.25)
+        assert L.mcr_create(ctypes.byref(cfg), ctypes.byref(h)) < 0 and b"out of range" in L.mcr_last_error()
+    assert L.mcr_create(None, ctypes.byref(h)) < 0
+    assert L.mcr_step(None, None, None, None, None, None, None) < 0
+    assert L.mcr_reset(None, None, None, None) < 0
+    assert L.mcr_render(None, 0, 600, 400, None, None) < 0
+    assert L.mcr_set_episode_stats(None, None, None) < 0
+    assert L.mcr_destroy(None) < 0

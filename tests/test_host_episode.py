@@ -135,3 +135,35 @@ def test_gym_seeding_restatement():
     import pytest
     with pytest.raises(ValueError):
         seeding.np_random(-1)
+
+
+def test_generated_episodes_are_well_formed_over_many_seeds(lib):
+    """Size-independent properties of the host episode generator (:183-338, :366-406) over 300 seeds: capacities hold,
+    the track is a closed loop of ~TRACK_DETAIL_STEP-spaced points inside the playfield, every tile owns one road quad,
+    kerb quads point at a tile, and the cars spawn on the track."""
+    L = lib.load()
+    n, N = 300, 4
+    mt_t = np.zeros((n, lib.MT_WORDS), np.uint32); mt_d = np.zeros((n, lib.MT_WORDS), np.uint32)
+    for e in range(n):
+        L.mcr_mt_seed(lib.ptr(mt_t[e]), ctypes.c_uint32(1000 + e)); L.mcr_mt_seed(lib.ptr(mt_d[e]), ctypes.c_uint32(5000 + e))
+    blobs = np.empty((n, lib.episode_bytes()), np.uint8); info = np.zeros((n, 12), np.int32)
+    lib.check(L.mcr_episodes_generate(lib.ptr(mt_t), lib.ptr(mt_d), n, N, 2, lib.ptr(blobs), lib.ptr(info), 4))
+    dirs = set()
+    for e in range(n):
+        ep = lib.unpack_episode(blobs[e])
+        T, P = ep["T"], ep["P"]
+        assert 150 <= T <= 512 and T <= P <= 768 and info[e, 0] == T and info[e, 1] == P
+        xy = ep["track"][:, :2]
+        assert np.isfinite(ep["track"]).all() and np.isfinite(ep["quads"]).all()
+        assert np.abs(xy).max() < 2000 / 6.0                                       # inside PLAYFIELD
+        d = np.linalg.norm(np.diff(np.vstack([xy, xy[:1]]), axis=0), axis=1)       # closed loop incl. the seam
+        assert np.allclose(d[:-1], 3.5, atol=1e-6) and d[-1] < 30.0               # TRACK_DETAIL_STEP apart; the seam is looser (:262-268)
+        tiles = (ep["quad_meta"] >> 8) & 0x3ff
+        owners = ep["quad_meta"] >> 18
+        assert np.array_equal(np.sort(tiles[tiles > 0]), np.arange(1, T + 1))       # every tile exactly one road quad
+        assert ((tiles > 0) | ((owners >= 1) & (owners <= T))).all()               # kerbs reference their tile
+        sp = ep["spawn"][:N]
+        dist = np.linalg.norm(sp[:, None, 1:3] - xy[None], axis=2).min(1)
+        assert (dist < 8.0).all()                                                  # spawned within the road's half width + lateral offset
+        dirs.add(ep["cw"])
+    assert dirs == {True, False}                                                   # use_random_direction draws both
