@@ -108,6 +108,7 @@ __device__ __forceinline__ bool box_may_touch(const float* e, int n, float X0, f
   }
   return !out;
 }
+typedef float f2 __attribute__((ext_vector_type(2)));     // pixel pairs for packed-f32 arithmetic (v_pk_fma_f32)
 #define UNI(x) __builtin_amdgcn_readfirstlane(x)
 // per-phase s_memtime stamps of thread 0 (debug bit 32) into the tail of the view's spill area
 #define PHASE_STAMP(i) do { if ((dbg & 32) && tid == 0) ((unsigned long long*)(spill + VIEW_SCRATCH_FLOATS - 64))[i] = __builtin_readcyclecounter(); } while (0)
@@ -497,6 +498,7 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
       const int list_v = (int)bins[b][lane < BIN_CAP ? lane : 0];
       const float fbx = (float)(bxi * 8), fby = (float)(byi * 16);
       const float cx = fbx + flx, cy0 = fby + fly, cy1 = cy0 + 8.0f;    // pixel centres, GL coords (origin bottom-left)
+      const f2 cxx = {cx, cx}, cyy = {cy0, cy1};
       uint32_t col0 = PAL_BLACK, col1 = PAL_BLACK;
       const int ucol = __builtin_amdgcn_readlane(ucol_v, it);
       if (ucol != 0xff) col0 = col1 = (uint32_t)ucol;
@@ -509,12 +511,15 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
       // highest draw index covering the pixel wins (painter's order): road_poly index, then car polygons
       const int cnt = __builtin_amdgcn_readlane(cnt_v, it);
       int best0 = -1, best1 = -1;
+      // both pixels of the lane share every edge's coefficients: packed f32 FMAs (v_pk_fma_f32) evaluate an edge
+      // function at (cx, cy0) and (cx, cy1) in one instruction
+#define PKF(A, X, Y) __builtin_elementwise_fma((f2){(A), (A)}, (X), (Y))
 #define EDGE4_2PX(r0, r1, r2, in0, in1)                                                                                   \
       {                                                                                                                  \
-        const float e0 = FMA(r0.x, cx, FMA(r0.y, cy0, r0.z)), e1 = FMA(r0.w, cx, FMA(r1.x, cy0, r1.y)),                  \
-                    e2 = FMA(r1.z, cx, FMA(r1.w, cy0, r2.x)), e3 = FMA(r2.y, cx, FMA(r2.z, cy0, r2.w));                  \
-        in0 = fminf(fminf(e0, e1), fminf(e2, e3)) >= 0.0f;                                                               \
-        in1 = fminf(fminf(FMA(8.0f, r0.y, e0), FMA(8.0f, r1.x, e1)), fminf(FMA(8.0f, r1.w, e2), FMA(8.0f, r2.z, e3))) >= 0.0f; \
+        const f2 e0 = PKF(r0.x, cxx, PKF(r0.y, cyy, ((f2){r0.z, r0.z}))), e1 = PKF(r0.w, cxx, PKF(r1.x, cyy, ((f2){r1.y, r1.y}))),  \
+                 e2 = PKF(r1.z, cxx, PKF(r1.w, cyy, ((f2){r2.x, r2.x}))), e3 = PKF(r2.y, cxx, PKF(r2.z, cyy, ((f2){r2.w, r2.w})));  \
+        in0 = fminf(fminf(e0.x, e1.x), fminf(e2.x, e3.x)) >= 0.0f;                                                       \
+        in1 = fminf(fminf(e0.y, e1.y), fminf(e2.y, e3.y)) >= 0.0f;                                                       \
       }
       if (cnt <= BIN_CAP) {
         for (int k = 0; k < cnt; ++k) {
@@ -564,6 +569,7 @@ __global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __
         }
       }
 #undef EDGE4_2PX
+#undef PKF
 #undef FMA
       if (best0 >= 0) col0 = (uint32_t)best0 & 31u;
       if (best1 >= 0) col1 = (uint32_t)best1 & 31u;
