@@ -212,6 +212,12 @@ class VecMultiCarRacing:
         return self.obs, self.reward, self.done, {"TimeLimit.truncated": self.truncated, "episode_return": self.episode_return,
                                                    "episode_length": self.episode_length}
 
+    def debug_counters(self):
+        """cumulative [envs deferred, envs resumed, contact envs routed to the side stream, -] (synchronises)"""
+        out = np.zeros(4, np.uint64)
+        _lib.check(self.L.mcr_debug_read_counters(self.h, _lib.ptr(out)), "mcr_debug_read_counters")
+        return out
+
     def rollout_stats(self, reset=False):
         """(episodes finished, sum of their returns over all agents) accumulated on the device; synchronises."""
         out = np.zeros(2)
