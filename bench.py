@@ -179,7 +179,8 @@ def main():
                                    "TimeLimit 1000 auto-reset incl. host track generation%s" % (N, B, "96x96 RGB obs" if args.obs else "obs=none", ", episode phases staggered (steady state)" if args.stagger else ", all episodes in phase"),
                        "global_batch": B * world, "parallelism": "env-sharded dp%d (no data-path collective)" % world,
                        "episodes_reset_in_timed_region": m["episodes"], "mean_episode_return_per_env": (m["return_sum"] / m["episodes"]) if m["episodes"] else None,
-                       "tracks_generated_on_host_in_timed_region_rank0": generated},
+                       "tracks_generated_on_host_in_timed_region_rank0": generated,
+                       "env_steps_frozen_waiting_for_host_rank0": int(env.env.debug_counters()[3] - ctr0[3])},
             "roofline": roofline,
         }
         if args.time_all_kernels:

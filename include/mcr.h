@@ -146,7 +146,8 @@ int mcr_debug_read_view_scratch(mcr_env* h, int view, void* out, int nbytes);
 /* debug bit 8 (256): k_dynamics stamps the clock per phase, [2 roles][blocks][8]; read n_u64 words of it */
 int mcr_debug_read_dynamics_stamps(mcr_env* h, uint64_t* out, int n_u64);
 /* cumulative diagnostics of the multi-stream step: [0] envs deferred by the main dynamics launch, [1] envs resumed,
- * [2] contact envs routed to the side stream, [3] unused */
+ * [2] contact envs routed to the side stream, [3] env-steps frozen because the host had not staged the next episode yet
+ * (a healthy rollout keeps this at 0) */
 int mcr_debug_read_counters(mcr_env* h, uint64_t* out4);
 /* number of touching car<->car fixture pairs (stored manifolds) per env after the last collide pass */
 int mcr_debug_read_contact_counts(mcr_env* h, int32_t* out /*[num_envs]*/);

@@ -899,7 +899,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
         E->t = es.t + 1.0 / MCR_FPS;
         if (p.actions) E->steps = es.steps + 1;
         E->just_reset = 0;
-        if (done && p.auto_reset) E->active = 0;      // no staged episode: freeze until mcr_reset
+        if (done && p.auto_reset) { E->active = 0; atomicAdd(&p.counters[3], 1ull); }   // no staged episode yet (host refill late): freeze until it arrives
       }
       // raster launch order: zoomed-out frames (first second of an episode, :540-542) cost several times a normal
       // one, so their workgroups go FIRST (front of vorder) and cannot end up as the launch's tail
@@ -1039,6 +1039,12 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
   }   // run
   DYN_STAMP(4);
 
+}
+
+// mcr_stage_episodes: the staged slots of envs ids[0..n) (all envs when ids == nullptr) hold a fresh episode now
+__global__ void k_mark_staged(McrParams p, const int32_t* __restrict__ ids, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p.env[ids ? ids[i] : i].staged_ready = 1;
 }
 
 // Explicit reset(): install the staged episode for masked envs and spawn the cars; the caller then

@@ -44,6 +44,7 @@ struct mcr_env {
   bool any_reset;
   bool split;                 // contact side stream enabled (cfg.num_streams == 2)
   int step_parity;            // which contact-list buffer the next step fills
+  int32_t* stage_ids;         // [B] device scratch of mcr_stage_episodes
   hipStream_t s_side, s_defer; // internal streams: the contact envs' chain, the deferred envs' chain
   hipEvent_t ev_fork, ev_join, ev_fork2, ev_join2;
   float* view_scratch;        // per-view spill area of the rasteriser (zoomed-out frames only)
@@ -74,6 +75,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   const size_t o_dlist = carve(sizeof(int32_t) * ((size_t)B + 1));
   const size_t o_dstate = carve(BN);
   const size_t o_counters = carve(sizeof(unsigned long long) * 4);
+  const size_t o_stage_ids = carve(sizeof(int32_t) * (size_t)B);
   const size_t o_stats = carve(sizeof(double) * 2);
   const size_t o_vorder = carve(sizeof(int32_t) * ((size_t)B + 2));
   const size_t o_stamps = carve(sizeof(unsigned long long) * 8 * ((((size_t)B * G + 63) / 64) + 2 * (size_t)B));
@@ -95,7 +97,8 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   P.cc_store = (uint32_t*)(base + o_cc); P.shapes = (const McrShapes*)(base + o_shapes); P.slots = base + o_slots;
   h->view_scratch = (float*)(base + o_vscratch);
   P.viewp = (float*)(base + o_viewp);
-  P.part = base + o_part; P.dlist = (int32_t*)(base + o_dlist); P.defer_state = base + o_dstate; P.counters = (unsigned long long*)(base + o_counters); P.stats = (double*)(base + o_stats); P.vcount = (int32_t*)(base + o_vorder); P.vorder = P.vcount + 2; P.dbg_stamps = (unsigned long long*)(base + o_stamps); P.clist = (int32_t*)(base + o_clist);
+  P.part = base + o_part; P.dlist = (int32_t*)(base + o_dlist); P.defer_state = base + o_dstate; P.counters = (unsigned long long*)(base + o_counters); P.stats = (double*)(base + o_stats);
+  h->stage_ids = (int32_t*)(base + o_stage_ids); P.vcount = (int32_t*)(base + o_vorder); P.vorder = P.vcount + 2; P.dbg_stamps = (unsigned long long*)(base + o_stamps); P.clist = (int32_t*)(base + o_clist);
   P.carpoly = (float*)(base + o_carpoly);
   P.auto_reset = cfg->auto_reset; P.max_steps = cfg->max_episode_steps; P.car_contacts = cfg->car_contacts;
   P.backwards_flag = cfg->backwards_flag; P.use_ego_color = cfg->use_ego_color; P.h_ratio = cfg->h_ratio;
@@ -155,14 +158,23 @@ extern "C" int mcr_stage_episodes(mcr_env* h, const int32_t* env_ids, int n, con
   // The staged slot of env e is ((installs & 1) ^ 1): slot 0 is "current" before the first install and every
   // install flips it.  `installs` is read from the mapped-host counter the install wrote; the device cannot
   // install again before this copy lands (staged_ready is 0 until then), so the slot chosen here is free.
-  static const int32_t one = 1;
   for (int i = 0; i < n; ++i) {
     const int e = env_ids ? env_ids[i] : i;
     if (e < 0 || e >= B) { g_err = "env id out of range"; return MCR_ERR_ARG; }
     const int32_t installs = ((volatile int32_t*)h->consumed_host)[e];
     uint8_t* dst = h->P.slots + ((size_t)e * 2 + ((installs & 1) ^ 1)) * MCR_SLOT_BYTES;
     HIPCHK(hipMemcpyAsync(dst, (const uint8_t*)blobs + (size_t)i * MCR_SLOT_BYTES, MCR_SLOT_BYTES, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(&h->P.env[e].staged_ready, &one, sizeof(int32_t), hipMemcpyHostToDevice, st));
+  }
+  // one id upload + one tiny kernel flip the n staged_ready flags (a 4-byte copy per env from pageable memory made
+  // staging a whole batch take longer than generating it)
+  if (n > 0) {
+    const int32_t* d_ids = nullptr;
+    if (env_ids) {
+      HIPCHK(hipMemcpyAsync(h->stage_ids, env_ids, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+      d_ids = h->stage_ids;
+    }
+    hipLaunchKernelGGL(k_mark_staged, dim3((n + 255) / 256), dim3(256), 0, st, h->P, d_ids, n);
+    HIPCHK(hipGetLastError());
   }
   return MCR_OK;
 }

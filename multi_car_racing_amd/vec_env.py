@@ -12,7 +12,9 @@ Determinism: env with global index g uses two numpy-compatible MT19937 streams,
                 direction choice then car order, multi_car_racing.py:351-357)
 so results do not depend on B, on the GPU count, or on scheduling.
 """
+import atexit
 import ctypes
+import weakref
 import os
 import queue
 import threading
@@ -23,6 +25,22 @@ import torch
 from . import _lib
 
 _DIRECTION_MODE = {"CCW": 0, "CW": 1}
+
+
+_LIVE = weakref.WeakSet()
+
+
+def _close_all():
+    """Interpreter exit with envs still open (e.g. after an exception): stop the refill threads before the runtime is
+    torn down — a worker inside the native generator at that moment would abort the process."""
+    for env in list(_LIVE):
+        try:
+            env.close()
+        except Exception:
+            pass
+
+
+atexit.register(_close_all)
 
 
 class VecMultiCarRacing:
@@ -76,6 +94,7 @@ class VecMultiCarRacing:
         self._worker = None
         self._closed = False
         self._has_reset = False
+        _LIVE.add(self)
 
     # ------------------------------------------------------------------ episode generation / staging
     def _generate(self, ids):
