@@ -973,12 +973,14 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
     const double vx = (double)b[0].vx, vy = (double)b[0].vy;
     const double speed = sqrt(vx * vx + vy * vy);
     if (speed > 0.5) angle = atan2(vx, vy);
-    const double ttx = MCR_WINDOW_W / 2 - (sx * zoom * cos(angle) - sy * zoom * sin(angle));
-    const double tty = MCR_WINDOW_H * p.h_ratio - (sx * zoom * sin(angle) + sy * zoom * cos(angle));
+    double sin_a, cos_a; mcr_sincos_core(angle, &sin_a, &cos_a);     // |angle| is a few turns at most; only pixels depend on it
+    const double ttx = MCR_WINDOW_W / 2 - (sx * zoom * cos_a - sy * zoom * sin_a);
+    const double tty = MCR_WINDOW_H * p.h_ratio - (sx * zoom * sin_a + sy * zoom * cos_a);
     const float ftx = (float)ttx, fty = (float)tty, fz = (float)zoom;
     const float fdeg = (float)(57.29577951308232 * angle);
     const double rad = (double)fdeg * (3.14159265358979323846 / 180.0);
-    const float fcs = (float)cos(rad), fsn = (float)sin(rad);
+    double sin_r, cos_r; mcr_sincos_core(rad, &sin_r, &cos_r);
+    const float fcs = (float)cos_r, fsn = (float)sin_r;
     const float kx = 96.0f / 1000.0f, ky = 96.0f / 800.0f;
     vp[VP_CAM + 0] = fcs * fz * kx; vp[VP_CAM + 1] = -fsn * fz * kx; vp[VP_CAM + 2] = fsn * fz * ky; vp[VP_CAM + 3] = fcs * fz * ky;
     vp[VP_CAM + 4] = ftx * kx; vp[VP_CAM + 5] = fty * ky;
@@ -1007,16 +1009,23 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
       vp[VP_IND + (5 + i) * 4 + 2] = (float)(2 * hH) * ky; vp[VP_IND + (5 + i) * 4 + 3] = (float)(4 * hH) * ky;
     }
     vp[VP_HUDTOP] = hud_top;
-    // world-space vertices of the 12 Car.draw polygons (trans*v in f32, as pybox2d hands them to the viewer)
-    float* cp = p.carpoly + (size_t)ci * MCR_CARPOLY_FLOATS;   // AoS on purpose: the raster reads a car's record as one 832-byte run
+    // world-space vertices of the 12 Car.draw polygons (trans*v in f32, as pybox2d hands them to the viewer).
+    // The record is AoS on purpose (the raster reads a car's 832 bytes as one run); every lane writes it with
+    // 16-byte stores — a polygon is 4 of them — and each distinct vertex is transformed once (padding repeats the last).
+    float4* cp4 = (float4*)(p.carpoly + (size_t)ci * MCR_CARPOLY_FLOATS);
+    int counts[12];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const Xf wxf = xf_of(v2(b[k + 1].cx, b[k + 1].cy), b[k + 1].a, v2(0.0f, 0.0f));
-      float* box = cp + (2 * k) * 16; float* stripe = cp + (2 * k + 1) * 16;
-      for (int i = 0; i < 8; ++i) { const int ii = i < 4 ? i : 3; const V2 w = xmul(wxf, v2(S.wheel.vx[ii], S.wheel.vy[ii])); box[i * 2] = w.x; box[i * 2 + 1] = w.y; }   // padded to 8 by repeating the last vertex
-      cp[MCR_CARPOLY_NOFF + 2 * k] = __int_as_float(S.wheel.n);
+      V2 w[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w[i] = xmul(wxf, v2(S.wheel.vx[i], S.wheel.vy[i]));
+      float4* box = cp4 + (2 * k) * 4;
+      box[0] = make_float4(w[0].x, w[0].y, w[1].x, w[1].y); box[1] = make_float4(w[2].x, w[2].y, w[3].x, w[3].y);
+      box[2] = make_float4(w[3].x, w[3].y, w[3].x, w[3].y); box[3] = box[2];
+      counts[2 * k] = S.wheel.n;
       const double a1 = phase[k], a2 = phase[k] + 1.2;
-      double s1, s2, c1, c2; sincos(a1, &s1, &c1); sincos(a2, &s2, &c2);        // one argument reduction per angle
+      double s1, s2, c1, c2; mcr_sincos_core(a1, &s1, &c1); mcr_sincos_core(a2, &s2, &c2);   // phases stay far below the core's 1.6e6 rad range
       int ns = 0;
       if (!(s1 > 0 && s2 > 0)) {
         if (s1 > 0) c1 = np_sign(c1);
@@ -1024,17 +1033,29 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
         ns = 4;
         const float lx[4] = {(float)(-MCR_WHEEL_W * MCR_SIZE), (float)(+MCR_WHEEL_W * MCR_SIZE), (float)(+MCR_WHEEL_W * MCR_SIZE), (float)(-MCR_WHEEL_W * MCR_SIZE)};
         const float ly[4] = {(float)(+MCR_WHEEL_R * c1 * MCR_SIZE), (float)(+MCR_WHEEL_R * c1 * MCR_SIZE), (float)(+MCR_WHEEL_R * c2 * MCR_SIZE), (float)(+MCR_WHEEL_R * c2 * MCR_SIZE)};
-        for (int i = 0; i < 8; ++i) { const int ii = i < 4 ? i : 3; const V2 w = xmul(wxf, v2(lx[ii], ly[ii])); stripe[i * 2] = w.x; stripe[i * 2 + 1] = w.y; }
+        V2 u[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i] = xmul(wxf, v2(lx[i], ly[i]));
+        float4* stripe = cp4 + (2 * k + 1) * 4;
+        stripe[0] = make_float4(u[0].x, u[0].y, u[1].x, u[1].y); stripe[1] = make_float4(u[2].x, u[2].y, u[3].x, u[3].y);
+        stripe[2] = make_float4(u[3].x, u[3].y, u[3].x, u[3].y); stripe[3] = stripe[2];
       }
-      cp[MCR_CARPOLY_NOFF + 2 * k + 1] = __int_as_float(ns);
+      counts[2 * k + 1] = ns;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      float* hp = cp + (8 + k) * 16;
-      const int n = S.hull[k].n;
-      for (int i = 0; i < 8; ++i) { const int ii = i < n ? i : n - 1; const V2 w = xmul(hxf, v2(S.hull[k].vx[ii], S.hull[k].vy[ii])); hp[i * 2] = w.x; hp[i * 2 + 1] = w.y; }
-      cp[MCR_CARPOLY_NOFF + 8 + k] = __int_as_float(n);
+      const int n = __builtin_amdgcn_readfirstlane(S.hull[k].n);     // the shape table is the same for every lane: scalar loads
+      V2 w[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { if (i < n) w[i] = xmul(hxf, v2(S.hull[k].vx[i], S.hull[k].vy[i])); else w[i] = w[i - 1 < 0 ? 0 : i - 1]; }
+      float4* hp = cp4 + (8 + k) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) hp[i] = make_float4(w[2 * i].x, w[2 * i].y, w[2 * i + 1].x, w[2 * i + 1].y);
+      counts[8 + k] = n;
     }
+    float4* cn = cp4 + MCR_CARPOLY_NOFF / 4;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) cn[i] = make_float4(__int_as_float(counts[4 * i]), __int_as_float(counts[4 * i + 1]), __int_as_float(counts[4 * i + 2]), __int_as_float(counts[4 * i + 3]));
   }
   }   // run
   DYN_STAMP(4);

@@ -146,9 +146,10 @@ MCR_HD float mcr_max(float a, float b) { return a < b ? b : a; }   // std::max s
 MCR_HD float mcr_clamp(float a, float lo, float hi) { return mcr_max(lo, mcr_min(a, hi)); }
 MCR_HD float length(V2 a) { return sqrtf(a.x * a.x + a.y * a.y); }
 
-// sinf/cosf spec of the build: bit-identical on host (x86-64) and gfx950.
-MCR_HD void mcr_sincosf(float a, float* s, float* c) {
-  double x = (double)a;
+// f64 sin/cos core: 2-constant Cody-Waite reduction (exact products for |x| < ~1.6e6) + fdlibm minimax kernels;
+// absolute error ~1e-16.  Branch-free and ~45 f64 operations: also used where the device would otherwise call the
+// general-purpose libm sin/cos (camera rotation, wheel stripe phases), whose results only reach pixels.
+MCR_HD void mcr_sincos_core(double x, double* s, double* c) {
   double fn = rint(x * 6.36619772367581382433e-01);
   int n = (int)fn;
   double r = (x - fn * 1.57079632673412561417e+00) - fn * 6.07710050650619224932e-11;
@@ -157,13 +158,17 @@ MCR_HD void mcr_sincosf(float a, float* s, float* c) {
               z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)))));
   double pc = 1.0 - 0.5 * z + z * z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
               z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
-  double ss, cc;
   switch (n & 3) {
-    case 0: ss = ps; cc = pc; break;
-    case 1: ss = pc; cc = -ps; break;
-    case 2: ss = -ps; cc = -pc; break;
-    default: ss = -pc; cc = ps; break;
+    case 0: *s = ps; *c = pc; break;
+    case 1: *s = pc; *c = -ps; break;
+    case 2: *s = -ps; *c = -pc; break;
+    default: *s = -pc; *c = ps; break;
   }
+}
+// sinf/cosf spec of the build: the core above rounded once to f32 — bit-identical on host (x86-64) and gfx950.
+MCR_HD void mcr_sincosf(float a, float* s, float* c) {
+  double ss, cc;
+  mcr_sincos_core((double)a, &ss, &cc);
   *s = (float)ss; *c = (float)cc;
 }
 struct Rot { float s, c; };
