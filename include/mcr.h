@@ -46,7 +46,7 @@ typedef struct mcr_config {
   int32_t car_contacts;      /* 1: car<->car rigid contacts (Box2D default); 0: ghost cars (debug) */
   int32_t max_episode_steps; /* gym TimeLimit from __init__.py:8 (1000); 0 disables */
   int32_t num_streams;       /* 0/1: every kernel on the caller's stream; 2: envs whose dynamics chain is long (a touching car<->car pair,
-                              * or a position loop still iterating after 6 sweeps) run it + their raster on internal streams, concurrently
+                              * or a position loop still iterating after 2 sweeps) run it + their raster on internal streams, concurrently
                               * with the others; results are bit-identical in both modes */
   double h_ratio;            /* :159 */
 } mcr_config;

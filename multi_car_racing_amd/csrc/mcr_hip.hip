@@ -206,11 +206,11 @@ static void launch_reset(mcr_env* h, McrParams P, hipStream_t st) {
 // step(): collide -> dynamics [-> auto-reset pass] -> view on the caller's stream `st`.
 // With num_streams == 2 the step forks into three chains that meet again at the end (grids are sized for the worst
 // case, surplus workgroups exit on their first load):
-//   st      : collide(all) -+-> dynamics(main envs, 6 position sweeps) -+-> reset pass -> view(main envs) -+-> late reset pass
+//   st      : collide(all) -+-> dynamics(main envs, 2 position sweeps) -+-> reset pass -> view(main envs) -+-> late reset pass
 //   s_side  :               +-> dynamics(contact envs) -> view(contact envs) ------------------------------+
 //   s_defer :                                                          +-> dynamics(resume deferred envs) -> view(them) --+
 // Contact envs: a wavefront holding a touching car<->car pair takes 2-4x as long as the others.  Deferred envs: the
-// few whose position loop is still iterating after 6 sweeps (a slow marginal crawl that would hold the whole main
+// few whose position loop is still iterating after 2 sweeps (a slow marginal crawl that would hold the whole main
 // launch for up to 60).  s_defer's dynamics starts while the GPU is nearly idle (the reset pass), so it finds free
 // SIMDs at once.  An env of either list that ended its episode in this step (rare) gets its reset pass + first frame
 // in the "late" pass on `st`: three launches that exit at once in every other step.

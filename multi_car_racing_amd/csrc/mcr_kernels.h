@@ -72,7 +72,7 @@ __device__ __forceinline__ int mcr_env_of_slot(const McrParams& p, int s) {
 // holds car<->car contacts): MCR_SIDE_ENVS_PER_WAVE envs per wavefront, so that the wavefront's LDS pool of contact
 // constraints (DYN_VC_POOL = MCR_SIDE_ENVS_PER_WAVE * MCR_CC_MAX) can never overflow, however the envs are packed.
 #define MCR_SIDE_ENVS_PER_WAVE 2
-#define MCR_DEFER_AFTER 6          // position sweeps the main dynamics launch grants an env before deferring it (99.9 % need 1)
+#define MCR_DEFER_AFTER 2          // position sweeps the main dynamics launch grants an env before deferring it (99.86 % need 1)
 __device__ __forceinline__ int mcr_dyn_slot(const McrParams& p) {
   const int grp = (int)threadIdx.x / p.G;
   if (p.role >= 2) return grp < MCR_SIDE_ENVS_PER_WAVE ? (int)blockIdx.x * MCR_SIDE_ENVS_PER_WAVE + grp : -1;
