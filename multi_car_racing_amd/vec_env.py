@@ -98,11 +98,13 @@ class VecMultiCarRacing:
 
     # ------------------------------------------------------------------ episode generation / staging
     def _generate(self, ids):
-        """Fill self._blobs rows `ids` with each env's next episode (advances the env's RNG streams)."""
+        """Generate each listed env's next episode (advances its RNG streams).  Returns the pinned, contiguous array
+        [len(ids), slot_bytes] holding the blobs in the order of `ids` — what `_stage` uploads; it stays valid until the
+        next `_generate` call of the same thread."""
         ids = np.ascontiguousarray(ids, np.int32)
         n = len(ids)
         if n == 0:
-            return
+            return None
         mt_t = np.ascontiguousarray(self.mt_track[ids]); mt_d = np.ascontiguousarray(self.mt_draw[ids])
         if n != self.B:               # subset: generate into a contiguous pinned buffer so that staging is ONE call
             if self._refill_pin is None or self._refill_pin.shape[0] < n:
@@ -116,23 +118,21 @@ class VecMultiCarRacing:
         self.mt_track[ids] = mt_t; self.mt_draw[ids] = mt_d
         self.episode_info[ids] = info
         if n != self.B:
-            self._blobs_np[ids] = blobs
+            self._blobs_np[ids] = blobs              # per-env copy for introspection (current_episode / facade env.track)
         self.episodes_generated += n
+        return blobs
 
-    def _stage(self, ids, stream):
+    def _stage(self, ids, rows, stream):
+        """Upload `rows` (from `_generate(ids)`) into the staged device slots of envs `ids` (async on `stream`)."""
         ids = np.ascontiguousarray(ids, np.int32)
         if len(ids) == 0:
             return
-        if len(ids) == self.B and np.array_equal(ids, np.arange(self.B)):
-            rows = self._blobs_np
-        else:                         # rows generated by the matching _generate(ids) call
-            rows = self._refill_pin.numpy()[:len(ids)]
         _lib.check(self.L.mcr_stage_episodes(self.h, _lib.ptr(ids), len(ids), _lib.ptr(rows), ctypes.c_void_p(stream.cuda_stream)), "mcr_stage_episodes")
 
     def _refill(self, ids):
-        self._generate(ids)
-        self._stage(ids, self._copy_stream)
-        self._copy_stream.synchronize()      # blobs may be regenerated as soon as this returns
+        rows = self._generate(ids)
+        self._stage(ids, rows, self._copy_stream)
+        self._copy_stream.synchronize()      # the bounce buffer may be overwritten as soon as this returns
 
     def _worker_main(self):
         torch.cuda.set_device(self.device)
@@ -182,8 +182,8 @@ class VecMultiCarRacing:
         st = torch.cuda.current_stream(self.device)
         self.wait_refills()
         if not self._has_reset:
-            self._generate(np.arange(self.B, dtype=np.int32))
-            self._stage(np.arange(self.B, dtype=np.int32), st)
+            every = np.arange(self.B, dtype=np.int32)
+            self._stage(every, self._generate(every), st)
         else:
             # a staged episode already waits on the device for every env that consumed one; envs whose staged
             # slot is still full simply install it
