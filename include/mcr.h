@@ -138,8 +138,11 @@ int mcr_sincos_device(mcr_env* h, const float* d_in, float* d_sin, float* d_cos,
  * the auto-reset pass, 5/6 = dynamics/view of the contact side stream, 7 = its reset pass (255 = all, 0 = off).
  * mcr_timing_read synchronises the device and drains accumulated milliseconds + launch counts. */
 int mcr_timing_enable(mcr_env* h, int mask);
-/* profiling ablations of the raster kernel (bit 0 skip flags block, 1 skip road shading, 2 skip cars, 3 skip
- * write-out, 4 skip binning/cull); 0 in production.  Results are WRONG when non-zero. */
+/* Profiling switches, 0 in production.  Bits 0-4, 6, 7, 9, 10 are ABLATIONS (results are WRONG when set):
+ *   raster: 0 skip flags block, 1 skip road shading, 2 skip cars, 3 skip write-out, 4 skip binning/cull;
+ *   dynamics: 6 cap the position loops at 2 sweeps, 7 cap the velocity sweeps of contact waves at 2,
+ *             9 skip the contact velocity solve, 10 skip the LDS body exchange of contact waves.
+ * Bits 5 and 8 only add clock stamps (raster / dynamics phases) and leave the results untouched. */
 int mcr_debug_set(mcr_env* h, int value);
 /* debug bit 5 (32): the raster kernel stamps s_memtime per phase; read the 64-float tail of a view's scratch */
 int mcr_debug_read_view_scratch(mcr_env* h, int view, void* out, int nbytes);

@@ -657,14 +657,14 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
 #pragma unroll
         for (int q = 3; q >= 0; --q) joint_velocity(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);
       }
-      if (ccn > 0) {
+      if (ccn > 0 && !(p.debug & 1024)) {
 #pragma unroll
         for (int k = 0; k < 5; ++k) { xv[0 * 5 + k][lane] = b[k].vx; xv[1 * 5 + k][lane] = b[k].vy; xv[2 * 5 + k][lane] = b[k].w; }
       }
       __syncthreads();
-      if (ccn > 0 && agent == 0) for (int i = 0; i < ccn; ++i) cc_velocity(S, vcpool[pool_base + i], xv);
+      if (ccn > 0 && agent == 0 && !(p.debug & 512)) for (int i = 0; i < ccn; ++i) cc_velocity(S, vcpool[pool_base + i], xv);
       __syncthreads();
-      if (ccn > 0) {
+      if (ccn > 0 && !(p.debug & 1024)) {
 #pragma unroll
         for (int k = 0; k < 5; ++k) { b[k].vx = xv[0 * 5 + k][lane]; b[k].vy = xv[1 * 5 + k][lane]; b[k].w = xv[2 * 5 + k][lane]; }
       }
