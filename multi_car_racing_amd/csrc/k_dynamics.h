@@ -189,12 +189,15 @@ __device__ __forceinline__ double np_sign(double x) { return x > 0.0 ? 1.0 : (x 
 // car<->car contact constraints, executed by the env's leader lane on LDS-resident body state.
 // xs[comp*5 + body][lane]: comp 0..2 = (vx, vy, w) or (cx, cy, a) of `body` of the car owned by `lane`.
 #define DYN_VC_POOL (MCR_SIDE_ENVS_PER_WAVE * MCR_CC_MAX)
-__device__ __forceinline__ void cc_masses(const McrShapes& S, int body, float& m, float& i, V2& lc) {
-  if (body == 0) { m = S.hull_invMass; i = S.hull_invI; lc = v2(S.hull_lcx, S.hull_lcy); }
-  else { m = S.wheel_invMass; i = S.wheel_invI; lc = v2(0.0f, 0.0f); }
+// mass data of the two body kinds, held in registers by the kernel (reading the shape table from memory inside the
+// contact sweeps would put a load on the critical path of every contact of every sweep)
+struct CcMass { float mH, iH, mW, iW, lcx, lcy; };
+__device__ __forceinline__ void cc_masses(const CcMass& S, int body, float& m, float& i, V2& lc) {
+  if (body == 0) { m = S.mH; i = S.iH; lc = v2(S.lcx, S.lcy); }
+  else { m = S.mW; i = S.iW; lc = v2(0.0f, 0.0f); }
 }
 // b2ContactSolver ctor + InitializeVelocityConstraints + WarmStart for one stored manifold
-__device__ inline void cc_init(const McrShapes& S, const uint32_t* rec, int rec_index, int leader_lane, float (*xp)[64], float (*xv)[64], float* vc) {
+__device__ inline void cc_init(const CcMass& S, const uint32_t* rec, int rec_index, int leader_lane, float (*xp)[64], float (*xv)[64], float* vc) {
   const uint32_t key = rec[0];
   const int carA = key & 15, fixA = (key >> 4) & 15, carB = (key >> 8) & 15, fixB = (key >> 12) & 15;
   const int bA = cc::fixture_body(fixA), bB = cc::fixture_body(fixB);
@@ -274,7 +277,7 @@ __device__ inline void cc_init(const McrShapes& S, const uint32_t* rec, int rec_
 // b2ContactSolver::SolveVelocityConstraints for one contact.  The record and both bodies are pulled into
 // registers with a few wide LDS reads, and only the accumulated impulses + body velocities are written back
 // (one LDS round trip per contact per iteration instead of one per scalar).
-__device__ inline void cc_velocity(const McrShapes& S, float* __restrict__ vcf, float (* __restrict__ xv)[64]) {
+__device__ inline void cc_velocity(const CcMass& S, float* __restrict__ vcf, float (* __restrict__ xv)[64]) {
   const float4* __restrict__ v4 = (const float4*)vcf;
   const float4 r0 = v4[0], r1 = v4[1], r2 = v4[2], r3 = v4[3], r4 = v4[4], r5 = v4[5], r6 = v4[6];
   // layout: [0]=nx [1]=ny [2]=n [3]=LA | [4]=LB [5..12]=P0 | [13..20]=P1 | [21]=k11 [22]=k12 [23]=k22 [24]=nm11 [25]=nm12 [26]=nm22
@@ -354,7 +357,7 @@ __device__ inline void cc_velocity(const McrShapes& S, float* __restrict__ vcf, 
 }
 
 // b2ContactSolver::SolvePositionConstraints for one contact; returns its min separation
-__device__ inline float cc_position(const McrShapes& S, const uint32_t* rec, int leader_lane, float (*xp)[64]) {
+__device__ inline float cc_position(const CcMass& S, const uint32_t* rec, int leader_lane, float (*xp)[64]) {
   const uint32_t key = rec[0];
   const int carA = key & 15, fixA = (key >> 4) & 15, carB = (key >> 8) & 15, fixB = (key >> 12) & 15;
   const int bA = cc::fixture_body(fixA), bB = cc::fixture_body(fixB);
@@ -436,6 +439,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
   const McrShapes& S = *p.shapes;
   const float mH = S.hull_invMass, iH = S.hull_invI, mW = S.wheel_invMass, iW = S.wheel_invI;
   const float lcx = S.hull_lcx, lcy = S.hull_lcy;
+  const CcMass CM{mH, iH, mW, iW, lcx, lcy};
   const float h = (float)(1.0 / MCR_FPS);
   const double dt = 1.0 / MCR_FPS;
 
@@ -569,7 +573,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
       for (int c = 0; c < MCR_MAX_AGENTS; ++c) root[c] = c;
       for (int i = 0; i < ccn; ++i) {
         const uint32_t* rec = store + 4 + i * MCR_CC_WORDS;
-        cc_init(S, rec, i, leader_lane, xp, xv, vcpool[pool_base + i]);
+        cc_init(CM, rec, i, leader_lane, xp, xv, vcpool[pool_base + i]);
 #pragma unroll
         for (int w = 0; w < 16; ++w) pcrec[pool_base + i][w] = rec[w];      // once per step instead of one HBM round trip per sweep
         // union-find over cars (b2World::Solve island DFS through touching contacts)
@@ -662,7 +666,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
         for (int k = 0; k < 5; ++k) { xv[0 * 5 + k][lane] = b[k].vx; xv[1 * 5 + k][lane] = b[k].vy; xv[2 * 5 + k][lane] = b[k].w; }
       }
       __syncthreads();
-      if (ccn > 0 && agent == 0 && !(p.debug & 512)) for (int i = 0; i < ccn; ++i) cc_velocity(S, vcpool[pool_base + i], xv);
+      if (ccn > 0 && agent == 0 && !(p.debug & 512)) for (int i = 0; i < ccn; ++i) cc_velocity(CM, vcpool[pool_base + i], xv);
       __syncthreads();
       if (ccn > 0 && !(p.debug & 1024)) {
 #pragma unroll
@@ -754,7 +758,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
           const int ca = rec[0] & 15;
           const int r = xisl[leader_lane + ca];
           if (!xact[leader_lane + r]) continue;
-          const float ms = cc_position(S, rec, leader_lane, xp);
+          const float ms = cc_position(CM, rec, leader_lane, xp);
 #pragma unroll
           for (int c = 0; c < MCR_MAX_AGENTS; ++c) if (c == r) minSep[c] = mcr_min(minSep[c], ms);
         }
