@@ -144,7 +144,7 @@ __device__ inline bool point_in_road_poly_f64(const uint8_t* __restrict__ slot, 
 
 // flags_mode: 1 = evaluate the backward/on-grass block (:446-495) for this agent.
 // dynamic LDS: car polygon records, N*12 x 6 float4 (8 edges each, padded with always-true edges)
-__global__ __launch_bounds__(VIEW_THREADS, 5) void k_view(McrParams p, float* __restrict__ scratch, int flags_mode, int only_just_reset) {
+__global__ __launch_bounds__(VIEW_THREADS, 6) void k_view(McrParams p, float* __restrict__ scratch, int flags_mode, int only_just_reset) {
   using namespace view;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
