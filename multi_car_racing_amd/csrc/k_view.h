@@ -26,8 +26,8 @@
 namespace view {
 
 #define VIEW_THREADS 256
-#define VIS_LDS 112                  // road survivors kept in LDS; more spill to HBM scratch (zoomed-out frames)
-#define BIN_CAP 20                   // entries per bin list; overflow -> the bin walks every survivor
+#define VIS_LDS 144                  // road survivors kept in LDS; more spill to HBM scratch (zoomed-out frames)
+#define BIN_CAP 24                   // entries per bin list; overflow -> the bin walks every survivor
 #define CAR_KEY 1024                 // bin-list ids >= CAR_KEY are car polygons (drawn after every road quad)
 #define NBINS 72                     // 12 x 6 bins of 8 x 16 pixels: one wave shades a bin, each lane two pixels (y, y+8)
 #define CARPOLY_CAP (MCR_MAX_AGENTS * 12)
