@@ -26,8 +26,9 @@
 namespace view {
 
 #define VIEW_THREADS 256
-#define VIS_LDS 144                  // road survivors kept in LDS; more spill to HBM scratch (zoomed-out frames)
-#define BIN_CAP 24                   // entries per bin list; overflow -> the bin walks every survivor
+// VIS_LDS: road survivors kept in LDS, more spill to HBM scratch (zoomed-out frames); BIN_CAP: entries per bin list,
+// overflow -> the bin walks every survivor.  Both are template parameters of the raster body: few agents leave LDS
+// for larger tables at 6 workgroups/CU, many agents need the LDS for their car polygons.
 #define CAR_KEY 1024                 // bin-list ids >= CAR_KEY are car polygons (drawn after every road quad)
 #define NBINS 72                     // 12 x 6 bins of 8 x 16 pixels: one wave shades a bin, each lane two pixels (y, y+8)
 #define CARPOLY_CAP (MCR_MAX_AGENTS * 12)
@@ -144,7 +145,8 @@ __device__ inline bool point_in_road_poly_f64(const uint8_t* __restrict__ slot, 
 
 // flags_mode: 1 = evaluate the backward/on-grass block (:446-495) for this agent.
 // dynamic LDS: car polygon records, N*12 x 6 float4 (8 edges each, padded with always-true edges)
-__global__ __launch_bounds__(VIEW_THREADS, 6) void k_view(McrParams p, float* __restrict__ scratch, int flags_mode, int only_just_reset) {
+template <int VIS_LDS, int BIN_CAP>
+__device__ __forceinline__ void view_body(const McrParams& p, float* __restrict__ scratch, const int flags_mode, const int only_just_reset) {
   using namespace view;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -613,4 +615,13 @@ __global__ __launch_bounds__(VIEW_THREADS, 6) void k_view(McrParams p, float* __
     }
   }
   PHASE_STAMP(9);
+}
+
+// N <= 2: 2.3 KB of car polygons in dynamic LDS -> 25 KB per workgroup, 6 workgroups per CU
+__global__ __launch_bounds__(VIEW_THREADS, 6) void k_view(McrParams p, float* __restrict__ scratch, int flags_mode, int only_just_reset) {
+  view_body<144, 24>(p, scratch, flags_mode, only_just_reset);
+}
+// N > 2: up to 9.2 KB of car polygons -> smaller survivor / bin tables keep 5 workgroups per CU
+__global__ __launch_bounds__(VIEW_THREADS, 5) void k_view_many(McrParams p, float* __restrict__ scratch, int flags_mode, int only_just_reset) {
+  view_body<112, 20>(p, scratch, flags_mode, only_just_reset);
 }

@@ -200,7 +200,7 @@ static void launch_reset(mcr_env* h, McrParams P, hipStream_t st) {
   hipLaunchKernelGGL(k_install, dim3(dyn_blocks), dim3(64), 0, st, P);
   LAUNCH_LDS(3, k_collide, B, 64, col::lds_bytes(N), st, P, 1);
   LAUNCH(4, k_dynamics, dyn_blocks, 64, st, P, 1);
-  if (P.obs) LAUNCH_LDS(2, k_view, B * N, VIEW_THREADS, (size_t)N * 12 * 6 * 16, st, P, h->view_scratch, 0, 1);
+  if (P.obs) if (N <= 2) LAUNCH_LDS(2, k_view, B * N, VIEW_THREADS, (size_t)N * 12 * 6 * 16, st, P, h->view_scratch, 0, 1); else LAUNCH_LDS(2, k_view_many, B * N, VIEW_THREADS, (size_t)N * 12 * 6 * 16, st, P, h->view_scratch, 0, 1);
 }
 
 // step(): collide -> dynamics [-> auto-reset pass] -> view on the caller's stream `st`.
@@ -234,7 +234,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     (void)hipStreamWaitEvent(h->s_side, h->ev_fork, 0);
     P.role = 2;
     LAUNCH(5, k_dynamics, side_blocks, 64, h->s_side, P, 0);
-    if (draw) LAUNCH_LDS(6, k_view, B * N, VIEW_THREADS, view_lds, h->s_side, P, h->view_scratch, view_flags, 0);
+    if (draw) if (N <= 2) LAUNCH_LDS(6, k_view, B * N, VIEW_THREADS, view_lds, h->s_side, P, h->view_scratch, view_flags, 0); else LAUNCH_LDS(6, k_view_many, B * N, VIEW_THREADS, view_lds, h->s_side, P, h->view_scratch, view_flags, 0);
     (void)hipEventRecord(h->ev_join, h->s_side);
     P.role = 1;
   }
@@ -244,7 +244,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     (void)hipStreamWaitEvent(h->s_defer, h->ev_fork2, 0);
     P.role = 3;
     LAUNCH(7, k_dynamics, side_blocks, 64, h->s_defer, P, 0);
-    if (draw) LAUNCH_LDS(7, k_view, B * N, VIEW_THREADS, view_lds, h->s_defer, P, h->view_scratch, view_flags, 0);
+    if (draw) if (N <= 2) LAUNCH_LDS(7, k_view, B * N, VIEW_THREADS, view_lds, h->s_defer, P, h->view_scratch, view_flags, 0); else LAUNCH_LDS(7, k_view_many, B * N, VIEW_THREADS, view_lds, h->s_defer, P, h->view_scratch, view_flags, 0);
     (void)hipEventRecord(h->ev_join2, h->s_defer);
     P.role = 1;
   }
@@ -253,7 +253,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     LAUNCH(4, k_dynamics, dyn_blocks, 64, st, P, 1);
   }
   P.use_vorder = 1;
-  if (draw) LAUNCH_LDS(2, k_view, (B + 7) / 8 * 8 * N, VIEW_THREADS, view_lds, st, P, h->view_scratch, view_flags, 0);
+  if (draw) if (N <= 2) LAUNCH_LDS(2, k_view, (B + 7) / 8 * 8 * N, VIEW_THREADS, view_lds, st, P, h->view_scratch, view_flags, 0); else LAUNCH_LDS(2, k_view_many, (B + 7) / 8 * 8 * N, VIEW_THREADS, view_lds, st, P, h->view_scratch, view_flags, 0);
   P.use_vorder = 0;
   if (h->split) {
     (void)hipStreamWaitEvent(st, h->ev_join, 0);
@@ -262,7 +262,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
       P.role = 4;
       LAUNCH_LDS(7, k_collide, B, 64, col::lds_bytes(N), st, P, 1);
       LAUNCH(7, k_dynamics, side_blocks, 64, st, P, 1);
-      if (draw) LAUNCH_LDS(7, k_view, B * N, VIEW_THREADS, view_lds, st, P, h->view_scratch, view_flags, 1);
+      if (draw) if (N <= 2) LAUNCH_LDS(7, k_view, B * N, VIEW_THREADS, view_lds, st, P, h->view_scratch, view_flags, 1); else LAUNCH_LDS(7, k_view_many, B * N, VIEW_THREADS, view_lds, st, P, h->view_scratch, view_flags, 1);
     }
   }
 }
