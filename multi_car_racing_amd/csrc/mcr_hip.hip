@@ -192,6 +192,13 @@ static hipEvent_t get_event(mcr_env* h) {
     if (tm_) { (void)hipEventRecord(tl_.b, st); h->pending.push_back(tl_); }                   \
   } while (0)
 
+// raster launch: the instantiation depends on the agent count (k_view.h)
+static void launch_view(mcr_env* h, int kid, int grid, hipStream_t st, const McrParams& P, int view_flags, int only_just_reset) {
+  const size_t lds = (size_t)P.N * 12 * 6 * 16;      // car polygon edge records
+  if (P.N <= 2) LAUNCH_LDS(kid, k_view, grid, VIEW_THREADS, lds, st, P, h->view_scratch, view_flags, only_just_reset);
+  else LAUNCH_LDS(kid, k_view_many, grid, VIEW_THREADS, lds, st, P, h->view_scratch, view_flags, only_just_reset);
+}
+
 // reset(): install -> collide(1) -> dynamics(1) -> view, in order on one stream
 static void launch_reset(mcr_env* h, McrParams P, hipStream_t st) {
   const int B = P.B, N = P.N;
@@ -200,7 +207,7 @@ static void launch_reset(mcr_env* h, McrParams P, hipStream_t st) {
   hipLaunchKernelGGL(k_install, dim3(dyn_blocks), dim3(64), 0, st, P);
   LAUNCH_LDS(3, k_collide, B, 64, col::lds_bytes(N), st, P, 1);
   LAUNCH(4, k_dynamics, dyn_blocks, 64, st, P, 1);
-  if (P.obs) if (N <= 2) LAUNCH_LDS(2, k_view, B * N, VIEW_THREADS, (size_t)N * 12 * 6 * 16, st, P, h->view_scratch, 0, 1); else LAUNCH_LDS(2, k_view_many, B * N, VIEW_THREADS, (size_t)N * 12 * 6 * 16, st, P, h->view_scratch, 0, 1);
+  if (P.obs) launch_view(h, 2, B * N, st, P, 0, 1);
 }
 
 // step(): collide -> dynamics [-> auto-reset pass] -> view on the caller's stream `st`.
@@ -218,7 +225,6 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   const int B = P.B, N = P.N;
   const int dyn_blocks = (B * P.G + 63) / 64;
   const int side_blocks = (B + MCR_SIDE_ENVS_PER_WAVE - 1) / MCR_SIDE_ENVS_PER_WAVE;   // list launches: few envs per wavefront
-  const size_t view_lds = (size_t)N * 12 * 6 * 16;
   const bool draw = P.obs || view_flags;
   P.role = 0; P.split = h->split ? 1 : 0; P.defer_after = 0;
   if (h->split) {      // the contact list is double-buffered by step parity; no memset on the critical path
@@ -234,7 +240,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     (void)hipStreamWaitEvent(h->s_side, h->ev_fork, 0);
     P.role = 2;
     LAUNCH(5, k_dynamics, side_blocks, 64, h->s_side, P, 0);
-    if (draw) if (N <= 2) LAUNCH_LDS(6, k_view, B * N, VIEW_THREADS, view_lds, h->s_side, P, h->view_scratch, view_flags, 0); else LAUNCH_LDS(6, k_view_many, B * N, VIEW_THREADS, view_lds, h->s_side, P, h->view_scratch, view_flags, 0);
+    if (draw) launch_view(h, 6, B * N, h->s_side, P, view_flags, 0);
     (void)hipEventRecord(h->ev_join, h->s_side);
     P.role = 1;
   }
@@ -244,7 +250,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     (void)hipStreamWaitEvent(h->s_defer, h->ev_fork2, 0);
     P.role = 3;
     LAUNCH(7, k_dynamics, side_blocks, 64, h->s_defer, P, 0);
-    if (draw) if (N <= 2) LAUNCH_LDS(7, k_view, B * N, VIEW_THREADS, view_lds, h->s_defer, P, h->view_scratch, view_flags, 0); else LAUNCH_LDS(7, k_view_many, B * N, VIEW_THREADS, view_lds, h->s_defer, P, h->view_scratch, view_flags, 0);
+    if (draw) launch_view(h, 7, B * N, h->s_defer, P, view_flags, 0);
     (void)hipEventRecord(h->ev_join2, h->s_defer);
     P.role = 1;
   }
@@ -253,7 +259,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     LAUNCH(4, k_dynamics, dyn_blocks, 64, st, P, 1);
   }
   P.use_vorder = 1;
-  if (draw) if (N <= 2) LAUNCH_LDS(2, k_view, (B + 7) / 8 * 8 * N, VIEW_THREADS, view_lds, st, P, h->view_scratch, view_flags, 0); else LAUNCH_LDS(2, k_view_many, (B + 7) / 8 * 8 * N, VIEW_THREADS, view_lds, st, P, h->view_scratch, view_flags, 0);
+  if (draw) launch_view(h, 2, (B + 7) / 8 * 8 * N, st, P, view_flags, 0);
   P.use_vorder = 0;
   if (h->split) {
     (void)hipStreamWaitEvent(st, h->ev_join, 0);
@@ -262,7 +268,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
       P.role = 4;
       LAUNCH_LDS(7, k_collide, B, 64, col::lds_bytes(N), st, P, 1);
       LAUNCH(7, k_dynamics, side_blocks, 64, st, P, 1);
-      if (draw) if (N <= 2) LAUNCH_LDS(7, k_view, B * N, VIEW_THREADS, view_lds, st, P, h->view_scratch, view_flags, 1); else LAUNCH_LDS(7, k_view_many, B * N, VIEW_THREADS, view_lds, st, P, h->view_scratch, view_flags, 1);
+      if (draw) launch_view(h, 7, B * N, st, P, view_flags, 1);
     }
   }
 }
