@@ -272,9 +272,15 @@ __device__ __forceinline__ void view_body(const McrParams& p, float* __restrict_
   }
 
   PHASE_STAMP(2);
-  // ---- car polygons (Car.draw): world vertices come from k_dynamics; threads 0..12N-1 set one polygon up each
-  if (draw && tid < N * 12) {
-    const int k = tid, c = k / 12, j = k % 12;
+  PHASE_STAMP(3);
+  __syncthreads();
+  PHASE_STAMP(4);
+
+  // ---- car polygons (Car.draw): world vertices come from k_dynamics; the LAST 12N threads set one polygon up each,
+  // in the same phase as pass 2 — survivors fill the threads from 0 upwards (~100-150 of them on a normal frame), so
+  // the two set-ups usually run on different wavefronts instead of one after the other
+  if (draw && tid >= VIEW_THREADS - N * 12) {
+    const int k = tid - (VIEW_THREADS - N * 12), c = k / 12, j = k % 12;
     const float* __restrict__ cp = p.carpoly + (size_t)(env * N + c) * MCR_CARPOLY_FLOATS;
     // one burst: 8 vertices (4 x float4) + the vertex count, all issued before anything is consumed
     const float* cv = cp + j * 16;
@@ -330,10 +336,6 @@ __device__ __forceinline__ void view_body(const McrParams& p, float* __restrict_
     }
     cinfo[k] = info;
   }
-  PHASE_STAMP(3);
-  __syncthreads();
-  PHASE_STAMP(4);
-
   // ---- pass 2: dense set-up of the survivors (edge equations, colour, bins)
   const int nq = nsurv;
   const int nq_lds = nq < VIS_LDS ? nq : VIS_LDS;
