@@ -224,13 +224,21 @@ __device__ __forceinline__ void view_body(const McrParams& p, float* __restrict_
   // ---- pass 1 over road_poly: cull (ballot-compacted survivor list) + bookkeeping prefilter
   float cd2[3] = {MCR_MAXFLT, MCR_MAXFLT, MCR_MAXFLT}; int cti[3] = {-1, -1, -1};       // nearest-track-point candidates (f32)
   bool inside = false;
+  // all three quads of the thread are requested before the first is used: one exposed HBM/L2 latency instead of three
+  float4 qa_[3], qb_[3]; uint32_t qm_[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int q = tid + r * VIEW_THREADS;
+    if (q < P) { qa_[r] = QA[q]; qb_[r] = QB[q]; qm_[r] = QM[q]; }
+    else { qa_[r] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); qb_[r] = qa_[r]; qm_[r] = 0u; }
+  }
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const int q = tid + r * VIEW_THREADS;
     bool keep = false;
     if (q < P) {
-      const float4 a = QA[q], b = QB[q];
-      const uint32_t meta = QM[q];
+      const float4 a = qa_[r], b = qb_[r];
+      const uint32_t meta = qm_[r];
       if (draw && !(dbg & 16)) {
         float x0 = MCR_MAXFLT, x1 = -MCR_MAXFLT, y0 = MCR_MAXFLT, y1 = -MCR_MAXFLT;
         const float wx[4] = {a.x, a.z, b.x, b.z}, wy[4] = {a.y, a.w, b.y, b.w};
