@@ -20,11 +20,34 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def cpu_baseline(num_agents, obs, steps=60):
-    """Oracle (C++ CPU restatement of the same step, oracle/mcr_oracle.cpp) on a bounded sample of the same
-    workload: 4 envs per host core x `steps` steps, same action distribution, one OpenMP thread per core,
-    no Python inside the timed loop.  Returns the cpu_baseline JSON object."""
+def _cpu_leg(O, envs, num_agents, obs, threads, seed, t0_step, budget_s):
+    """Time the oracle on `envs` with the counter-based synthetic action stream (host twin of what the GPU consumes)
+    for about `budget_s` seconds.  Returns (env-steps/s, steps, seconds, next step index)."""
+    import ctypes
     import numpy as np
+    from multi_car_racing_amd import _lib
+    L = _lib.load()
+    n = len(envs)
+
+    def acts(t0, k):
+        a = np.zeros((k, n, num_agents, 3), np.float32)
+        for i in range(k):
+            L.mcr_synth_actions_host(_lib.ptr(a[i]), n, num_agents, ctypes.c_uint64(seed), ctypes.c_uint32(t0 + i), ctypes.c_uint32(0))
+        return a
+    probe = 20
+    a = acts(t0_step, probe)
+    t0 = time.perf_counter(); O.rollout(envs, a, render=obs, threads=threads); dt = time.perf_counter() - t0
+    t0_step += probe
+    steps = int(max(probe, min(4000, probe * budget_s / max(dt, 1e-4))))
+    a = acts(t0_step, steps)
+    t0 = time.perf_counter(); O.rollout(envs, a, render=obs, threads=threads); dt = time.perf_counter() - t0
+    return n * steps / dt, steps, dt, t0_step + steps
+
+
+def cpu_baseline(num_agents, obs):
+    """Oracle (C++ CPU restatement of the same step, oracle/mcr_oracle.cpp) on a bounded sample of the same workload:
+    8 envs per host core, same counter-based action stream, one OpenMP thread per core, no Python inside the timed
+    loops.  Headline leg: all cores, obs as benched; extra legs: 1 thread, and obs off.  ~25 s in total."""
     from oracle import oracle as O
     from tests.util import oracle_episode
     from multi_car_racing_amd._lib import effective_cpus
@@ -35,27 +58,39 @@ def cpu_baseline(num_agents, obs, steps=60):
         o = O.OracleEnv(num_agents)
         o.reset(oracle_episode(O, num_agents, 12345, e, use_random_direction=True), render=False)
         envs.append(o)
-    rng = np.random.RandomState(1)
-    def acts(k):
-        return np.stack([rng.uniform(-1, 1, (k, n_envs, num_agents)), rng.uniform(0, 1, (k, n_envs, num_agents)),
-                         rng.uniform(0, 1, (k, n_envs, num_agents))], -1).astype(np.float32)
-    O.rollout(envs, acts(55), render=obs, threads=cores)          # warm-up through the zoom-in
-    a = acts(steps)
-    t0 = time.perf_counter()
-    O.rollout(envs, a, render=obs, threads=cores)
-    dt = time.perf_counter() - t0
-    if dt < 5.0:                                                   # scale the sample to >= ~10 s of CPU work in total
-        more = int(steps * min(20.0, 10.0 / max(dt, 1e-3)))
-        a = acts(more)
-        t0 = time.perf_counter()
-        O.rollout(envs, a, render=obs, threads=cores)
-        dt = time.perf_counter() - t0; steps = more
+    seed = 4321
+    _, _, _, t = _cpu_leg(O, envs, num_agents, obs, cores, seed, 0, 1.0)          # warm-up through the zoom-in (>= 50 steps)
+    v, steps, dt, t = _cpu_leg(O, envs, num_agents, obs, cores, seed, t, 10.0)
+    v1, s1, d1, t = _cpu_leg(O, envs[:8], num_agents, obs, 1, seed, t, 5.0)
+    v0, s0, d0, t = _cpu_leg(O, envs, num_agents, False, cores, seed, t, 5.0)
     for o in envs:
         o.close()
-    return {"value": n_envs * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n_envs} envs x {steps} steps, num_agents={num_agents}, obs={'96x96x3' if obs else 'none'}, "
-                      f"oracle/mcr_oracle.cpp with OpenMP over envs (CPU restatement; the reference's Box2D+pyglet path "
-                      f"is not installable here), {dt:.1f} s wall; host reports {os.cpu_count()} logical CPUs, cgroup/affinity allows {cores}"}
+    what = "oracle/mcr_oracle.cpp with OpenMP over envs (CPU restatement; the reference's Box2D+pyglet path is not installable here)"
+    return {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n_envs} envs x {steps} steps, num_agents={num_agents}, obs={'96x96x3' if obs else 'none'}, {what}, "
+                      f"{dt:.1f} s wall; host reports {os.cpu_count()} logical CPUs, cgroup/affinity allows {cores}",
+            "legs": [{"value": v1, "unit": "env-steps/s", "cores": 1, "sample": f"8 envs x {s1} steps, obs={'96x96x3' if obs else 'none'}, {d1:.1f} s"},
+                     {"value": v0, "unit": "env-steps/s", "cores": cores, "sample": f"{n_envs} envs x {s0} steps, obs=none (physics + bookkeeping only), {d0:.1f} s"}]}
+
+
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.stderr.write(f"bench.py: --gpus {n} requested but this node exposes {have} HIP device(s); refusing to report a "
+                         f"{n}-GPU number from fewer GPUs\n")
+        sys.exit(2)
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -71,16 +106,26 @@ def main():
     ap.add_argument("--debug-bits", type=int, default=0, help="mcr_debug_set value for timing experiments (results are WRONG when non-zero)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event time all three kernels (adds overhead)")
+    ap.add_argument("--action-seed", type=int, default=1234)
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        _spawn_ranks(args.gpus)                 # does not return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks\n")
+        sys.exit(2)
 
     import numpy as np
     import torch
     import torch.distributed as dist
     from multi_car_racing_amd.sharded import ShardedVecEnv, reduce_metrics
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if local_rank >= torch.cuda.device_count():
+        sys.stderr.write(f"bench.py: rank {rank} needs HIP device {local_rank}, the node exposes {torch.cuda.device_count()}\n")
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -91,10 +136,16 @@ def main():
     env = ShardedVecEnv(B * world, N, seed=0, rank=rank, world_size=world, device=dev, obs=bool(args.obs),
                         auto_reset=True, use_random_direction=True, streams=args.streams)
     env.reset()
-    # synthetic actions resident in HBM: a pool of i.i.d. (steer~U(-1,1), gas~U(0,1), brake~U(0,1)) batches
+    # synthetic actions, generated ON THE DEVICE every step by a counter-based stream keyed (seed, global env, agent, t)
+    # (SURVEY 8d): i.i.d. steer~U(-1,1), gas~U(0,1), brake~U(0,1); one 3 us kernel inside the timed region
     g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
-    pool = torch.rand((64, B, N, 3), device=dev, generator=g)
-    pool[..., 0] = pool[..., 0] * 2 - 1
+    act = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+    tstep = [0]
+
+    def next_actions():
+        env.env.synth_actions(tstep[0], seed=args.action_seed, out=act)
+        tstep[0] += 1
+        return act
     # Steady state before anything is timed: a real rollout has its episodes ending at different steps, not all
     # B TimeLimits expiring in the same step (which would put B host track generations into one burst).  One
     # un-timed TimeLimit period in which every env is reset once, at a step drawn without replacement, leaves the
@@ -104,12 +155,12 @@ def main():
         L = 1000
         ids = torch.randperm(B, device=dev, generator=g)      # which env gets which phase: random, as in a real rollout
         for j in range(L):
-            env.step(pool[j % 64])
+            env.step(next_actions())
             msk = ((ids * L) // B == j).to(torch.uint8)
             if bool(msk.any()):
                 env.reset_envs(msk)
     for k in range(W):
-        env.step(pool[k % 64])
+        env.step(next_actions())
     env.wait_refills()
     if args.debug_bits:
         from multi_car_racing_amd import _lib as _L
@@ -129,7 +180,7 @@ def main():
     evs = [torch.cuda.Event() for _ in range(LOOKAHEAD)]
     t0 = time.perf_counter()
     for k in range(K):
-        env.step(pool[(W + k) % 64])
+        env.step(next_actions())
         if k >= LOOKAHEAD:
             evs[k % LOOKAHEAD].synchronize()
         evs[k % LOOKAHEAD].record()
@@ -159,15 +210,20 @@ def main():
         off_main = float((ctr1[0] - ctr0[0]) + (ctr1[2] - ctr0[2])) / K
         main_envs = max(B - off_main, 1.0)
         achieved = bytes_per_env_step * main_envs / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE need runs of their own:
+        # tools/profile_round.sh); this run did not collect counters, so the figure is quoted from the committed
+        # summary of the same command and labelled with its source
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "view_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = "profiles/view_traffic.json (%s; PMC passes of tools/profile_round.sh, not measured in this run)" % tj.get("round", "?")
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": "k_view", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                    "frac": achieved / 8000.0, "traffic": traffic, "avg_launch_ms": avg_ms, "launches": int(nl[2]),
+                    "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": avg_ms, "launches": int(nl[2]),
                     "algorithmic_bytes_per_launch": bytes_per_env_step * main_envs, "envs_per_launch": main_envs}
     if rank == 0:
         out = {
@@ -183,6 +239,9 @@ def main():
                        "env_steps_frozen_waiting_for_host_rank0": int(env.env.debug_counters()[3] - ctr0[3])},
             "roofline": roofline,
         }
+        if K < 200:
+            out["config"]["note"] = ("short run: %d steps = %.0f ms of timed work; the default (1000 steps = one TimeLimit period, "
+                                     "every env resets once) is the representative figure" % (K, m["elapsed_s"] * 1e3))
         if args.time_all_kernels:
             out["kernel_ms"] = {"collide": ms[0] / max(nl[0], 1), "dynamics": ms[1] / max(nl[1], 1), "view": ms[2] / max(nl[2], 1),
                                 "collide_reset_pass": ms[3] / max(nl[3], 1), "dynamics_reset_pass": ms[4] / max(nl[4], 1),

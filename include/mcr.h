@@ -98,11 +98,9 @@ int mcr_reset(mcr_env* h, const uint8_t* d_env_mask, uint8_t* d_obs, void* strea
  * With auto_reset, a finished env's obs row is the first observation of its next episode. */
 int mcr_step(mcr_env* h, const float* d_actions, uint8_t* d_obs, double* d_reward, uint8_t* d_done,
              uint8_t* d_trunc, void* stream);
-/* Envs whose staged episode was consumed since the last poll (host must stage a fresh one).
- * Synchronises `stream` only for a B-byte readback. Returns count (>=0) or error. */
 /* render(mode) at another viewport (multi_car_racing.py:511-604 with VP_W x VP_H of :573-586; 'rgb_array' = 600 x 400):
  * the CURRENT state of env `env` as seen by each of its agents, d_out [N, height, width, 3] u8 (device), rows top-down.
- * Skid particles and the score label are not drawn.  Needs obs_enabled. */
+ * Needs obs_enabled. */
 int mcr_render(mcr_env* h, int env, int width, int height, uint8_t* d_out, void* stream);
 /* Episode statistics (what gym's RecordEpisodeStatistics would add): in the step that ends an env's
  * episode (done), mcr_step writes the sum of the step rewards of that episode per agent into d_ep_return[B,N] and
@@ -112,6 +110,10 @@ int mcr_set_episode_stats(mcr_env* h, double* d_ep_return, int32_t* d_ep_len);
  * out2[0] = episodes finished, out2[1] = sum of their returns over all agents.  These are the per-rank inputs of the
  * job-wide metric all-reduce. */
 int mcr_read_rollout_stats(mcr_env* h, double* out2, int reset);
+/* Envs whose staged episode was consumed (installed by a reset or an auto-reset) since the last poll: the host must
+ * stage a fresh one for each.  Reads per-env install counters the kernels write to mapped host memory — no device
+ * synchronisation, `stream` is unused; an install whose kernel has not finished yet shows up in a later poll.
+ * Writes up to `cap` env ids; returns the count (>=0) or an error. */
 int mcr_poll_consumed(mcr_env* h, int32_t* env_ids_out, int cap, void* stream);
 
 /* ---- state access for differential tests / facade attributes (synchronous) */
@@ -132,6 +134,23 @@ void mcr_mass_props(float* out6);
 /* the build's sinf/cosf spec evaluated on the host (tests compare with the device kernel's) */
 void mcr_sincos_host(float a, float* s, float* c);
 int mcr_sincos_device(mcr_env* h, const float* d_in, float* d_sin, float* d_cos, int n, void* stream);
+
+/* ---- full state snapshot / restore of one env (differential tests, checkpoint/resume; SURVEY 8b "mcr_get_state /
+ * mcr_set_state").  The blob holds everything the step path reads for env `env`: per-car f32/f64/u32 state (bodies, joint
+ * impulses, sleep timers, wheel omega/phase, controls, rewards, episode return, limit states, on-road bits, tile-visit
+ * counts, flags), the env record (t, TimeLimit counter, flags), per-tile touch/visit state, the car<->car manifold store
+ * (warm-start impulses) and the CURRENT episode slot (track, quads, tile hulls, spawn poses).  Restoring a blob into any
+ * env index of any handle with the same num_agents continues bit-identically.  Both calls synchronise the device. */
+size_t mcr_state_blob_bytes(const mcr_env* h);
+int mcr_get_state_blob(mcr_env* h, int env, void* blob_out);
+int mcr_set_state_blob(mcr_env* h, int env, const void* blob);
+
+/* ---- synthetic workload (bench.py, tests): counter-based action stream, action of (global env, agent) at step t is a
+ * pure function of (seed, env_offset + env, agent, t): steer ~ U(-1,1), gas ~ U(0,1), brake ~ U(0,1) (the action_space
+ * bounds, multi_car_racing.py:162-165).  Device version writes d_actions [B,N,3] f32 on `stream`; the host twin produces
+ * the same values for the CPU baseline. */
+int mcr_synth_actions(mcr_env* h, float* d_actions, uint64_t seed, uint32_t t, uint32_t env_offset, void* stream);
+void mcr_synth_actions_host(float* out, int num_envs, int num_agents, uint64_t seed, uint32_t t, uint32_t env_offset);
 
 /* ---- instrumentation for bench.py: HIP-event timing of the kernels enqueued by mcr_step, recorded on the
  * launch stream.  `mask` bit k enables timing slot k: 0 collide, 1 dynamics, 2 view, 3/4 = collide/dynamics of

@@ -56,6 +56,11 @@ SYMBOLS = {
     "mcr_debug_read_counters": (_i, [_vp, _vp]),
     "mcr_debug_read_dynamics_stamps": (_i, [_vp, _vp, _i]),
     "mcr_timing_read": (_i, [_vp, _vp, _vp]),
+    "mcr_state_blob_bytes": (ctypes.c_size_t, [_vp]),
+    "mcr_get_state_blob": (_i, [_vp, _i, _vp]),
+    "mcr_set_state_blob": (_i, [_vp, _i, _vp]),
+    "mcr_synth_actions": (_i, [_vp, _vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _vp]),
+    "mcr_synth_actions_host": (None, [_vp, _i, _i, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32]),
 }
 
 _lib = None

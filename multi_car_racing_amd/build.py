@@ -5,7 +5,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "_lib", "libmcr_hip.so")
 SOURCES = ["mcr_hip.hip", "mcr_host.cpp"]
-DEPS = SOURCES + ["mcr_common.h", "mcr_kernels.h", "k_dynamics.h", "k_collide.h", "k_view.h", os.path.join("..", "..", "include", "mcr.h")]
+
+
+def deps():
+    """every file the library is built from: all of csrc/ plus the public header"""
+    import glob
+    out = [f for pat in ("*.h", "*.hip", "*.cpp", "*.inc") for f in glob.glob(os.path.join(CSRC, pat))]
+    return out + [os.path.join(HERE, "..", "include", "mcr.h")]
+
 # -ffp-contract=off: host (x86-64) and gfx950 must round identically (DESIGN.md, numerics)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-value"]
 
@@ -14,7 +21,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    return any(os.path.getmtime(d) > t for d in deps())
 
 
 def build(force=False, verbose=False):

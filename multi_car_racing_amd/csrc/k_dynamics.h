@@ -435,6 +435,12 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
   if (env < env_end) es = p.env[env]; else { es.active = 0; es.resetting = 0; }
   bool run = lane_ok && es.active;
   if (mode == 1) run = run && es.resetting;
+  // Thaw: an env that finished while the host had not staged its next episode yet was frozen (inactive, zero
+  // outputs).  As soon as the staged slot is filled, the next step's main launch re-spawns it exactly like the
+  // auto-reset of a `done` step does (install -> reset pass -> first observation); reward/done of that step are 0.
+  const bool frozen_now = lane_ok && mode == 0 && p.role <= 1 && !es.active && es.frozen && p.auto_reset;
+  const bool thaw = frozen_now && es.staged_ready;
+  if (frozen_now && agent == 0) atomicAdd(&p.counters[3], 1ull);          // env-steps that produced nothing
 
   const McrShapes& S = *p.shapes;
   const float mH = S.hull_invMass, iH = S.hull_invI, mW = S.wheel_invMass, iW = S.wheel_invI;
@@ -888,22 +894,22 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
       p.reward_out[ci] = 0.0;
       if (agent == 0) { p.done_out[env] = 0; if (p.trunc_out) p.trunc_out[env] = 0; }
     }
-    respawn = run && done && p.auto_reset && es.staged_ready;
+    respawn = (run && done && p.auto_reset && es.staged_ready) || thaw;
   }
 
   // ---- env state update by the group leader
-  if (lane_ok && agent == 0 && es.active && (mode == 0 || es.resetting)) {
+  if (lane_ok && agent == 0 && (es.active || thaw) && (mode == 0 || es.resetting)) {
     McrEnvState* E = &p.env[env];
     if (mode == 0) {
       if (respawn) {
         E->slot = es.slot ^ 1; E->staged_ready = 0; E->consumed = es.consumed + 1; E->resetting = 1; E->just_reset = 1;
-        E->t = 0.0; E->steps = 0;
+        E->t = 0.0; E->steps = 0; E->active = 1; E->frozen = 0;
         p.consumed_host[env] = es.consumed + 1;
       } else {
         E->t = es.t + 1.0 / MCR_FPS;
         if (p.actions) E->steps = es.steps + 1;
         E->just_reset = 0;
-        if (done && p.auto_reset) { E->active = 0; atomicAdd(&p.counters[3], 1ull); }   // no staged episode yet (host refill late): freeze until it arrives
+        if (done && p.auto_reset) { E->active = 0; E->frozen = 1; }   // no staged episode yet (host refill late): frozen until it arrives, see `thaw`
       }
       // raster launch order: zoomed-out frames (first second of an episode, :540-542) cost several times a normal
       // one, so their workgroups go FIRST (front of vorder) and cannot end up as the launch's tail
@@ -918,7 +924,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
     }
   }
 
-  if (run) {
+  if (run || thaw) {
   if (respawn) {
     // Car(world, angle, x, y): hull at the pose, wheels at UNROTATED offsets with the same angle
     const McrSlotHeader* H = (const McrSlotHeader*)(p.slots + ((size_t)env * 2 + (es.slot ^ 1)) * MCR_SLOT_BYTES);
@@ -1108,7 +1114,7 @@ __global__ __launch_bounds__(64) void k_install(McrParams p) {
   p.caru[CU_LIMIT * BN + ci] = 0; p.caru[CU_ONROAD * BN + ci] = 0; p.caru[CU_TVC * BN + ci] = 0; p.caru[CU_FLAGS * BN + ci] = 0;
   if (agent == 0) {
     McrEnvState* E = &p.env[env];
-    E->slot = es.slot ^ 1; E->staged_ready = 0; E->consumed = es.consumed + 1; E->resetting = 1; E->just_reset = 1; E->active = 1;
+    E->slot = es.slot ^ 1; E->staged_ready = 0; E->consumed = es.consumed + 1; E->resetting = 1; E->just_reset = 1; E->active = 1; E->frozen = 0;
     E->t = 0.0; E->steps = 0;
     p.consumed_host[env] = es.consumed + 1;
   }

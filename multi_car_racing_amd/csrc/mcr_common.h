@@ -115,7 +115,7 @@ struct McrEnvState {
   int32_t active;          // 0 until the first reset
   int32_t resetting;       // episode installed; the action-less step of reset() (:408) is still pending
   int32_t just_reset;      // the obs being produced is a first observation (a7 bookkeeping is skipped, :435)
-  int32_t pad[1];
+  int32_t frozen;          // auto-reset found no staged episode when this env finished: inactive until the host stages one (then it thaws)
 };
 
 // fixtures of one car in body-local coordinates (host builds them with its b2PolygonShape::Set
@@ -129,6 +129,25 @@ struct McrShapes {
   float anchor_x[4], anchor_y[4];     // revolute joint localAnchorA
   float pad[2];
 };
+
+// ------------------------------------------------------------------ synthetic action stream (bench / tests)
+// Counter-based: the action of (global env g, agent a) at step t is a pure function of (seed, g, a, t) — the same
+// on the device, on the host and whatever the batch or world size.  splitmix64 finaliser, 24-bit uniforms.
+MCR_HD uint64_t mcr_mix64(uint64_t x) {
+  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31;
+  return x;
+}
+MCR_HD float mcr_synth_uniform(uint64_t seed, uint32_t g, uint32_t agent, uint32_t t, uint32_t comp) {
+  const uint64_t ctr = ((uint64_t)t << 32) | ((uint64_t)g * 8u + agent);
+  const uint64_t x = mcr_mix64(mcr_mix64(seed + 0x9e3779b97f4a7c15ull * ctr) + comp);
+  return (float)(x >> 40) * (1.0f / 16777216.0f);
+}
+// (steer ~ U(-1,1), gas ~ U(0,1), brake ~ U(0,1)): the action_space bounds of multi_car_racing.py:162-165
+MCR_HD void mcr_synth_action(uint64_t seed, uint32_t g, uint32_t agent, uint32_t t, float* a3) {
+  a3[0] = mcr_synth_uniform(seed, g, agent, t, 0) * 2.0f - 1.0f;
+  a3[1] = mcr_synth_uniform(seed, g, agent, t, 1);
+  a3[2] = mcr_synth_uniform(seed, g, agent, t, 2);
+}
 
 // ------------------------------------------------------------------ math
 struct V2 { float x, y; };

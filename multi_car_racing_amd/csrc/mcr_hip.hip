@@ -298,6 +298,21 @@ extern "C" int mcr_step(mcr_env* h, const float* d_actions, uint8_t* d_obs, doub
   return MCR_OK;
 }
 
+__global__ void k_synth_actions(float* __restrict__ out, int n_cars, int N, unsigned long long seed, unsigned t, unsigned env_offset) {
+  const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ci >= n_cars) return;
+  float a[3];
+  mcr_synth_action(seed, env_offset + (unsigned)(ci / N), (unsigned)(ci % N), t, a);
+  out[ci * 3] = a[0]; out[ci * 3 + 1] = a[1]; out[ci * 3 + 2] = a[2];
+}
+extern "C" int mcr_synth_actions(mcr_env* h, float* d_actions, uint64_t seed, uint32_t t, uint32_t env_offset, void* stream) {
+  if (!h || !d_actions) { g_err = "null argument"; return MCR_ERR_ARG; }
+  hipLaunchKernelGGL(k_synth_actions, dim3((h->P.BN + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_actions, h->P.BN, h->P.N,
+                     (unsigned long long)seed, t, env_offset);
+  HIPCHK(hipGetLastError());
+  return MCR_OK;
+}
+
 extern "C" int mcr_render(mcr_env* h, int env, int width, int height, uint8_t* d_out, void* stream) {
   if (!h || !d_out) { g_err = "null argument"; return MCR_ERR_ARG; }
   if (env < 0 || env >= h->cfg.num_envs || width < 1 || height < 1 || width > 4096 || height > 4096) { g_err = "env / viewport out of range"; return MCR_ERR_ARG; }
@@ -405,6 +420,84 @@ extern "C" int mcr_get_env_state(mcr_env* h, double* reward, int32_t* tvc, uint8
     HIPCHK(hipMemcpy(&H, h->P.slots + ((size_t)e * 2 + es[e].slot) * MCR_SLOT_BYTES, sizeof(H), hipMemcpyDeviceToHost));
     num_tiles[e] = H.T;
   }
+  return MCR_OK;
+}
+
+// ---------------------------------------------------------------------------- full state snapshot / restore
+namespace {
+struct BlobLayout { size_t carf, card, caru, es, touch, tflags, cc, viewp, carpoly, slot, total; };
+BlobLayout blob_layout(int N) {
+  BlobLayout L; size_t o = 16;                                         // header: magic, N, reserved
+  L.carf = o; o += sizeof(float) * CF_COUNT * N;
+  o = (o + 7) & ~(size_t)7; L.card = o; o += sizeof(double) * CD_COUNT * N;
+  L.caru = o; o += sizeof(uint32_t) * CU_COUNT * N;
+  o = (o + 7) & ~(size_t)7; L.es = o; o += sizeof(McrEnvState);
+  L.touch = o; o += sizeof(uint32_t) * MCR_TILE_CAP;
+  L.tflags = o; o += sizeof(uint16_t) * MCR_TILE_CAP;
+  L.cc = o; o += sizeof(uint32_t) * (MCR_CC_MAX * MCR_CC_WORDS + 4);
+  L.viewp = o; o += sizeof(float) * MCR_VIEWP_FLOATS * N;
+  L.carpoly = o; o += sizeof(float) * MCR_CARPOLY_FLOATS * N;
+  o = (o + 15) & ~(size_t)15; L.slot = o; o += MCR_SLOT_BYTES;
+  L.total = o;
+  return L;
+}
+const uint32_t BLOB_MAGIC = 0x3152434du;   // "MCR1"
+}  // namespace
+
+extern "C" size_t mcr_state_blob_bytes(const mcr_env* h) { return h ? blob_layout(h->P.N).total : 0; }
+
+extern "C" int mcr_get_state_blob(mcr_env* h, int env, void* blob_out) {
+  if (!h || !blob_out) { g_err = "null argument"; return MCR_ERR_ARG; }
+  if (env < 0 || env >= h->P.B) { g_err = "env out of range"; return MCR_ERR_ARG; }
+  if (!h->any_reset) { g_err = "state snapshot before reset()"; return MCR_ERR_STATE; }
+  HIPCHK(hipDeviceSynchronize());
+  const McrParams& P = h->P; const int N = P.N; const size_t BN = P.BN;
+  const BlobLayout L = blob_layout(N);
+  uint8_t* b = (uint8_t*)blob_out;
+  memset(b, 0, L.total);
+  ((uint32_t*)b)[0] = BLOB_MAGIC; ((uint32_t*)b)[1] = (uint32_t)N;
+  HIPCHK(hipMemcpy2D(b + L.carf, sizeof(float) * N, P.carf + (size_t)env * N, sizeof(float) * BN, sizeof(float) * N, CF_COUNT, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy2D(b + L.card, sizeof(double) * N, P.card + (size_t)env * N, sizeof(double) * BN, sizeof(double) * N, CD_COUNT, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy2D(b + L.caru, sizeof(uint32_t) * N, P.caru + (size_t)env * N, sizeof(uint32_t) * BN, sizeof(uint32_t) * N, CU_COUNT, hipMemcpyDeviceToHost));
+  McrEnvState es;
+  HIPCHK(hipMemcpy(&es, P.env + env, sizeof(es), hipMemcpyDeviceToHost));
+  memcpy(b + L.es, &es, sizeof(es));
+  HIPCHK(hipMemcpy(b + L.touch, P.tile_touch + (size_t)env * MCR_TILE_CAP, sizeof(uint32_t) * MCR_TILE_CAP, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(b + L.tflags, P.tile_flags + (size_t)env * MCR_TILE_CAP, sizeof(uint16_t) * MCR_TILE_CAP, hipMemcpyDeviceToHost));
+  const size_t ccw = MCR_CC_MAX * MCR_CC_WORDS + 4;
+  HIPCHK(hipMemcpy(b + L.cc, P.cc_store + (size_t)env * ccw, sizeof(uint32_t) * ccw, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(b + L.viewp, P.viewp + (size_t)env * N * MCR_VIEWP_FLOATS, sizeof(float) * MCR_VIEWP_FLOATS * N, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(b + L.carpoly, P.carpoly + (size_t)env * N * MCR_CARPOLY_FLOATS, sizeof(float) * MCR_CARPOLY_FLOATS * N, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(b + L.slot, P.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES, MCR_SLOT_BYTES, hipMemcpyDeviceToHost));
+  return MCR_OK;
+}
+
+extern "C" int mcr_set_state_blob(mcr_env* h, int env, const void* blob) {
+  if (!h || !blob) { g_err = "null argument"; return MCR_ERR_ARG; }
+  if (env < 0 || env >= h->P.B) { g_err = "env out of range"; return MCR_ERR_ARG; }
+  const McrParams& P = h->P; const int N = P.N; const size_t BN = P.BN;
+  const uint8_t* b = (const uint8_t*)blob;
+  if (((const uint32_t*)b)[0] != BLOB_MAGIC || ((const uint32_t*)b)[1] != (uint32_t)N) { g_err = "not a state blob of this num_agents"; return MCR_ERR_ARG; }
+  HIPCHK(hipDeviceSynchronize());
+  const BlobLayout L = blob_layout(N);
+  HIPCHK(hipMemcpy2D(P.carf + (size_t)env * N, sizeof(float) * BN, b + L.carf, sizeof(float) * N, sizeof(float) * N, CF_COUNT, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy2D(P.card + (size_t)env * N, sizeof(double) * BN, b + L.card, sizeof(double) * N, sizeof(double) * N, CD_COUNT, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy2D(P.caru + (size_t)env * N, sizeof(uint32_t) * BN, b + L.caru, sizeof(uint32_t) * N, sizeof(uint32_t) * N, CU_COUNT, hipMemcpyHostToDevice));
+  // the staging protocol (which slot is current, whether a staged episode waits, install counter) belongs to the
+  // TARGET handle; everything else of the env record comes from the blob
+  McrEnvState cur, in;
+  HIPCHK(hipMemcpy(&cur, P.env + env, sizeof(cur), hipMemcpyDeviceToHost));
+  memcpy(&in, b + L.es, sizeof(in));
+  in.slot = cur.slot; in.staged_ready = cur.staged_ready; in.consumed = cur.consumed;
+  HIPCHK(hipMemcpy(P.env + env, &in, sizeof(in), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(P.tile_touch + (size_t)env * MCR_TILE_CAP, b + L.touch, sizeof(uint32_t) * MCR_TILE_CAP, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(P.tile_flags + (size_t)env * MCR_TILE_CAP, b + L.tflags, sizeof(uint16_t) * MCR_TILE_CAP, hipMemcpyHostToDevice));
+  const size_t ccw = MCR_CC_MAX * MCR_CC_WORDS + 4;
+  HIPCHK(hipMemcpy(P.cc_store + (size_t)env * ccw, b + L.cc, sizeof(uint32_t) * ccw, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(P.viewp + (size_t)env * N * MCR_VIEWP_FLOATS, b + L.viewp, sizeof(float) * MCR_VIEWP_FLOATS * N, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(P.carpoly + (size_t)env * N * MCR_CARPOLY_FLOATS, b + L.carpoly, sizeof(float) * MCR_CARPOLY_FLOATS * N, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(P.slots + ((size_t)env * 2 + cur.slot) * MCR_SLOT_BYTES, b + L.slot, MCR_SLOT_BYTES, hipMemcpyHostToDevice));
+  h->any_reset = true;
   return MCR_OK;
 }
 

@@ -449,3 +449,9 @@ extern "C" int mcr_episode_unpack(const void* blob_in, int32_t* T, int32_t* P, i
   if (spawn) memcpy(spawn, H->spawn, sizeof(H->spawn));
   return MCR_OK;
 }
+
+// host twin of mcr_synth_actions (same counter-based stream; the CPU baseline and the tests consume it)
+extern "C" void mcr_synth_actions_host(float* out, int num_envs, int num_agents, uint64_t seed, uint32_t t, uint32_t env_offset) {
+  for (int e = 0; e < num_envs; ++e)
+    for (int a = 0; a < num_agents; ++a) mcr_synth_action(seed, env_offset + (uint32_t)e, (uint32_t)a, t, out + ((size_t)e * num_agents + a) * 3);
+}

@@ -38,23 +38,36 @@ class TimeLimit:
         return self.env
 
 
-_registered_with_gym = False
+_ENTRY_POINT = "multi_car_racing_amd:MultiCarRacing"
 
 
 def register():
-    global _registered_with_gym
+    """Register the id with a real `gym` if one is importable.  Returns True only when `gym.make(ENV_ID)` is known to
+    construct THIS package's env: an id already registered by someone else (e.g. the reference package itself) or a
+    gym that rejects the entry point leaves the built-in TimeLimit path in charge."""
     try:
-        from gym.envs.registration import register as gym_register
+        import gym
+        from gym.envs.registration import register as gym_register, registry
     except Exception:
         return False
-    if not _registered_with_gym:
+
+    def spec_entry_point():
         try:
-            gym_register(id=ENV_ID, entry_point="multi_car_racing_amd:MultiCarRacing",
-                         max_episode_steps=MAX_EPISODE_STEPS, reward_threshold=REWARD_THRESHOLD)
+            specs = getattr(registry, "env_specs", registry)
+            spec = specs.get(ENV_ID) if hasattr(specs, "get") else None
+            return getattr(spec, "entry_point", None) if spec is not None else None
         except Exception:
-            pass
-        _registered_with_gym = True
-    return True
+            return None
+
+    ep = spec_entry_point()
+    if ep is None:
+        try:
+            gym_register(id=ENV_ID, entry_point=_ENTRY_POINT, max_episode_steps=MAX_EPISODE_STEPS,
+                         reward_threshold=REWARD_THRESHOLD)
+        except getattr(gym, "error", type("E", (), {"Error": Exception})).Error:
+            pass                          # re-registration race: decided by the spec check below
+        ep = spec_entry_point()
+    return ep == _ENTRY_POINT
 
 
 def make(env_id=ENV_ID, **kwargs):
@@ -62,5 +75,8 @@ def make(env_id=ENV_ID, **kwargs):
         raise ValueError(f"unknown environment id {env_id!r}; this package provides {ENV_ID!r}")
     if register():
         import gym
-        return gym.make(env_id, **kwargs)
+        env = gym.make(env_id, **kwargs)
+        if isinstance(getattr(env, "unwrapped", env), MultiCarRacing):
+            return env
+        env.close()
     return TimeLimit(MultiCarRacing(**kwargs), MAX_EPISODE_STEPS)

@@ -38,7 +38,8 @@ class ShardedVecEnv:
         from .vec_env import VecMultiCarRacing
         self.rank, self.world_size = rank, world_size
         self.lo, self.hi = shard_range(total_envs, rank, world_size)
-        self.env = VecMultiCarRacing(self.hi - self.lo, num_agents, device=device, seed=seed, env_offset=self.lo, **kw)
+        self.env = VecMultiCarRacing(self.hi - self.lo, num_agents, device=device, seed=seed, env_offset=self.lo,
+                                     world_size=world_size, **kw)
 
     def __getattr__(self, name):
         return getattr(self.env, name)

