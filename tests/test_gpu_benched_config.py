@@ -69,13 +69,44 @@ def _cmp_state(env, followers, idx, what):
         assert es["num_tiles"][e] == T
 
 
-def _run_sampled(torch, O, B, N, seed, steps, n_sample, max_steps, masked_reset_at=(), state_every=50, car1_floors=False):
+def _actions(torch, g, B, N, car1_floors):
+    a = torch.rand((B, N, 3), device="cuda", generator=g); a[..., 0] = a[..., 0] * 2 - 1
+    if car1_floors:
+        a[:, 1:, 1] = 1.0; a[:, 0, 2] *= 0.3
+    return a
+
+
+def _contact_envs(torch, B, N, seed, steps, max_steps, car1_floors):
+    """GPU-only pre-pass of the SAME deterministic rollout: which envs hold a touching car<->car pair at some step?
+    (the sampled comparison then follows those envs from their reset, so the contact path is certain to be checked)"""
+    from multi_car_racing_amd.vec_env import VecMultiCarRacing
+    from multi_car_racing_amd import _lib
+    env = VecMultiCarRacing(B, N, seed=seed, use_random_direction=True, auto_reset=True, max_episode_steps=max_steps,
+                            car_contacts=True, async_refill=True, streams=2)
+    env.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    cnt = np.zeros(B, np.int32); seen = np.zeros(B, bool)
+    for k in range(steps):
+        env.step(_actions(torch, g, B, N, car1_floors))
+        if k % 3 == 2:
+            _lib.check(env.L.mcr_debug_read_contact_counts(env.h, _lib.ptr(cnt))); seen |= cnt > 0
+    env.close()
+    return np.nonzero(seen)[0]
+
+
+def _run_sampled(torch, O, B, N, seed, steps, n_sample, max_steps, masked_reset_at=(), state_every=50, car1_floors=False,
+                 prefer=None):
     from multi_car_racing_amd.vec_env import VecMultiCarRacing
     env = VecMultiCarRacing(B, N, seed=seed, use_random_direction=True, auto_reset=True, max_episode_steps=max_steps,
                             car_contacts=True, async_refill=True, streams=2)
     obs = env.reset()
     rs = np.random.RandomState(seed + 99)
-    idx = np.sort(rs.choice(B, n_sample, replace=False))
+    if prefer is not None and len(prefer):                 # half the sample from the preferred envs, the rest at random
+        pick = rs.choice(prefer, min(len(prefer), n_sample // 2), replace=False)
+        rest = np.setdiff1d(np.arange(B), pick)
+        idx = np.sort(np.concatenate([pick, rs.choice(rest, n_sample - len(pick), replace=False)]))
+    else:
+        idx = np.sort(rs.choice(B, n_sample, replace=False))
     idx_t = torch.from_numpy(idx).cuda()
     fol = [_Follower(O, N, seed, int(g), max_steps) for g in idx]
     o0 = obs[idx_t].cpu().numpy()
@@ -85,9 +116,7 @@ def _run_sampled(torch, O, B, N, seed, steps, n_sample, max_steps, masked_reset_
     threads = os.cpu_count() or 1
     n_resets = n_contacts = 0
     for k in range(steps):
-        a = torch.rand((B, N, 3), device="cuda", generator=g); a[..., 0] = a[..., 0] * 2 - 1
-        if car1_floors:
-            a[:, 1:, 1] = 1.0; a[:, 0, 2] *= 0.3
+        a = _actions(torch, g, B, N, car1_floors)
         obs, rew, done, info = env.step(a)
         check_px = (k % state_every == state_every - 1)
         a_s = a[idx_t].cpu().numpy()
@@ -137,8 +166,10 @@ def test_benched_config_b4096_sampled_oracles(torch_cuda, oracle):
 def test_benched_config_b4096_contacts_sample(torch_cuda, oracle):
     """Same batch with car 1 flooring it (rear-end collisions): the sampled envs must exercise car<->car contacts and
     the contact side stream at full batch size."""
+    hot = _contact_envs(torch_cuda, 4096, 2, 21, 260, 120, True)
+    assert len(hot) > 0, "rollout produced no car<->car contact in 4096 envs"
     n_resets, n_contacts, frozen = _run_sampled(torch_cuda, oracle, B=4096, N=2, seed=21, steps=260, n_sample=96,
-                                                max_steps=120, state_every=40, car1_floors=True)
+                                                max_steps=120, state_every=40, car1_floors=True, prefer=hot)
     assert n_resets >= 96 and n_contacts > 0, (n_resets, n_contacts)
     assert frozen == 0
 
@@ -148,8 +179,9 @@ def test_n8_b4096_properties_and_sampled_oracles(torch_cuda, oracle):
     pixels of all 8 views) + size-independent properties + batch independence (env g in B=4096 == env g in B=4)."""
     torch = torch_cuda
     from multi_car_racing_amd.vec_env import VecMultiCarRacing
+    hot = _contact_envs(torch, 4096, 8, 23, 130, 100, True)
     n_resets, n_contacts, frozen = _run_sampled(torch, oracle, B=4096, N=8, seed=23, steps=130, n_sample=24, max_steps=100,
-                                                state_every=26, car1_floors=True)
+                                                state_every=26, car1_floors=True, prefer=hot)
     assert n_resets >= 24 and n_contacts > 0 and frozen == 0, (n_resets, n_contacts, frozen)
     big = VecMultiCarRacing(4096, 8, seed=5, use_random_direction=True, auto_reset=True, async_refill=True, streams=2)
     small = VecMultiCarRacing(4, 8, seed=5, use_random_direction=True, auto_reset=True, async_refill=False, streams=1)
