@@ -857,6 +857,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
   double step_reward = 0.0, reward = 0.0, prev_reward = 0.0, epret = 0.0;
   uint32_t tvc = 0, flags = 0;
   if (run) { reward = p.card[CD_REWARD * BN + ci]; prev_reward = p.card[CD_PREV_REWARD * BN + ci]; tvc = p.caru[CU_TVC * BN + ci]; flags = p.caru[CU_FLAGS * BN + ci]; }
+  const double reward_shown = reward;      // the score label is drawn (:431) before this step's -0.1 (:437)
   int T = 0;
   if (env < env_end && es.active) T = ((const McrSlotHeader*)(p.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES))->T;
   if (mode == 0) {
@@ -913,7 +914,9 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
       }
       // raster launch order: zoomed-out frames (first second of an episode, :540-542) cost several times a normal
       // one, so their workgroups go FIRST (front of vorder) and cannot end up as the launch's tail
-      if (p.role != 2 && (respawn || !(done && p.auto_reset))) {
+      // (only the main launch fills the list: envs of the contact / resume launches are drawn by launches of their own, and
+      // an append from those streams would race with the main raster launch that is reading the counts)
+      if (p.role < 2 && (respawn || !(done && p.auto_reset))) {
         const bool heavy = respawn || es.t + 1.0 / MCR_FPS < 1.0;
         if (heavy) p.vorder[atomicAdd(&p.vcount[0], 1)] = env;
         else p.vorder[p.B - 1 - atomicAdd(&p.vcount[1], 1)] = env;
@@ -1019,6 +1022,30 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
       vp[VP_IND + (5 + i) * 4 + 2] = (float)(2 * hH) * ky; vp[VP_IND + (5 + i) * 4 + 3] = (float)(4 * hH) * ky;
     }
     vp[VP_HUDTOP] = hud_top;
+    vp[VP_SCORE] = __int_as_float(mcr_label_value(reward_shown));
+    vp[VP_OLDFLAGS] = __uint_as_float(flags);                       // :669-674 draws the flag from the value the PREVIOUS step computed
+    {
+      // Light grass squares the viewport can see + "is the whole viewport inside the playfield", from the inverse camera at
+      // the four corners of the scene rectangle, in checker units U = world.x / (2k), V = world.y / (2k), k = PLAYFIELD / 20:
+      // the playfield is |U|,|V| <= 10 and light square m covers [m, m + 0.5] (:615-627).  One pixel of slack.
+      const float hk = 0.5f / (float)(MCR_PLAYFIELD / 20.0);
+      const float aU = vp[VP_INV + 0] * hk, bU = vp[VP_INV + 1] * hk, cU = vp[VP_INV + 2] * hk;
+      const float aV = vp[VP_INV + 3] * hk, bV = vp[VP_INV + 4] * hk, cV = vp[VP_INV + 5] * hk;
+      float umin = MCR_MAXFLT, umax = -MCR_MAXFLT, vmin = MCR_MAXFLT, vmax = -MCR_MAXFLT;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float X = (k & 1) ? 96.0f : 0.0f, Y = (k & 2) ? 96.0f : 12.0f;
+        const float u = aU * X + bU * Y + cU, v = aV * X + bV * Y + cV;
+        umin = fminf(umin, u); umax = fmaxf(umax, u); vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+      }
+      const float mu = fabsf(aU) + fabsf(bU) + 1e-3f, mv = fabsf(aV) + fabsf(bV) + 1e-3f;
+      const bool inside_field = umin - mu >= -10.0f && umax + mu <= 10.0f && vmin - mv >= -10.0f && vmax + mv <= 10.0f;
+      int a0 = (int)ceilf(umin - mu - 0.5f), a1 = (int)floorf(umax + mu), b0 = (int)ceilf(vmin - mv - 0.5f), b1 = (int)floorf(vmax + mv);
+      a0 = max(a0, -10); a1 = min(a1, 9); b0 = max(b0, -10); b1 = min(b1, 9);
+      vp[VP_GRASS + 0] = __int_as_float(a0); vp[VP_GRASS + 1] = __int_as_float(max(a1 - a0 + 1, 0));
+      vp[VP_GRASS + 2] = __int_as_float(b0); vp[VP_GRASS + 3] = __int_as_float(max(b1 - b0 + 1, 0));
+      vp[VP_GRASS + 4] = __int_as_float(inside_field ? 1 : 0);
+    }
     // world-space vertices of the 12 Car.draw polygons (trans*v in f32, as pybox2d hands them to the viewer).
     // The record is AoS on purpose (the raster reads a car's 832 bytes as one run); every lane writes it with
     // 16-byte stores — a polygon is 4 of them — and each distinct vertex is transformed once (padding repeats the last).

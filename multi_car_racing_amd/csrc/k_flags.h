@@ -1,0 +1,95 @@
+// k_flags.h — one wavefront per car: the backward / on-grass bookkeeping of multi_car_racing.py:446-495 on the poses
+// the step just produced.  Its results (`driving_backward`, `driving_on_grass`) have no reward effect (K_BACKWARD = 0,
+// :78); they reach pixels one step later (the HUD flag is drawn from LAST step's value, which k_dynamics hands to the
+// raster in the view record) and the host through mcr_get_env_state.  Round 1 computed them inside the raster kernel;
+// they are a per-car O(T + P) scan with f64 tails (atan2, fmod) that cost the raster registers, barriers and a serial
+// lane — as a kernel of its own the scan is 8,192 independent wavefronts that overlap with the raster's tail.
+//   nearest track point (:465-467, np.linalg.norm + argmin = first minimum): f32 distances of all tiles, wave minimum,
+//     exact f64 distance for the tiles within the rounding band of that minimum, lowest index among exact ties;
+//   on grass (:470-472, shapely Point.within = strict interior): f32 bbox prefilter, exact f64 test on the polygon the
+//     reference builds for the tile / kerb;
+//   heading vs track direction (:449-495) by one lane.
+#pragma once
+#include "k_raster_common.h"
+
+__global__ __launch_bounds__(64) void k_flags(McrParams p) {
+  const int lane = threadIdx.x;
+  const int N = p.N, BN = p.BN;
+  const int ci = p.env0 * N + (int)blockIdx.x;
+  if (ci >= (p.env0 + p.nenv) * N) return;
+  const int env = ci / N;
+  const McrEnvState es = p.env[env];
+  if (!es.active || es.just_reset) return;                   // reset() -> step(None) skips the block (:435); a re-spawned car keeps its zeroed flags
+  const uint8_t* __restrict__ slot = p.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES;
+  const McrSlotHeader* H = (const McrSlotHeader*)slot;
+  const int T = H->T, P = H->P;
+  const McrShapes& S = *p.shapes;
+  const float hvx = p.carf[(CF_VX + 0) * BN + ci], hvy = p.carf[(CF_VY + 0) * BN + ci], ha = p.carf[(CF_A + 0) * BN + ci];
+  const Xf hxf = xf_of(v2(p.carf[(CF_CX + 0) * BN + ci], p.carf[(CF_CY + 0) * BN + ci]), ha, v2(S.hull_lcx, S.hull_lcy));
+  const float fpx = hxf.p.x, fpy = hxf.p.y;                  // hull.position (body origin)
+  const double dpx = (double)fpx, dpy = (double)fpy;
+  const float4* __restrict__ QA = (const float4*)(slot + MCR_OFF_QA); const float4* __restrict__ QB = (const float4*)(slot + MCR_OFF_QB);
+  const uint32_t* __restrict__ QM = (const uint32_t*)(slot + MCR_OFF_QMETA);
+  const double* __restrict__ TX = (const double*)(slot + MCR_OFF_TRACK_X); const double* __restrict__ TY = (const double*)(slot + MCR_OFF_TRACK_Y);
+
+  // pass 1 over road_poly: on-grass + f32 distance to every tile's track point (~ midpoint of the tile's leading edge)
+  bool inside = false;
+  float dmin = MCR_MAXFLT;
+  for (int q = lane; q < P; q += 64) {
+    const float4 a = QA[q], b = QB[q];
+    const uint32_t meta = QM[q];
+    const uint32_t tile1 = (meta >> 8) & 0x3ffu, owner1 = meta >> 18;
+    const float bx0 = fminf(fminf(a.x, a.z), fminf(b.x, b.z)) - 0.02f, bx1 = fmaxf(fmaxf(a.x, a.z), fmaxf(b.x, b.z)) + 0.02f;
+    const float by0 = fminf(fminf(a.y, a.w), fminf(b.y, b.w)) - 0.02f, by1 = fmaxf(fmaxf(a.y, a.w), fmaxf(b.y, b.w)) + 0.02f;
+    if (!inside && fpx >= bx0 && fpx <= bx1 && fpy >= by0 && fpy <= by1)
+      inside = point_in_road_poly_f64(slot, (int)(tile1 ? tile1 : owner1) - 1, T, tile1 == 0, dpx, dpy);
+    if (tile1) {
+      const float mx = 0.5f * (a.x + a.z), my = 0.5f * (a.y + a.w);
+      const float ddx = fpx - mx, ddy = fpy - my;
+      dmin = fminf(dmin, ddx * ddx + ddy * ddy);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, o));
+  const bool any_inside = __any(inside) != 0;
+  // pass 2: exact distance (f64, as np.linalg.norm evaluates it) of the tiles within the f32 error band of the minimum
+  const float band = sqrtf(dmin) * (1.0f + 1e-5f) + 2e-3f;
+  const float thr = band * band;
+  double bd = 1e300; int bi = 0x7fffffff;
+  for (int q = lane; q < P; q += 64) {
+    const uint32_t tile1 = (QM[q] >> 8) & 0x3ffu;
+    if (!tile1) continue;
+    const float4 a = QA[q];
+    const float mx = 0.5f * (a.x + a.z), my = 0.5f * (a.y + a.w);
+    const float ddx = fpx - mx, ddy = fpy - my;
+    if (ddx * ddx + ddy * ddy <= thr) {
+      const int t = (int)tile1 - 1;
+      const double dx = dpx - TX[t], dy = dpy - TY[t];
+      const double d = sqrt(dx * dx + dy * dy);
+      if (d < bd || (d == bd && t < bi)) { bd = d; bi = t; }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const double od = __shfl_xor(bd, o); const int oi = __shfl_xor(bi, o);
+    if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+  }
+  if (lane != 0) return;
+  if (bi == 0x7fffffff) {                                      // cannot happen with a valid track; exact full scan keeps the result defined
+    bd = 1e300; bi = 0;
+    for (int t = 0; t < T; ++t) { const double dx = dpx - TX[t], dy = dpy - TY[t]; const double d = sqrt(dx * dx + dy * dy); if (d < bd) { bd = d; bi = t; } }
+  }
+  const double* TB = (const double*)(slot + MCR_OFF_TRACK_B);
+  const double TWO_PI = 2 * 3.141592653589793, PI = 3.141592653589793;
+  double car_angle;
+  const double vx = (double)hvx, vy = (double)hvy;
+  if (sqrt(vx * vx + vy * vy) > 0.5) car_angle = -atan2(vx, vy); else car_angle = (double)ha;
+  car_angle = fmod(car_angle + TWO_PI, TWO_PI); if (car_angle < 0) car_angle += TWO_PI;
+  double desired = TB[bi];
+  if (H->cw) desired += PI;
+  desired = fmod(desired + TWO_PI, TWO_PI); if (desired < 0) desired += TWO_PI;
+  double diff = fabs(desired - car_angle);
+  if (diff > PI) diff = fabs(diff - TWO_PI);
+  uint32_t f = 0;
+  if (diff > PI / 2) f |= 1u;
+  if (!any_inside) f |= 2u;
+  p.caru[CU_FLAGS * BN + ci] = f;
+}

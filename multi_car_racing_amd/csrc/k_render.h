@@ -3,10 +3,10 @@
 // a straightforward tile rasteriser (16x16 pixels per workgroup, road quads culled per tile in chunks of 256 through
 // LDS, painter's order == highest draw index wins) that reuses the camera, HUD rectangles and car polygons the last
 // k_dynamics left in HBM.  Same sampling rule as k_view: pixel centres, inside <=> all oriented edge functions >= 0.
-// NOT reproduced (documented deviations): skid particles (Car.draw(viewer, True), :564 — GL wide lines) and the
-// font-rendered score label (:665-666).
+// The score label (:665-666) is the build's bitmap font (k_raster_common.h).  NOT reproduced: skid particles
+// (Car.draw(viewer, True), :564 — GL wide lines).
 #pragma once
-#include "k_view.h"
+#include "k_raster_common.h"
 
 #define RENDER_TILE 16
 
@@ -143,6 +143,8 @@ __global__ __launch_bounds__(256) void k_render_frame(McrParams p, int env, int 
       const float x0 = vp[VP_IND + i * 4] * rx, x1 = vp[VP_IND + i * 4 + 1] * rx, y0 = vp[VP_IND + i * 4 + 2] * ry, y1 = vp[VP_IND + i * 4 + 3] * ry;
       if (x1 > x0 && y1 > y0 && cx >= x0 && cx <= x1 && cy >= y0 && cy <= y1) col = ind_col[i];
     }
+    // score label (:665-666) of the CURRENT reward (render() between steps shows self.reward after the step's -0.1)
+    if (label_on(mcr_label_value(p.card[CD_REWARD * BN + ci]), cx * (1000.0f / (float)W), cy * (800.0f / (float)H))) col = PAL_WHITE;
     if ((p.caru[CU_FLAGS * BN + ci] & 1u) && p.backwards_flag) {
       const float fx[3] = {900.0f * kx, 925.0f * kx, 950.0f * kx}, fy[3] = {30.0f * ky, 70.0f * ky, 30.0f * ky};
       float fe[9];

@@ -5,6 +5,7 @@
 #include "k_dynamics.h"
 #include "k_collide.h"
 #include "k_view.h"
+#include "k_flags.h"
 #include "k_render.h"
 #include <hip/hip_runtime.h>
 #include <string>
@@ -47,7 +48,7 @@ struct mcr_env {
   int32_t* stage_ids;         // [B] device scratch of mcr_stage_episodes
   hipStream_t s_side, s_defer; // internal streams: the contact envs' chain, the deferred envs' chain
   hipEvent_t ev_fork, ev_join, ev_fork2, ev_join2;
-  float* view_scratch;        // per-view spill area of the rasteriser (zoomed-out frames only)
+  unsigned long long* view_stamps;   // [BN][16] phase clocks of the rasteriser (debug bit 5)
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -83,11 +84,11 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   const size_t o_shapes = carve(sizeof(McrShapes));
   const size_t o_viewp = carve(sizeof(float) * MCR_VIEWP_FLOATS * BN);
   const size_t o_carpoly = carve(sizeof(float) * MCR_CARPOLY_FLOATS * BN);
-  const size_t o_vscratch = carve(sizeof(float) * (size_t)VIEW_SCRATCH_FLOATS * BN);
+  const size_t o_vscratch = carve(sizeof(unsigned long long) * 16 * BN);
   const size_t o_slots = carve((size_t)B * 2 * MCR_SLOT_BYTES);
   h->slab_bytes = off;
   if (hipMalloc(&h->slab, off) != hipSuccess) { g_err = "hipMalloc failed"; delete h; return MCR_ERR_HIP; }
-  (void)hipMemset(h->slab, 0, o_vscratch);
+  (void)hipMemset(h->slab, 0, o_slots);
   uint8_t* base = (uint8_t*)h->slab;
   McrParams& P = h->P;
   memset(&P, 0, sizeof(P));
@@ -95,7 +96,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   P.carf = (float*)(base + o_carf); P.card = (double*)(base + o_card); P.caru = (uint32_t*)(base + o_caru);
   P.env = (McrEnvState*)(base + o_env); P.tile_touch = (uint32_t*)(base + o_touch); P.tile_flags = (uint16_t*)(base + o_tflags);
   P.cc_store = (uint32_t*)(base + o_cc); P.shapes = (const McrShapes*)(base + o_shapes); P.slots = base + o_slots;
-  h->view_scratch = (float*)(base + o_vscratch);
+  h->view_stamps = (unsigned long long*)(base + o_vscratch);
   P.viewp = (float*)(base + o_viewp);
   P.part = base + o_part; P.dlist = (int32_t*)(base + o_dlist); P.defer_state = base + o_dstate; P.counters = (unsigned long long*)(base + o_counters); P.stats = (double*)(base + o_stats);
   h->stage_ids = (int32_t*)(base + o_stage_ids); P.vcount = (int32_t*)(base + o_vorder); P.vorder = P.vcount + 2; P.dbg_stamps = (unsigned long long*)(base + o_stamps); P.clist = (int32_t*)(base + o_clist);
@@ -103,6 +104,8 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   P.auto_reset = cfg->auto_reset; P.max_steps = cfg->max_episode_steps; P.car_contacts = cfg->car_contacts;
   P.backwards_flag = cfg->backwards_flag; P.use_ego_color = cfg->use_ego_color; P.h_ratio = cfg->h_ratio;
   McrShapes S; mcr_build_shapes(&S);
+  // the raster gives two record slots to hull polygon 2 (HULL_POLY3, 8 vertices) and one to every other car polygon
+  if (S.hull[0].n > 4 || S.hull[1].n > 4 || S.hull[2].n > 8 || S.hull[3].n > 4 || S.wheel.n > 4) { g_err = "unexpected car fixture vertex counts"; (void)hipFree(h->slab); delete h; return MCR_ERR_STATE; }
   (void)hipMemcpy((void*)P.shapes, &S, sizeof(S), hipMemcpyHostToDevice);
   if (hipHostMalloc((void**)&h->consumed_host, sizeof(int32_t) * B, hipHostMallocMapped) != hipSuccess) { g_err = "hipHostMalloc failed"; (void)hipFree(h->slab); delete h; return MCR_ERR_HIP; }
   memset(h->consumed_host, 0, sizeof(int32_t) * B);
@@ -192,11 +195,9 @@ static hipEvent_t get_event(mcr_env* h) {
     if (tm_) { (void)hipEventRecord(tl_.b, st); h->pending.push_back(tl_); }                   \
   } while (0)
 
-// raster launch: the instantiation depends on the agent count (k_view.h)
-static void launch_view(mcr_env* h, int kid, int grid, hipStream_t st, const McrParams& P, int view_flags, int only_just_reset) {
-  const size_t lds = (size_t)P.N * 12 * 6 * 16;      // car polygon edge records
-  if (P.N <= 2) LAUNCH_LDS(kid, k_view, grid, VIEW_THREADS, lds, st, P, h->view_scratch, view_flags, only_just_reset);
-  else LAUNCH_LDS(kid, k_view_many, grid, VIEW_THREADS, lds, st, P, h->view_scratch, view_flags, only_just_reset);
+// raster launch (k_view.h): one workgroup per env (its N agent views one after the other)
+static void launch_view(mcr_env* h, int kid, int grid, hipStream_t st, const McrParams& P, int only_just_reset) {
+  LAUNCH(kid, k_view, grid, VIEW_THREADS, st, P, h->view_stamps, only_just_reset);
 }
 
 // reset(): install -> collide(1) -> dynamics(1) -> view, in order on one stream
@@ -207,7 +208,7 @@ static void launch_reset(mcr_env* h, McrParams P, hipStream_t st) {
   hipLaunchKernelGGL(k_install, dim3(dyn_blocks), dim3(64), 0, st, P);
   LAUNCH_LDS(3, k_collide, B, 64, col::lds_bytes(N), st, P, 1);
   LAUNCH(4, k_dynamics, dyn_blocks, 64, st, P, 1);
-  if (P.obs) launch_view(h, 2, B * N, st, P, 0, 1);
+  if (P.obs) launch_view(h, 2, B, st, P, 1);
 }
 
 // step(): collide -> dynamics [-> auto-reset pass] -> view on the caller's stream `st`.
@@ -225,7 +226,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   const int B = P.B, N = P.N;
   const int dyn_blocks = (B * P.G + 63) / 64;
   const int side_blocks = (B + MCR_SIDE_ENVS_PER_WAVE - 1) / MCR_SIDE_ENVS_PER_WAVE;   // list launches: few envs per wavefront
-  const bool draw = P.obs || view_flags;
+  const bool draw = P.obs != nullptr;
   P.role = 0; P.split = h->split ? 1 : 0; P.defer_after = 0;
   if (h->split) {      // the contact list is double-buffered by step parity; no memset on the critical path
     int32_t* base = h->P.clist;
@@ -240,7 +241,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     (void)hipStreamWaitEvent(h->s_side, h->ev_fork, 0);
     P.role = 2;
     LAUNCH(5, k_dynamics, side_blocks, 64, h->s_side, P, 0);
-    if (draw) launch_view(h, 6, B * N, h->s_side, P, view_flags, 0);
+    if (draw) launch_view(h, 6, B, h->s_side, P, 0);
     (void)hipEventRecord(h->ev_join, h->s_side);
     P.role = 1;
   }
@@ -250,7 +251,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     (void)hipStreamWaitEvent(h->s_defer, h->ev_fork2, 0);
     P.role = 3;
     LAUNCH(7, k_dynamics, side_blocks, 64, h->s_defer, P, 0);
-    if (draw) launch_view(h, 7, B * N, h->s_defer, P, view_flags, 0);
+    if (draw) launch_view(h, 7, B, h->s_defer, P, 0);
     (void)hipEventRecord(h->ev_join2, h->s_defer);
     P.role = 1;
   }
@@ -259,7 +260,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     LAUNCH(4, k_dynamics, dyn_blocks, 64, st, P, 1);
   }
   P.use_vorder = 1;
-  if (draw) launch_view(h, 2, (B + 7) / 8 * 8 * N, st, P, view_flags, 0);
+  if (draw) launch_view(h, 2, B, st, P, 0);
   P.use_vorder = 0;
   if (h->split) {
     (void)hipStreamWaitEvent(st, h->ev_join, 0);
@@ -268,8 +269,13 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
       P.role = 4;
       LAUNCH_LDS(7, k_collide, B, 64, col::lds_bytes(N), st, P, 1);
       LAUNCH(7, k_dynamics, side_blocks, 64, st, P, 1);
-      if (draw) launch_view(h, 7, B * N, st, P, view_flags, 1);
+      if (draw) launch_view(h, 7, B, st, P, 1);
     }
+  }
+  // backward / on-grass bookkeeping (:446-495) on the poses this step produced, one wavefront per car (k_flags.h)
+  if (view_flags) {
+    P.role = 0;
+    hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, st, P);
   }
 }
 
@@ -530,9 +536,9 @@ extern "C" int mcr_sincos_device(mcr_env* h, const float* d_in, float* d_sin, fl
 }
 
 extern "C" int mcr_debug_read_view_scratch(mcr_env* h, int view, void* out, int nbytes) {
-  if (!h || !out) return MCR_ERR_ARG;
+  if (!h || !out || view < 0 || view >= h->P.BN || nbytes < 0 || nbytes > 128) return MCR_ERR_ARG;
   HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipMemcpy(out, h->view_scratch + (size_t)(view + 1) * VIEW_SCRATCH_FLOATS - 64, nbytes, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out, h->view_stamps + (size_t)view * 16, nbytes, hipMemcpyDeviceToHost));
   return MCR_OK;
 }
 extern "C" int mcr_debug_read_counters(mcr_env* h, uint64_t* out4) {

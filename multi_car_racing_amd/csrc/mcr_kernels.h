@@ -50,7 +50,13 @@ struct McrParams {
 
 // per-car view parameters (f32): camera (:540-556) and HUD rectangles (:634-674) in pixel units
 #define MCR_VIEWP_FLOATS 48
-enum { VP_CAM = 0 /*m00 m01 m10 m11 tx ty*/, VP_INV = 6 /*ax bx cx0 ay by cy0*/, VP_IND = 12 /*7 x (x0 x1 y0 y1)*/, VP_HUDTOP = 40 };
+enum { VP_CAM = 0 /*m00 m01 m10 m11 tx ty*/, VP_INV = 6 /*ax bx cx0 ay by cy0*/, VP_IND = 12 /*7 x (x0 x1 y0 y1)*/, VP_HUDTOP = 40,
+       VP_SCORE = 41 /*int bits: the integer the score label shows, "%04i" % reward[agent] at render time (:431 precedes :437)*/,
+       VP_OLDFLAGS = 42 /*u32 bits: the car's backward / on-grass flags as of the previous step — what this step's HUD flag shows*/,
+       VP_GRASS = 43 /*5 x int bits: light grass squares the viewport can see (first column, columns, first row, rows in the
+                       20 x 20 lattice of :620-627) and 1 if the whole viewport lies inside the playfield*/ };
+// "%04i" % reward: Python formats a float with %i by truncating towards zero
+__device__ __forceinline__ int mcr_label_value(double reward) { return (reward > -2.0e9 && reward < 2.0e9) ? (int)reward : 0; }
 
 // Car.draw polygons per car in draw order: 4 x (wheel box, white stripe) then the 4 hull polygons; each slot holds
 // 8 vertices (x0 y0 .. x7 y7) and slot header words live in carpoly_n: vertex count (0 = not drawn)

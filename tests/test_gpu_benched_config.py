@@ -53,7 +53,10 @@ class _Follower:
 def _cmp_pixels(got, want, amb, what, budget=14):
     d = (got != want).any(-1)
     bad = int((d & (amb == 0)).sum())
-    assert bad == 0, f"{what}: {bad} unambiguous pixels differ"
+    if bad:
+        where = np.argwhere(d & (amb == 0))[:6]
+        detail = "; ".join(f"view {a} row {r} col {c}: got {got[a, r, c].tolist()} want {want[a, r, c].tolist()}" for a, r, c in where)
+        raise AssertionError(f"{what}: {bad} unambiguous pixels differ: {detail}")
     assert int(d.sum()) <= budget * got.shape[0], f"{what}: {int(d.sum())} edge pixels differ"
 
 

@@ -12,15 +12,17 @@ for k in range(80): env.step(pool[k % 64])
 _lib.check(env.L.mcr_debug_set(env.h, 32))
 for k in range(3): env.step(pool[k])
 torch.cuda.synchronize()
-names = ["prologue", "init-barrier", "pass1(cull+flags)", "cars", "barrier", "pass2(setup+bin)+flags2", "barrier", "shade", "barrier", "writeout"]
+names = ["prologue (agent 0: env-level loads) / hand-over", "wait: barrier", "clear + label + candidates (cull, set-up, scan)", "wait: barrier",
+         "next fetch + task fill", "wait: barrier", "span fill", "wait: barrier", "resolve + write-out"]
 rows = []
 for v in range(0, B * N, 97):
     buf = np.zeros(10, np.uint64)
     env.L.mcr_debug_read_view_scratch(env.h, v, _lib.ptr(buf), 80)
-    rows.append(np.diff(buf.astype(np.int64)))
+    if buf[:9].sum() > 0:
+        rows.append(np.concatenate([buf.astype(np.int64), [v % N]]))
 d = np.array(rows)
-print("views sampled", len(d), " (s_memtime ticks; 100 MHz constant clock -> 10 ns per tick)")
-for i, nme in enumerate(names[1:]):
-    print(f"{nme:>26}: median {np.median(d[:, i]):8.0f} ticks  mean {d[:, i].mean():8.0f}  p90 {np.percentile(d[:, i], 90):8.0f}")
-print(f"{'total':>26}: median {np.median(d.sum(1)):8.0f} ticks")
+print("views sampled", len(d), " rounds per view: mean %.2f" % d[:, 9].mean(), " (clock ticks of thread 0, summed over the view's rounds)")
+for i, nme in enumerate(names):
+    print(f"{nme:>52}: median {np.median(d[:, i]):8.0f} ticks  mean {d[:, i].mean():8.0f}  p90 {np.percentile(d[:, i], 90):8.0f}")
+print(f"{'total per view':>52}: median {np.median(d[:, :9].sum(1)):8.0f} ticks   (agent 0: {np.median(d[d[:, 10] == 0][:, :9].sum(1)):.0f}, later agents: {np.median(d[d[:, 10] > 0][:, :9].sum(1)):.0f})")
 env.close()
