@@ -114,6 +114,13 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
   if (p.role >= 2 && !only_just_reset && es.resetting) return;
   const uint8_t* __restrict__ slot = p.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES;
   const McrSlotHeader* H = (const McrSlotHeader*)slot;
+  const float4* __restrict__ QA = (const float4*)(slot + MCR_OFF_QA); const float4* __restrict__ QB = (const float4*)(slot + MCR_OFF_QB);
+  const uint32_t* __restrict__ QM = (const uint32_t*)(slot + MCR_OFF_QMETA);
+  // what a candidate needs from HBM, requested one round ahead; the first round (road quads tid < RC <= capacity) goes
+  // out before the slot header is back: entries beyond P are never looked at
+  struct Raw { float4 a, b, c, d; uint32_t m; };     // quad: a = v0 v1, b = v2 v3, m = meta | car polygon: a..d = 8 vertices, m = vertex count
+  Raw nxt; nxt.a = nxt.b = nxt.c = nxt.d = make_float4(0.0f, 0.0f, 0.0f, 0.0f); nxt.m = 0u;
+  if (tid < view::RC) { nxt.a = QA[tid]; nxt.b = QB[tid]; nxt.m = QM[tid]; }
   const int T = H->T, P = H->P;
   const int dbg = p.debug;
   unsigned long long pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = (dbg & 32) ? __builtin_readcyclecounter() : 0ull;
@@ -136,11 +143,7 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
   if (tid >= 64 && tid < 64 + MCR_VIEWP_FLOATS) vrec[0][tid - 64] = p.viewp[(size_t)(env * N) * MCR_VIEWP_FLOATS + (tid - 64)];
   // grass lattice as the reference builds it (:620-627): f32(k*x) and f32(k*x + k) for x = -20, -18, .., 18
   if (tid >= 224 && tid < 244) { const double k = MCR_PLAYFIELD / 20.0, x = 2.0 * (double)(tid - 224 - 10); glo[tid - 224] = (float)(k * x + 0); ghi[tid - 224] = (float)(k * x + k); }
-  const float4* __restrict__ QA = (const float4*)(slot + MCR_OFF_QA); const float4* __restrict__ QB = (const float4*)(slot + MCR_OFF_QB);
-  const uint32_t* __restrict__ QM = (const uint32_t*)(slot + MCR_OFF_QMETA);
   const float kx = 96.0f / 1000.0f, ky = 96.0f / 800.0f;
-  // what a candidate needs from HBM, requested one round ahead
-  struct Raw { float4 a, b, c, d; uint32_t m; };     // quad: a = v0 v1, b = v2 v3, m = meta | car polygon: a..d = 8 vertices, m = vertex count
   // `sb`: first candidate index of the view's specials (they sit at the END of the last round, see below)
   auto fetch_raw = [&](int c, int sb) -> Raw {
     Raw r; r.a = r.b = r.c = r.d = make_float4(0.0f, 0.0f, 0.0f, 0.0f); r.m = 0u;
@@ -157,8 +160,6 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
     }
     return r;
   };
-  Raw nxt; nxt.a = nxt.b = nxt.c = nxt.d = make_float4(0.0f, 0.0f, 0.0f, 0.0f); nxt.m = 0u;
-  if (tid < RC) nxt = fetch_raw(tid, 1 << 30);                              // round 0 of the first view starts with road quads (specials, if any, are fetched in place)
 
 #pragma nounroll
   for (int agent = 0; agent < N; ++agent) {
