@@ -214,7 +214,7 @@ def lib():
         L.orc_create.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         for name in ("orc_destroy", "orc_set_track", "orc_reset", "orc_step", "orc_render", "orc_get_state",
                      "orc_set_body", "orc_get_env", "orc_positions", "orc_contact_event", "orc_set_hull_pose",
-                     "orc_bookkeeping", "orc_wheel_tile_counts", "orc_reset_nostep", "orc_step_masked", "orc_reset_masked"):
+                     "orc_bookkeeping", "orc_wheel_tile_counts", "orc_reset_nostep", "orc_step_masked", "orc_reset_masked", "orc_solve_only"):
             getattr(L, name).restype = None
         L.orc_render_size.restype = None
         L.orc_render_size.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
@@ -257,6 +257,17 @@ def step_batch(envs, actions, render_mask=None, threads=None):
     L.orc_step_batch(hs, ctypes.c_int(n), _p(a), _p(rm) if rm is not None else None, _p(obs), _p(amb), _p(rew), _p(done),
                      ctypes.c_int(threads or os.cpu_count() or 1))
     return obs, amb, rew, done.astype(bool)
+
+
+def overlap_sweep(n, seed=1, band=1e-5, far=5e-5, threads=None):
+    """b2TestOverlap as Box2D computes it (GJK b2Distance, oracle restatement) vs the SAT + vertex-edge predicate the
+    oracle and the kernels use, on n random wheel/tile pairs at core separation 0.02 + U(-band, band).
+    Returns dict(samples, disagree, gjk_touching, sat_touching, max_gjk_iters, disagree_far) — `far`: |delta| > far."""
+    out = np.zeros(6, np.int64)
+    L = lib(); L.orc_overlap_sweep.restype = None
+    L.orc_overlap_sweep(ctypes.c_longlong(int(n)), ctypes.c_uint(int(seed)), ctypes.c_double(band), ctypes.c_double(far), _p(out),
+                        ctypes.c_int(threads or os.cpu_count() or 1))
+    return dict(samples=int(out[0]), disagree=int(out[1]), gjk_touching=int(out[2]), sat_touching=int(out[3]), max_gjk_iters=int(out[4]), disagree_far=int(out[5]))
 
 
 def sincos(a, mode=0):
@@ -390,6 +401,17 @@ class OracleEnv:
         out = np.zeros((self.N, 4), np.int32)
         self.L.orc_wheel_tile_counts(self.h, _p(out))
         return out
+
+    def draw_list(self, agent=0, width=96, height=96, cap=2048):
+        """Polygons of the frame render_view() would draw now, in draw order: list of (xy [n,2] f64 pixel space, rgb)."""
+        buf = np.zeros((cap, 20))
+        self.L.orc_draw_list.restype = ctypes.c_int
+        n = self.L.orc_draw_list(self.h, ctypes.c_int(agent), ctypes.c_int(width), ctypes.c_int(height), _p(buf), ctypes.c_int(cap))
+        return [(buf[i, 4:4 + 2 * int(buf[i, 0])].reshape(-1, 2).copy(), buf[i, 1:4].astype(np.uint8)) for i in range(n)]
+
+    def solve_only(self, steps=1):
+        self.L.orc_set_trig_mode(self.trig_mode)
+        self.L.orc_solve_only(self.h, ctypes.c_int(steps))
 
     def num_car_contacts(self):
         return self.L.orc_num_car_contacts(self.h)

@@ -1,0 +1,197 @@
+"""CPU: what can be pinned about the oracle's third-party restatements without Box2D / gym / pyglet.
+
+* b2TestOverlap: Box2D's actual algorithm (GJK b2Distance, restated in the oracle) against the SAT + vertex-edge predicate
+  the oracle and the kernels use, >= 1e7 random wheel/tile poses at the 0.02 threshold -> measured disagreement rates;
+* closed-form solver KATs: momentum conservation of the joint/contact solver, a revolute joint driven into its limit,
+  a point-symmetric head-on collision;
+* the raster: an independent scanline rasteriser (f64 edge intersections, no half-plane tests) re-draws the oracle's
+  polygon list; the two may differ only inside the oracle's ambiguity mask."""
+import numpy as np
+import pytest
+
+from tests.util import oracle_episode
+
+
+# ----------------------------------------------------------------------------- b2TestOverlap: GJK vs SAT
+def test_gjk_vs_sat_overlap_at_the_threshold(oracle):
+    """1e7 poses with the exact (f64) core separation drawn from 0.02 +- 1e-5, i.e. inside the f32 noise of 250-unit world
+    coordinates (1 ulp = 1.5e-5).  Measured on this build: the two predicates decide differently in 19.4 % of those poses
+    (28 % inside +-1e-6); the disagreement decays to nothing by |delta| = 5e-5 (0 of 4e6 at band 1e-3), which makes the
+    effective half-width of the zone in which they can differ 2.4e-6 units.  A wheel approaching a tile closes >= 0.1
+    units per step, so about 5e-5 of the contact begin/end events fall into that zone — there the event moves by ONE step
+    (never lost: the next step is far past the threshold).  GJK itself never needed more than 5 of its 20 iterations."""
+    r = oracle.overlap_sweep(10_000_000, seed=1, band=1e-5, far=5e-5)
+    assert r["samples"] == 10_000_000
+    rate = r["disagree"] / r["samples"]
+    assert 0.10 < rate < 0.30, r
+    assert r["max_gjk_iters"] <= 20 and r["disagree_far"] == 0
+    assert abs(r["gjk_touching"] - r["sat_touching"]) < 0.02 * r["samples"]      # neither is biased towards touching
+    wide = oracle.overlap_sweep(4_000_000, seed=2, band=1e-3, far=5e-5)
+    assert wide["disagree_far"] == 0, wide                                        # agree whenever |separation - 0.02| > 5e-5
+    half_width = wide["disagree"] / wide["samples"] * 1e-3
+    assert half_width < 5e-6, half_width
+
+
+# ----------------------------------------------------------------------------- solver KATs
+def _env(oracle, N=2, seed=3, contacts=True):
+    o = oracle.OracleEnv(N, car_contacts=contacts)
+    o.reset(oracle_episode(oracle, N, seed, 0), render=False)
+    return o
+
+
+def _momentum(oracle, st):
+    m = oracle.mass_props()
+    mass = np.array([1 / m[0]] + [1 / m[4]] * 4); inertia = np.array([1 / m[1]] + [1 / m[5]] * 4)
+    b = st["bodies"].astype(np.float64)                                  # [N,5,6] c.x c.y a v.x v.y w
+    p = (mass[None, :, None] * b[:, :, 3:5]).sum((0, 1))
+    L = (mass[None, :] * (b[:, :, 0] * b[:, :, 4] - b[:, :, 1] * b[:, :, 3]) + inertia[None, :] * b[:, :, 5]).sum()
+    return p, L
+
+
+def test_joint_solver_conserves_momentum(oracle):
+    """Closed system (b2World::Step without Car.step: revolute joints only act between hull and wheels): linear and
+    angular momentum of every car are invariants of the exact solver; in f32 they drift by rounding only."""
+    o = _env(oracle, N=1, contacts=False)
+    st = o.state()["bodies"].copy()
+    st[0, :, 3] = 7.5; st[0, :, 4] = -3.25                                # common translation ...
+    st[0, 0, 5] = 1.7                                                     # ... hull spinning, wheels not: the joints have to work
+    st[0, 1:, 3] += np.array([0.4, -0.3, 0.2, -0.1])                      # and the wheels drifting apart a little
+    for k in range(5):
+        o.set_body(0, k, st[0, k])
+    p0, L0 = _momentum(oracle, o.state())
+    for _ in range(100):
+        o.solve_only(1)
+    p1, L1 = _momentum(oracle, o.state())
+    assert np.abs(p1 - p0).max() < 2e-4 * np.abs(p0).max(), (p0, p1)
+    assert abs(L1 - L0) < 2e-4 * abs(L0), (L0, L1)
+    b = o.state()["bodies"][0].astype(np.float64)
+    # the joints made one rigid assembly of it: every wheel centre moves with the hull's velocity field v + w x r
+    r = b[1:, :2] - b[0, :2]
+    v_rigid = b[0, 3:5][None, :] + b[0, 5] * np.stack([-r[:, 1], r[:, 0]], 1)
+    assert np.abs(b[1:, 3:5] - v_rigid).max() < 0.2, np.abs(b[1:, 3:5] - v_rigid).max()   # initial spread 0.7; residual of the soft position correction
+    o.close()
+
+
+def test_revolute_joint_limit(oracle):
+    """Full steering lock: the front-wheel joints run into their +-0.4 rad limits (b2RevoluteJoint limit branch, Solve33):
+    limitState at-lower / at-upper, the joint angle stays within the limit + angular slop, and the accumulated limit
+    impulse has the sign Box2D clamps it to (>= 0 at the lower limit, <= 0 at the upper)."""
+    slop = 2.0 / 180.0 * np.pi
+    for steer, want in ((1.0, None), (-1.0, None)):
+        o = _env(oracle, N=1, contacts=False)
+        a = np.array([[steer, 0.0, 0.0]], np.float32)
+        seen = set()
+        for k in range(80):
+            o.step(a, render=False)
+            st = o.state()
+            ang = st["bodies"][0, 1:3, 2] - st["bodies"][0, 0, 2]          # front wheels' joint angles
+            assert np.all(np.abs(ang) <= 0.4 + slop + 1e-4), (k, ang)
+            for w in range(2):
+                ls = int(st["limit"][0, w]); seen.add(ls)
+                if ls == 1: assert st["joints"][0, w, 2] >= 0.0
+                if ls == 2: assert st["joints"][0, w, 2] <= 0.0
+        assert (1 in seen) or (2 in seen), "steering lock never reached a joint limit"
+        ang = o.state()["bodies"][0, 1:3, 2] - o.state()["bodies"][0, 0, 2]
+        assert np.all(np.abs(np.abs(ang) - 0.4) < slop + 1e-3), ang         # parked at the limit
+        assert np.sign(ang[0]) == -np.sign(steer)                          # Car.steer(-action[0]) (:422): positive action turns the wheels clockwise
+        o.close()
+
+
+def test_point_symmetric_head_on_collision(oracle):
+    """Two cars that are each other's image under a rotation by pi about a point, driving at each other on grass with no
+    input: the set-up, the tyre model and the exact contact solver are symmetric, so the cars stay mirror images through
+    the collision (b2CollidePolygons + block solver with equal impulses) up to f32 rounding, and the total momentum,
+    zero by symmetry, stays zero."""
+    o = _env(oracle, N=2, contacts=True)
+    st = o.state()["bodies"].copy()
+    mid = np.array([250.0, 250.0], np.float32)                            # inside the playfield, away from any track tile
+    a0 = np.float32(0.3)
+    fwd = np.array([-np.sin(a0), np.cos(a0)], np.float32)
+    base = st[0, 0, :2].copy()
+    for k in range(5):                                                    # car 0: 4.5 units before the midpoint (noses 3.8 apart), driving at it
+        rel = st[0, k, :2] - base
+        ca, sa = np.cos(a0 - st[0, 0, 2]), np.sin(a0 - st[0, 0, 2])
+        rel = np.array([ca * rel[0] - sa * rel[1], sa * rel[0] + ca * rel[1]], np.float32)
+        st[0, k, :2] = mid - 4.5 * fwd + rel
+        st[0, k, 2] = st[0, k, 2] + (a0 - o.state()["bodies"][0, 0, 2]) if k else a0
+        st[0, k, 3:5] = 15.0 * fwd; st[0, k, 5] = 0.0
+    for k in range(1, 5):
+        st[0, k, 2] = a0
+    for k in range(5):                                                    # car 1: the image of car 0 under rotation by pi about mid
+        st[1, k, :2] = 2 * mid - st[0, k, :2]
+        st[1, k, 2] = st[0, k, 2] + np.float32(np.pi)
+        st[1, k, 3:5] = -st[0, k, 3:5]; st[1, k, 5] = st[0, k, 5]
+    for c in range(2):
+        for k in range(5):
+            o.set_body(c, k, st[c, k])
+    act = np.zeros((2, 3), np.float32)
+    touched = 0
+    for k in range(45):
+        o.step(act, render=False)
+        touched += o.num_car_contacts()
+        b = o.state()["bodies"].astype(np.float64)
+        tol = 2e-3 if touched == 0 else 5e-2                              # rounding is amplified by the stiff contact
+        assert np.abs(b[1, :, :2] - (2 * mid - b[0, :, :2])).max() < tol, (k, touched)
+        assert np.abs(b[1, :, 3:5] + b[0, :, 3:5]).max() < 10 * tol, (k, touched)
+        p, _ = _momentum(oracle, o.state())
+        assert np.abs(p).max() < 0.05, (k, p)                             # of ~86 per car before the impact
+    assert touched > 0, "the cars never touched"
+    v0 = o.state()["bodies"][0, 0, 3:5]
+    assert float(np.dot(v0, fwd)) < 3.0                                   # and the collision took the approach speed away
+    o.close()
+
+
+# ----------------------------------------------------------------------------- raster: independent scanline evaluation
+def _scanline(polys, W, H):
+    """Painter's algorithm by scanline intersection: for every pixel row, the x-interval in which the row's centre line
+    cuts the (convex) polygon; pixels whose centres lie inside the interval are painted.  No half-plane evaluation."""
+    img = np.zeros((H, W, 3), np.uint8)
+    for xy, rgb in polys:
+        n = len(xy)
+        if n < 3:
+            continue
+        ys = xy[:, 1]
+        y0 = max(int(np.floor(ys.min() - 0.5)), 0); y1 = min(int(np.ceil(ys.max() - 0.5)), H - 1)
+        for y in range(y0, y1 + 1):
+            cy = y + 0.5
+            xs = []
+            for i in range(n):
+                (xa, ya), (xb, yb) = xy[i], xy[(i + 1) % n]
+                if ya == yb:
+                    continue
+                if (ya <= cy < yb) or (yb <= cy < ya):
+                    xs.append(xa + (cy - ya) * (xb - xa) / (yb - ya))
+            if len(xs) < 2:
+                continue
+            xl, xr = min(xs), max(xs)
+            i0 = max(int(np.ceil(xl - 0.5)), 0); i1 = min(int(np.floor(xr - 0.5)), W - 1)
+            if i0 <= i1:
+                img[H - 1 - y, i0:i1 + 1] = rgb                         # rows top-down like the observation (arr[::-1], :602)
+    return img
+
+
+@pytest.mark.parametrize("N,seed", [(2, 11), (3, 5)])
+def test_oracle_raster_vs_independent_scanline(oracle, N, seed):
+    """The oracle's raster decides coverage by signed distances to every edge; the scanline rasteriser above decides it
+    by where each pixel row cuts the polygon.  Same polygon list, same sampling rule -> the two frames may differ only
+    where the oracle itself says a pixel centre is within 0.02 px of an edge (its ambiguity mask).  The score label
+    (a bitmap, not a polygon) is outside this comparison."""
+    o = _env(oracle, N=N, seed=seed)
+    rng = np.random.RandomState(seed)
+    label = np.zeros((96, 96), bool); label[86:94, 0:18] = True
+    checked = 0
+    for k in range(75):
+        a = np.stack([rng.uniform(-1, 1, N), rng.uniform(0, 1, N), rng.uniform(0, 0.2, N)], 1).astype(np.float32)
+        if k > 50:
+            a[:, 0] = 1.0                                                 # spin: backwards flag comes up
+        o.step(a, render=False)
+        if k in (0, 3, 12, 30, 49, 74):                                   # zoomed out ... zoomed in, flag
+            obs, amb = o.render_with_mask()
+            for ag in range(N):
+                img = _scanline(o.draw_list(ag), 96, 96)
+                d = (img != obs[ag]).any(-1) & ~label
+                assert (d & (amb[ag] == 0)).sum() == 0, f"step {k} agent {ag}: {(d & (amb[ag] == 0)).sum()} unambiguous pixels differ"
+                assert d.sum() <= 40
+                checked += 1
+    assert checked == 6 * N
+    o.close()
