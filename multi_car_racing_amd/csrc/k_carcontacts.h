@@ -38,18 +38,20 @@ __device__ inline float find_max_separation(int* edge, const LPoly& p1, const Xf
   *edge = best; return maxSep;
 }
 struct ClipV { V2 v; uint32_t id; };
+// b2ClipSegmentToLine without run-time indexing of out[] (which would put the clip vertices in scratch memory): the kept
+// input vertices first (in order), then the intersection point — exactly the sequence the original appends
 __device__ __forceinline__ int clip_segment(ClipV out[2], const ClipV in[2], V2 normal, float offset, int vertexIndexA) {
-  int n = 0;
   const float d0 = dot(normal, in[0].v) - offset, d1 = dot(normal, in[1].v) - offset;
-  if (d0 <= 0.0f) out[n++] = in[0];
-  if (d1 <= 0.0f) out[n++] = in[1];
-  if (d0 * d1 < 0.0f) {
+  const bool k0 = d0 <= 0.0f, k1 = d1 <= 0.0f, cut = d0 * d1 < 0.0f;
+  ClipV I; I.v = in[0].v; I.id = in[0].id;
+  if (cut) {
     const float interp = d0 / (d0 - d1);
-    out[n].v = in[0].v + interp * (in[1].v - in[0].v);
-    out[n].id = mkid(vertexIndexA, (in[0].id >> 8) & 255, 0, 1);
-    ++n;
+    I.v = in[0].v + interp * (in[1].v - in[0].v);
+    I.id = mkid(vertexIndexA, (in[0].id >> 8) & 255, 0, 1);
   }
-  return n;
+  out[0] = k0 ? in[0] : (k1 ? in[1] : I);
+  out[1] = (k0 && k1) ? in[1] : I;
+  return (k0 ? 1 : 0) + (k1 ? 1 : 0) + (cut ? 1 : 0);
 }
 struct Manifold { int type, n; V2 localNormal, localPoint; V2 pl[2]; uint32_t id[2]; };
 
@@ -91,6 +93,7 @@ __device__ inline void collide_polygons(Manifold& M, const LPoly& pA, const Xf& 
   if (clip_segment(c2, c1, tangent, sideOffset2, iv2) < 2) return;
   M.localNormal = localNormal; M.localPoint = planePoint;
   int pc = 0;
+#pragma unroll
   for (int i = 0; i < 2; ++i) {
     const float separation = dot(normal, c2[i].v) - frontOffset;
     if (separation <= totalRadius) {

@@ -296,14 +296,20 @@ __global__ __launch_bounds__(64) void k_collide(McrParams p, int pass) {
             const uint32_t* o = store + 4 + j * MCR_CC_WORDS;
             if (o[0] != key) continue;
             const int on = (int)(o[1] >> 8);
-            for (int i = 0; i < M.n; ++i)
-              for (int jj = 0; jj < on; ++jj)
-                if (o[6 + jj * 5 + 4] == M.id[i]) { ni[i] = __uint_as_float(o[6 + jj * 5 + 2]); ti[i] = __uint_as_float(o[6 + jj * 5 + 3]); break; }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {                    // fixed trip counts: ni/ti/M.id stay in registers
+              if (i >= M.n) continue;
+              bool found = false;
+#pragma unroll
+              for (int jj = 0; jj < 2; ++jj)
+                if (!found && jj < on && o[6 + jj * 5 + 4] == M.id[i]) { ni[i] = __uint_as_float(o[6 + jj * 5 + 2]); ti[i] = __uint_as_float(o[6 + jj * 5 + 3]); found = true; }
+            }
           }
           uint32_t* d = newrec[slot];
           d[0] = key; d[1] = (uint32_t)M.type | ((uint32_t)M.n << 8);
           d[2] = __float_as_uint(M.localNormal.x); d[3] = __float_as_uint(M.localNormal.y);
           d[4] = __float_as_uint(M.localPoint.x); d[5] = __float_as_uint(M.localPoint.y);
+#pragma unroll
           for (int i = 0; i < 2; ++i) {
             d[6 + i * 5 + 0] = __float_as_uint(M.pl[i].x); d[6 + i * 5 + 1] = __float_as_uint(M.pl[i].y);
             d[6 + i * 5 + 2] = __float_as_uint(ni[i]); d[6 + i * 5 + 3] = __float_as_uint(ti[i]); d[6 + i * 5 + 4] = M.id[i];

@@ -210,29 +210,36 @@ __device__ inline void cc_init(const CcMass& S, const uint32_t* rec, int rec_ind
   xfA.p = cA - rmul(xfA.q, lcA); xfB.p = cB - rmul(xfB.q, lcB);
   const V2 localNormal = v2(__uint_as_float(rec[2]), __uint_as_float(rec[3])), localPoint = v2(__uint_as_float(rec[4]), __uint_as_float(rec[5]));
   // b2WorldManifold::Initialize
-  V2 normal, pts[2];
+  V2 normal, pts[2]; pts[0] = pts[1] = v2(0.0f, 0.0f);
   const float rA_ = B2_POLYGON_RADIUS, rB_ = B2_POLYGON_RADIUS;
   if (type == 1) {
     normal = rmul(xfA.q, localNormal);
     const V2 planePoint = xmul(xfA, localPoint);
-    for (int j = 0; j < n; ++j) {
-      const V2 clip = xmul(xfB, v2(__uint_as_float(rec[6 + j * 5]), __uint_as_float(rec[6 + j * 5 + 1])));
-      const V2 pa = clip + (rA_ - dot(clip - planePoint, normal)) * normal;
-      const V2 pb = clip - rB_ * normal;
-      pts[j] = 0.5f * (pa + pb);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {                 // fixed trip count + guard: pts[] stays in registers (a `j < n` loop put it in scratch)
+      if (j < n) {
+        const V2 clip = xmul(xfB, v2(__uint_as_float(rec[6 + j * 5]), __uint_as_float(rec[6 + j * 5 + 1])));
+        const V2 pa = clip + (rA_ - dot(clip - planePoint, normal)) * normal;
+        const V2 pb = clip - rB_ * normal;
+        pts[j] = 0.5f * (pa + pb);
+      }
     }
   } else {
     normal = rmul(xfB.q, localNormal);
     const V2 planePoint = xmul(xfB, localPoint);
-    for (int j = 0; j < n; ++j) {
-      const V2 clip = xmul(xfA, v2(__uint_as_float(rec[6 + j * 5]), __uint_as_float(rec[6 + j * 5 + 1])));
-      const V2 pb = clip + (rB_ - dot(clip - planePoint, normal)) * normal;
-      const V2 pa = clip - rA_ * normal;
-      pts[j] = 0.5f * (pa + pb);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (j < n) {
+        const V2 clip = xmul(xfA, v2(__uint_as_float(rec[6 + j * 5]), __uint_as_float(rec[6 + j * 5 + 1])));
+        const V2 pb = clip + (rB_ - dot(clip - planePoint, normal)) * normal;
+        const V2 pa = clip - rA_ * normal;
+        pts[j] = 0.5f * (pa + pb);
+      }
     }
     normal = -normal;
   }
   const V2 tangent = cross(normal, 1.0f);
+#pragma unroll
   for (int j = 0; j < 2; ++j) {
     float* q = vc + (j == 0 ? cc::VC_P0 : cc::VC_P1);
     if (j < n) {

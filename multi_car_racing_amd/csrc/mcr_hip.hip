@@ -242,7 +242,6 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     P.role = 2;
     LAUNCH(5, k_dynamics, side_blocks, 64, h->s_side, P, 0);
     if (draw) launch_view(h, 6, B, h->s_side, P, 0);
-    (void)hipEventRecord(h->ev_join, h->s_side);
     P.role = 1;
   }
   LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 0);
@@ -253,6 +252,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     LAUNCH(7, k_dynamics, side_blocks, 64, h->s_defer, P, 0);
     if (draw) launch_view(h, 7, B, h->s_defer, P, 0);
     (void)hipEventRecord(h->ev_join2, h->s_defer);
+    (void)hipEventRecord(h->ev_join, h->s_side);
     P.role = 1;
   }
   if (P.auto_reset) {   // envs re-spawned by pass 0 take the action-less first step of their new episode (:408)
@@ -272,7 +272,9 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
       if (draw) launch_view(h, 7, B, st, P, 1);
     }
   }
-  // backward / on-grass bookkeeping (:446-495) on the poses this step produced, one wavefront per car (k_flags.h)
+  // backward / on-grass bookkeeping (:446-495; k_flags.h, one wavefront per car) on the poses this step produced.  It closes
+  // the step on the caller's stream: running it beside the main raster launch (tried: side stream, behind every dynamics
+  // launch) slows that launch down by more than it saves
   if (view_flags) {
     P.role = 0;
     hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, st, P);
