@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event time all three kernels (adds overhead)")
     ap.add_argument("--action-seed", type=int, default=1234)
+    ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket the raster launch with HIP events (no roofline object; lets --graph 1 replay)")
+    ap.add_argument("--graph", type=int, default=0, help="1: mcr_step replays a hipGraph of the step (bypassed while kernels are timed; measured gain 0.4 %); 0 (default): plain launches")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -134,7 +136,7 @@ def main():
 
     B, N, K, W = args.envs, args.agents, args.steps, args.warmup
     env = ShardedVecEnv(B * world, N, seed=0, rank=rank, world_size=world, device=dev, obs=bool(args.obs),
-                        auto_reset=True, use_random_direction=True, streams=args.streams)
+                        auto_reset=True, use_random_direction=True, streams=args.streams, graph=bool(args.graph))
     env.reset()
     # synthetic actions, generated ON THE DEVICE every step by a counter-based stream keyed (seed, global env, agent, t)
     # (SURVEY 8d): i.i.d. steer~U(-1,1), gas~U(0,1), brake~U(0,1); one 3 us kernel inside the timed region
@@ -165,7 +167,7 @@ def main():
     if args.debug_bits:
         from multi_car_racing_amd import _lib as _L
         _L.check(env.env.L.mcr_debug_set(env.env.h, args.debug_bits))
-    env.timing(255 if args.time_all_kernels else 4)
+    env.timing(0 if args.no_kernel_timing else (255 if args.time_all_kernels else 4))
     gen0 = env.env.episodes_generated
     env.env.rollout_stats(reset=True)
     ctr0 = env.env.debug_counters()

@@ -110,6 +110,11 @@ int mcr_set_episode_stats(mcr_env* h, double* d_ep_return, int32_t* d_ep_len);
  * out2[0] = episodes finished, out2[1] = sum of their returns over all agents.  These are the per-rank inputs of the
  * job-wide metric all-reduce. */
 int mcr_read_rollout_stats(mcr_env* h, double* out2, int reset);
+/* Replay mcr_step as a hipGraph (1) or as plain launches (0, default).  A step is a fixed sequence of launches whose
+ * arguments change only with an internal parity; the graph is (re)captured whenever an argument of mcr_step differs from
+ * the captured call (buffers, stream) and bypassed while kernel timing is enabled.  Results are identical; the measured
+ * gain at B=4096 is 0.4 % (the gaps between dependent kernels are not host launch cost), so it is off by default. */
+int mcr_set_step_graph(mcr_env* h, int enable);
 /* Envs whose staged episode was consumed (installed by a reset or an auto-reset) since the last poll: the host must
  * stage a fresh one for each.  Reads per-env install counters the kernels write to mapped host memory — no device
  * synchronisation, `stream` is unused; an install whose kernel has not finished yet shows up in a later poll.

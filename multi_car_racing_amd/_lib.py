@@ -56,6 +56,7 @@ SYMBOLS = {
     "mcr_debug_read_counters": (_i, [_vp, _vp]),
     "mcr_debug_read_dynamics_stamps": (_i, [_vp, _vp, _i]),
     "mcr_timing_read": (_i, [_vp, _vp, _vp]),
+    "mcr_set_step_graph": (_i, [_vp, _i]),
     "mcr_state_blob_bytes": (ctypes.c_size_t, [_vp]),
     "mcr_get_state_blob": (_i, [_vp, _i, _vp]),
     "mcr_set_state_blob": (_i, [_vp, _i, _vp]),

@@ -49,6 +49,10 @@ struct mcr_env {
   hipStream_t s_side, s_defer; // internal streams: the contact envs' chain, the deferred envs' chain
   hipEvent_t ev_fork, ev_join, ev_fork2, ev_join2;
   unsigned long long* view_stamps;   // [BN][16] phase clocks of the rasteriser (debug bit 5)
+  // hipGraph of one step (mcr_set_step_graph): one per contact-list parity, re-captured when any argument changes
+  struct StepGraph { bool valid; McrParams P; hipStream_t st; int view_flags; hipGraph_t graph; hipGraphExec_t exec; };
+  StepGraph sg[2];
+  int use_graph;              // 0 off, 1 on, -1 capture failed once: stay off
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -58,7 +62,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   if (cfg->num_envs < 1 || cfg->num_agents < 1 || cfg->num_agents > MCR_MAX_AGENTS) { g_err = "num_envs/num_agents out of range"; return MCR_ERR_ARG; }
   HIPCHK(hipSetDevice(cfg->device));
   mcr_env* h = new mcr_env();
-  h->cfg = *cfg; h->timing = 0; h->any_reset = false;
+  h->cfg = *cfg; h->timing = 0; h->any_reset = false; h->use_graph = 0; h->sg[0].valid = h->sg[1].valid = false;
   for (int i = 0; i < MCR_TIMING_SLOTS; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
   const int B = cfg->num_envs, N = cfg->num_agents;
   int G = 1; while (G < N) G <<= 1;
@@ -141,6 +145,7 @@ extern "C" int mcr_destroy(mcr_env* h) {
   if (!h) return MCR_ERR_ARG;
   (void)hipSetDevice(h->cfg.device);
   (void)hipDeviceSynchronize();
+  for (auto& g : h->sg) if (g.valid) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); g.valid = false; }
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : h->free_events) (void)hipEventDestroy(e);
   if (h->split) {
@@ -214,14 +219,14 @@ static void launch_reset(mcr_env* h, McrParams P, hipStream_t st) {
 // step(): collide -> dynamics [-> auto-reset pass] -> view on the caller's stream `st`.
 // With num_streams == 2 the step forks into three chains that meet again at the end (grids are sized for the worst
 // case, surplus workgroups exit on their first load):
-//   st      : collide(all) -+-> dynamics(main envs, 2 position sweeps) -+-> reset pass -> view(main envs) -+-> late reset pass
-//   s_side  :               +-> dynamics(contact envs) -> view(contact envs) ------------------------------+
-//   s_defer :                                                          +-> dynamics(resume deferred envs) -> view(them) --+
+//   st      : collide(all) -+-> dynamics(main envs, 2 position sweeps) -+-> reset pass -> view(main envs) -+-> flags
+//   s_side  :               +-> dynamics(contact envs) -> their reset pass -> view(contact envs) ---------+
+//   s_defer :                                                          +-> dynamics(resume deferred envs) -> their reset pass -> view(them) --+
 // Contact envs: a wavefront holding a touching car<->car pair takes 2-4x as long as the others.  Deferred envs: the
 // few whose position loop is still iterating after 2 sweeps (a slow marginal crawl that would hold the whole main
 // launch for up to 60).  s_defer's dynamics starts while the GPU is nearly idle (the reset pass), so it finds free
-// SIMDs at once.  An env of either list that ended its episode in this step (rare) gets its reset pass + first frame
-// in the "late" pass on `st`: three launches that exit at once in every other step.
+// SIMDs at once.  An env of either list that ended its episode in this step (rare) takes its reset pass inside its own
+// chain (two launches that exit at once in every other step; round 1 ran them as a "late" pass on the caller's stream).
 static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags) {
   const int B = P.B, N = P.N;
   const int dyn_blocks = (B * P.G + 63) / 64;
@@ -241,6 +246,10 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     (void)hipStreamWaitEvent(h->s_side, h->ev_fork, 0);
     P.role = 2;
     LAUNCH(5, k_dynamics, side_blocks, 64, h->s_side, P, 0);
+    if (P.auto_reset) {   // a contact env that ended its episode takes its reset pass (:408) right here, in its own chain
+      LAUNCH_LDS(7, k_collide, B, 64, col::lds_bytes(N), h->s_side, P, 1);
+      LAUNCH(7, k_dynamics, side_blocks, 64, h->s_side, P, 1);
+    }
     if (draw) launch_view(h, 6, B, h->s_side, P, 0);
     P.role = 1;
   }
@@ -250,6 +259,10 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     (void)hipStreamWaitEvent(h->s_defer, h->ev_fork2, 0);
     P.role = 3;
     LAUNCH(7, k_dynamics, side_blocks, 64, h->s_defer, P, 0);
+    if (P.auto_reset) {
+      LAUNCH_LDS(7, k_collide, B, 64, col::lds_bytes(N), h->s_defer, P, 1);
+      LAUNCH(7, k_dynamics, side_blocks, 64, h->s_defer, P, 1);
+    }
     if (draw) launch_view(h, 7, B, h->s_defer, P, 0);
     (void)hipEventRecord(h->ev_join2, h->s_defer);
     (void)hipEventRecord(h->ev_join, h->s_side);
@@ -265,12 +278,6 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   if (h->split) {
     (void)hipStreamWaitEvent(st, h->ev_join, 0);
     (void)hipStreamWaitEvent(st, h->ev_join2, 0);
-    if (P.auto_reset) {
-      P.role = 4;
-      LAUNCH_LDS(7, k_collide, B, 64, col::lds_bytes(N), st, P, 1);
-      LAUNCH(7, k_dynamics, side_blocks, 64, st, P, 1);
-      if (draw) launch_view(h, 7, B, st, P, 1);
-    }
   }
   // backward / on-grass bookkeeping (:446-495; k_flags.h, one wavefront per car) on the poses this step produced.  It closes
   // the step on the caller's stream: running it beside the main raster launch (tried: side stream, behind every dynamics
@@ -301,8 +308,43 @@ extern "C" int mcr_step(mcr_env* h, const float* d_actions, uint8_t* d_obs, doub
   P.reward_out = d_reward; P.done_out = d_done; P.trunc_out = d_trunc;
   // with auto_reset, finished envs are re-spawned on the device and take the action-less first step of their
   // new episode inside this call; the view kernel always runs (it also owns the backward/on-grass flags)
-  launch_step(h, P, st, d_actions ? 1 : 0);
+  const int vf = d_actions ? 1 : 0;
+  if (h->use_graph > 0 && !h->timing) {
+    // The step is a fixed sequence of ~13 launches on up to three streams whose arguments only change with the
+    // contact-list parity: it can be replayed as a hipGraph (measured r02: 0.4 % faster — the gaps between the step's
+    // dependent kernels are GPU-side drain/start-up, not host launch cost — so VecMultiCarRacing leaves it off).  Any change of an argument
+    // (other buffers, another stream, debug switches) re-captures.
+    const int par = h->split ? h->step_parity : 0;
+    mcr_env::StepGraph& G = h->sg[par];
+    if (G.valid && G.st == st && G.view_flags == vf && memcmp(&G.P, &P, sizeof(P)) == 0) {
+      if (h->split) h->step_parity ^= 1;               // what launch_step does on the host side
+      HIPCHK(hipGraphLaunch(G.exec, st));
+      return MCR_OK;
+    }
+    if (G.valid) { (void)hipGraphExecDestroy(G.exec); (void)hipGraphDestroy(G.graph); G.valid = false; }
+    const int parity_before = h->step_parity;
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+      launch_step(h, P, st, vf);
+      hipGraph_t graph = nullptr;
+      if (hipStreamEndCapture(st, &graph) == hipSuccess && graph && hipGraphInstantiate(&G.exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+        G.graph = graph; G.P = P; G.st = st; G.view_flags = vf; G.valid = true;
+        HIPCHK(hipGraphLaunch(G.exec, st));
+        return MCR_OK;
+      }
+      if (graph) (void)hipGraphDestroy(graph);
+    }
+    (void)hipGetLastError();
+    h->use_graph = -1;                                 // capture is not available here: plain launches from now on
+    h->step_parity = parity_before;
+  }
+  launch_step(h, P, st, vf);
   HIPCHK(hipGetLastError());
+  return MCR_OK;
+}
+
+extern "C" int mcr_set_step_graph(mcr_env* h, int enable) {
+  if (!h) { g_err = "null handle"; return MCR_ERR_ARG; }
+  h->use_graph = enable ? 1 : 0;
   return MCR_OK;
 }
 

@@ -531,3 +531,24 @@ def test_state_blob_round_trip_mid_episode(torch_cuda, oracle):
         for e in range(B):
             assert np.array_equal(s1[key][e], s2[key][perm[e] + 1]), key
     src.close(); dst.close()
+
+
+def test_step_graph_replay_is_bit_identical(torch_cuda):
+    """mcr_set_step_graph: replaying the step as a hipGraph (two graphs, one per contact-list parity, side streams
+    included) gives the same rewards, dones, observations and state as plain launches, across auto-resets."""
+    torch = torch_cuda
+    B, N, seed = 256, 2, 13
+    a1 = _make(B, N, seed, contacts=True, auto_reset=True, max_episode_steps=60, use_random_direction=True, streams=2, graph=False)
+    a2 = _make(B, N, seed, contacts=True, auto_reset=True, max_episode_steps=60, use_random_direction=True, streams=2, graph=True)
+    assert torch.equal(a1.reset(), a2.reset())
+    for k in range(150):
+        a = a1.synth_actions(k, seed=3)
+        a[:, 1, 1] = 1.0
+        o1, r1, d1, _ = a1.step(a); o2, r2, d2, _ = a2.step(a)
+        assert torch.equal(r1, r2) and torch.equal(d1, d2), k
+        if k % 10 == 9 or bool(d1.any()):
+            assert torch.equal(o1, o2), k
+    s1, s2 = a1.get_state(), a2.get_state()
+    for key in s1:
+        assert np.array_equal(s1[key], s2[key]), key
+    a1.close(); a2.close()
