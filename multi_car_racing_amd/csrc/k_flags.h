@@ -3,7 +3,8 @@
 // :78); they reach pixels one step later (the HUD flag is drawn from LAST step's value, which k_dynamics hands to the
 // raster in the view record) and the host through mcr_get_env_state.  Round 1 computed them inside the raster kernel;
 // they are a per-car O(T + P) scan with f64 tails (atan2, fmod) that cost the raster registers, barriers and a serial
-// lane — as a kernel of its own the scan is 8,192 independent wavefronts that overlap with the raster's tail.
+// lane — as a kernel of its own the scan is 8,192 independent wavefronts, launched per chain as soon as that chain's
+// dynamics is done (the main envs' launch runs beside the reset pass, before the raster needs the machine).
 //   nearest track point (:465-467, np.linalg.norm + argmin = first minimum): f32 distances of all tiles, wave minimum,
 //     exact f64 distance for the tiles within the rounding band of that minimum, lowest index among exact ties;
 //   on grass (:470-472, shapely Point.within = strict interior): f32 bbox prefilter, exact f64 test on the polygon the
@@ -15,9 +16,10 @@
 __global__ __launch_bounds__(64) void k_flags(McrParams p) {
   const int lane = threadIdx.x;
   const int N = p.N, BN = p.BN;
-  const int ci = p.env0 * N + (int)blockIdx.x;
-  if (ci >= (p.env0 + p.nenv) * N) return;
-  const int env = ci / N;
+  // roles as in the other step kernels: 0 every env, 1 the main launch's envs, 2 / 3 the contact / deferred lists
+  const int env = mcr_env_of_slot(p, (int)blockIdx.x / N);
+  if (env >= p.env0 + p.nenv) return;
+  const int ci = env * N + (int)blockIdx.x % N;
   const McrEnvState es = p.env[env];
   if (!es.active || es.just_reset) return;                   // reset() -> step(None) skips the block (:435); a re-spawned car keeps its zeroed flags
   const uint8_t* __restrict__ slot = p.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES;

@@ -251,6 +251,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
       LAUNCH(7, k_dynamics, side_blocks, 64, h->s_side, P, 1);
     }
     if (draw) launch_view(h, 6, B, h->s_side, P, 0);
+    if (view_flags) hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, h->s_side, P);      // bookkeeping of the contact envs
     P.role = 1;
   }
   LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 0);
@@ -264,6 +265,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
       LAUNCH(7, k_dynamics, side_blocks, 64, h->s_defer, P, 1);
     }
     if (draw) launch_view(h, 7, B, h->s_defer, P, 0);
+    if (view_flags) hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, h->s_defer, P);     // ... of the resumed envs
     (void)hipEventRecord(h->ev_join2, h->s_defer);
     (void)hipEventRecord(h->ev_join, h->s_side);
     P.role = 1;
@@ -279,11 +281,12 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     (void)hipStreamWaitEvent(st, h->ev_join, 0);
     (void)hipStreamWaitEvent(st, h->ev_join2, 0);
   }
-  // backward / on-grass bookkeeping (:446-495; k_flags.h, one wavefront per car) on the poses this step produced.  It closes
-  // the step on the caller's stream: running it beside the main raster launch (tried: side stream, behind every dynamics
-  // launch) slows that launch down by more than it saves
+  // The bookkeeping (:446-495; k_flags.h, one wavefront per car) of the main envs — of every env in single-stream mode —
+  // closes the step on the caller's stream.  Tried and measured: beside the raster on the side stream (fragments the
+  // raster's wavefront slots: 134 -> 158 us), behind the contact chain on the side stream (the step then waits for the
+  // longest contact chain), on a fourth stream beside the reset pass (a fifth HIP stream slows every queue down).
   if (view_flags) {
-    P.role = 0;
+    P.role = h->split ? 1 : 0;
     hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, st, P);
   }
 }
