@@ -415,19 +415,18 @@ __device__ inline float cc_position(const CcMass& S, const uint32_t* rec, int le
 // mode 1: the action-less step of reset() (:408) for envs whose `resetting` flag is set
 // debug bit 8 (256): lane 0 of every wavefront stamps the clock per phase (0 start, 1 state loaded + Car.step +
 // velocity integration, 2 velocity sweeps done, 3 position loop done, 4 end) into p.dbg_stamps[block][8] (main launch, then the launches of roles 2, 3, 4)
-#define DYN_STAMP(i) do { if ((p.debug & 256) && mode == 0 && threadIdx.x == 0) p.dbg_stamps[((p.role >= 2 ? (p.B * p.G + 63) / 64 + (p.role - 2) * ((p.B + 1) / 2) : 0) + blockIdx.x) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
-__global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
+#define DYN_STAMP(i) do { if ((p.debug & 256) && mode == 0 && threadIdx.x == 0) p.dbg_stamps[((p.role >= 2 ? (p.B * p.G + 63) / 64 + (p.role - 2) * ((p.B + 1) / 2) : 0) + blk) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+__device__ __forceinline__ void dynamics_block(const McrParams& p, const int mode, const int blk) {
   using namespace dyn;
   DYN_STAMP(0);
-  if (p.role == 1 && mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) p.clist_next[0] = 0;   // every reader of it finished last step
   // LDS used only by waves that contain a touching car<->car pair
   __shared__ float xv[15][64], xp[15][64];            // body exchange: (vx,vy,w) / (cx,cy,a) x 5 bodies per lane
   __shared__ __attribute__((aligned(16))) float vcpool[DYN_VC_POOL][cc::VC_SIZE];
   __shared__ uint32_t pcrec[DYN_VC_POOL][16];      // manifold records (key, type|n, local normal/point, 2 points) for the position sweeps
   __shared__ int xisl[64], xact[64], xjok[64], xcok[64];
   __shared__ float xms[64];
-  const int g = blockIdx.x * 64 + threadIdx.x;
-  const int env = mcr_env_of_slot(p, mcr_dyn_slot(p)), agent = g % p.G;
+  const int g = blk * 64 + threadIdx.x;
+  const int env = mcr_env_of_slot(p, mcr_dyn_slot(p, blk)), agent = g % p.G;
   const int env_end = p.env0 + p.nenv;
   bool lane_ok = env < env_end && agent < p.N;
   const int ci = lane_ok ? env * p.N + agent : 0;
@@ -923,6 +922,8 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
       // one, so their workgroups go FIRST (front of vorder) and cannot end up as the launch's tail
       // (only the main launch fills the list: envs of the contact / resume launches are drawn by launches of their own, and
       // an append from those streams would race with the main raster launch that is reading the counts)
+      // A re-spawned env of the main launch: with respawn_list its reset pass is a list launch (role 4)
+      if (p.role < 2 && respawn && p.respawn_list) p.rlist[1 + atomicAdd(&p.rlist[0], 1)] = env;
       if (p.role < 2 && (respawn || !(done && p.auto_reset))) {
         const bool heavy = respawn || es.t + 1.0 / MCR_FPS < 1.0;
         if (heavy) p.vorder[atomicAdd(&p.vcount[0], 1)] = env;
@@ -1106,7 +1107,19 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
 
 }
 
-// mcr_stage_episodes: the staged slots of envs ids[0..n) (all envs when ids == nullptr) hold a fresh episode now
+// LIST: the launches of roles >= 2, see k_collide
+template <bool LIST>
+__global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
+  if (!LIST) {
+    if (p.role == 1 && mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) p.clist_next[0] = 0;   // every reader of it finished last step
+    dynamics_block(p, mode, (int)blockIdx.x);
+  } else {
+    __builtin_amdgcn_s_setprio(3);
+    const int nb = mcr_virtual_blocks(p, p.list_envs_per_block);
+    for (int blk = blockIdx.x; blk < nb; blk += gridDim.x) { dynamics_block(p, mode, blk); __syncthreads(); }
+  }
+}
+
 __global__ void k_mark_staged(McrParams p, const int32_t* __restrict__ ids, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p.env[ids ? ids[i] : i].staged_ready = 1;

@@ -13,13 +13,13 @@
 #pragma once
 #include "k_raster_common.h"
 
-__global__ __launch_bounds__(64) void k_flags(McrParams p) {
+__device__ __forceinline__ void flags_block(const McrParams& p, const int blk) {
   const int lane = threadIdx.x;
   const int N = p.N, BN = p.BN;
   // roles as in the other step kernels: 0 every env, 1 the main launch's envs, 2 / 3 the contact / deferred lists
-  const int env = mcr_env_of_slot(p, (int)blockIdx.x / N);
+  const int env = mcr_env_of_slot(p, blk / N);
   if (env >= p.env0 + p.nenv) return;
-  const int ci = env * N + (int)blockIdx.x % N;
+  const int ci = env * N + blk % N;
   const McrEnvState es = p.env[env];
   if (!es.active || es.just_reset) return;                   // reset() -> step(None) skips the block (:435); a re-spawned car keeps its zeroed flags
   const uint8_t* __restrict__ slot = p.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES;
@@ -94,4 +94,15 @@ __global__ __launch_bounds__(64) void k_flags(McrParams p) {
   if (diff > PI / 2) f |= 1u;
   if (!any_inside) f |= 2u;
   p.caru[CU_FLAGS * BN + ci] = f;
+}
+
+// LIST: the launches of roles >= 2, see k_collide
+template <bool LIST>
+__global__ __launch_bounds__(64) void k_flags(McrParams p) {
+  if (!LIST) flags_block(p, (int)blockIdx.x);
+  else {
+    __builtin_amdgcn_s_setprio(3);
+    const int nb = mcr_list_len(p) * p.N;
+    for (int blk = blockIdx.x; blk < nb; blk += gridDim.x) flags_block(p, blk);
+  }
 }

@@ -1,0 +1,44 @@
+// k_list_chain.h — the step of the LIST envs (roles 2 / 3 / 4: the contact envs, the envs the main dynamics deferred, the
+// envs it re-spawned) in as few launches as possible.  These are a handful of envs per step whose work is a serial chain
+// of solver iterations; every launch of such a chain that has to start beside the main raster — which fills every CU —
+// queues for registers and LDS and then runs 2-4x slower than alone (measured), so the chain's kernels are fused and
+// launched before the raster: a small grid (how long the lists are only the device knows) whose workgroups walk the
+// list, wavefronts at issue priority 3.
+#pragma once
+#include "k_collide.h"
+#include "k_dynamics.h"
+#include "k_flags.h"
+
+// the reset pass (:408) of the list's envs that were re-spawned in this step: collide pass 1 (clear the per-tile state,
+// re-detect), then the action-less dynamics step
+__device__ __forceinline__ void list_reset_pass(const McrParams& p, const int blk) {
+  __threadfence();                                             // E->resetting as this step's dynamics left it
+  for (int k = 0; k < p.list_envs_per_block; ++k) { collide_block(p, 1, blk * p.list_envs_per_block + k); __syncthreads(); }
+  __threadfence();                                             // the dynamics lanes read what the collide lanes stored
+  __syncthreads();
+  dynamics_block(p, 1, blk);
+  __syncthreads();
+}
+
+// role 4: nothing but the reset pass (the main launch did the step; one env per workgroup: they run side by side)
+__global__ __launch_bounds__(64) void k_reset_list(McrParams p) {
+  __builtin_amdgcn_s_setprio(3);
+  const int nb = mcr_virtual_blocks(p, p.list_envs_per_block);
+  for (int blk = blockIdx.x; blk < nb; blk += gridDim.x) list_reset_pass(p, blk);
+}
+
+// roles 2 / 3: dynamics (for role 3: the rest of it) -> reset pass if the episode ended -> bookkeeping (k_flags.h)
+__global__ __launch_bounds__(64) void k_list_chain(McrParams p, const int with_flags) {
+  __builtin_amdgcn_s_setprio(3);
+  const int nb = mcr_virtual_blocks(p, p.list_envs_per_block);
+  for (int blk = blockIdx.x; blk < nb; blk += gridDim.x) {
+    dynamics_block(p, 0, blk);
+    __syncthreads();
+    if (p.auto_reset) list_reset_pass(p, blk);
+    if (with_flags) {
+      __threadfence();                                         // poses and env state as the dynamics left them
+      for (int c = 0; c < p.list_envs_per_block * p.N; ++c) flags_block(p, blk * p.list_envs_per_block * p.N + c);
+    }
+    __syncthreads();
+  }
+}

@@ -34,12 +34,18 @@ namespace view {
 
 constexpr int KS = 97;                 // key-buffer row stride in words: odd, so that a column of pixels walks all LDS banks
 constexpr int RC = 248;                // candidate slots (= record slots) per round
-constexpr int TASK4_CAP = 640;         // task entries per chunk; an entry covers 4 consecutive scan lines of one record
+constexpr int TASK4_CAP = 592;         // task entries per chunk; an entry covers 4 consecutive scan lines of one record
 constexpr float BIG = 1e30f;
-// draw order (painter's): key = index << 5 | palette index
-enum { IDX_PLAYFIELD = 1, IDX_GRASS = 2, IDX_ROAD = 8, IDX_CAR = CAR_KEY, IDX_BAR = 1200, IDX_GAUGE = 1201, IDX_FLAG = 1208, IDX_LABEL = 1209 };
-__device__ __forceinline__ uint32_t mk_key(int idx, int pal) { return ((uint32_t)idx << 5) | (uint32_t)pal; }
-// record meta word: key [0,16) | row-scan [16] | chained second half in the next slot [17] | first line [18,25) | lines [25,32)
+constexpr int NBLK = MCR_QUAD_CAP / MCR_QBLK;   // road_poly culling blocks per track
+// A pixel of the key buffer is rank << 24 | RGB: "highest rank wins" (ds_max_u32) is the painter's order of the reference
+// and the winner's colour needs no lookup.  Ranks: the playfield quad, the light grass squares, then the candidates in
+// slot order (road_poly entries in creation order, cars, gauges, flag: RANK_SLOT0 + slot), the score label on top.
+// A view that needs several rounds of candidates flattens what is drawn so far to RANK_FLAT before each further round.
+enum { RANK_BASE = 0, RANK_PLAYFIELD = 1, RANK_GRASS = 2, RANK_FLAT = 3, RANK_SLOT0 = 4, RANK_LABEL = 255 };
+// record key field: palette index [0,5) | rank [5,13) | HUD polygon, not clipped to the scene rows [13]
+__device__ __forceinline__ uint32_t mk_key(int rank, int pal) { return ((uint32_t)rank << 5) | (uint32_t)pal; }
+#define REC_HUD (1u << 13)
+// record meta word: key field [0,16) | row-scan [16] | chained second half in the next slot [17] | first line [18,25) | lines [25,32)
 #define REC_ROW (1u << 16)
 #define REC_CHAIN (1u << 17)
 
@@ -85,45 +91,57 @@ __device__ __forceinline__ uint32_t setup_poly(const float* px, const float* py,
 
 }  // namespace view
 
-// per-phase clock accumulators of thread 0 (debug bit 32): [view][16] u64, summed over the rounds of the view
-#define PHASE_ACC(i) do { if (dbg & 32) { const unsigned long long now_ = __builtin_readcyclecounter(); pacc[i] += now_ - tprev; tprev = now_; } } while (0)
+// per-phase clock accumulators of thread 0 (the PHASES instantiation, launched when debug bit 32 is set): [view][16] u64,
+// summed over the rounds of the view.  A separate instantiation: the accumulators cost 22 VGPRs the kernel does not have.
+#define PHASE_ACC(i) do { if constexpr (PHASES) { const unsigned long long now_ = __builtin_readcyclecounter(); pacc[i] += now_ - tprev; tprev = now_; } } while (0)
 
+template <bool PHASES, bool PERSIST>
 __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned long long* __restrict__ stamps, const int only_just_reset) {
   using namespace view;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = UNI(tid >> 6);
   const int N = p.N;
-  int env;
-  if (p.role >= 2) {                 // side streams / late pass: the envs in the contact / deferred lists
-    env = mcr_env_of_slot(p, blockIdx.x);
-    if (env >= p.env0 + p.nenv) return;
-  } else if (p.use_vorder) {         // step path: heavy (zoomed-out) envs first, see k_dynamics
-    const int idx = blockIdx.x, nh = p.vcount[0], nn = p.vcount[1];
-    if (idx >= nh + nn) return;
-    env = p.vorder[idx < nh ? idx : p.B - 1 - (idx - nh)];
-  } else {
-    env = p.env0 + (int)blockIdx.x;
-    if (env >= p.env0 + p.nenv) return;
+  // ---- this workgroup's envs.  Main launches: one env per workgroup (work slot = blockIdx; the hardware's dispatcher
+  // balances them better than a static assignment can: measured).  PERSIST — the list launches of the side streams, whose
+  // lists are short and whose length only the device knows: a small grid, workgroup b draws the envs of work slots
+  // b, b + gridDim, b + 2 gridDim, .. one after the other (lane k of every wavefront looks up slot b + k gridDim; the
+  // host sizes the grid so that 64 lanes cover the list), and what the next env needs from HBM — header, tile flags,
+  // view record, visible-block list, first candidates — is requested while the current one is drawn.
+  // Whose business is a work slot?
+  //   role >= 2 (side streams): the envs of the contact / deferred lists;  use_vorder (step path): the order k_dynamics
+  //   recorded, heavy (zoomed-out) envs first;  role 1: not the envs the side streams draw;  only_just_reset: reset().
+  if (PERSIST) __builtin_amdgcn_s_setprio(3);                               // a few envs beside the main launch that fills every CU: they go first
+  int my_env = -1, my_slot = 0;
+  {
+    const int s = (int)blockIdx.x + (PERSIST ? lane * (int)gridDim.x : 0);
+    int e = -1;
+    if (p.role >= 2) { e = mcr_env_of_slot(p, s); if (e >= p.env0 + p.nenv) e = -1; }
+    else if (p.use_vorder) { const int nh = p.vcount[0], nn = p.vcount[1]; if (s < nh + nn) e = p.vorder[s < nh ? s : p.B - 1 - (s - nh)]; }
+    else if (s < p.nenv) e = p.env0 + s;
+    if (e >= 0 && p.role == 1 && p.part[e]) e = -1;
+    if (e >= 0) {
+      const McrEnvState es = p.env[e];
+      // side-stream raster: a contact env re-spawned by this step's dynamics is drawn after its reset pass
+      if (!es.active || (only_just_reset && !es.just_reset) || (p.role >= 2 && !only_just_reset && es.resetting)) e = -1;
+      my_slot = es.slot;
+    }
+    my_env = e;
   }
-  if (p.role == 1 && p.part[env]) return;
-  const McrEnvState es = p.env[env];
-  if (!es.active) return;
-  if (only_just_reset && !es.just_reset) return;
-  // side-stream raster: a contact env re-spawned by this step's dynamics is drawn after its (late) reset pass
-  if (p.role >= 2 && !only_just_reset && es.resetting) return;
-  const uint8_t* __restrict__ slot = p.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES;
-  const McrSlotHeader* H = (const McrSlotHeader*)slot;
-  const float4* __restrict__ QA = (const float4*)(slot + MCR_OFF_QA); const float4* __restrict__ QB = (const float4*)(slot + MCR_OFF_QB);
-  const uint32_t* __restrict__ QM = (const uint32_t*)(slot + MCR_OFF_QMETA);
-  // what a candidate needs from HBM, requested one round ahead; the first round (road quads tid < RC <= capacity) goes
-  // out before the slot header is back: entries beyond P are never looked at
+  unsigned long long todo = PERSIST ? __ballot(my_env >= 0) : (my_env >= 0 ? 1ull : 0ull);
+  if (!todo) return;
+  auto slot_of = [&](int k) -> const uint8_t* {
+    return p.slots + ((size_t)__builtin_amdgcn_readlane(my_env, k) * 2 + __builtin_amdgcn_readlane(my_slot, k)) * MCR_SLOT_BYTES;
+  };
+  int env, P;
+  const uint8_t* __restrict__ slot;
+  { const int k = UNI(__builtin_ctzll(todo)); todo &= todo - 1; env = __builtin_amdgcn_readlane(my_env, k); slot = slot_of(k); }
+  // what a candidate needs from HBM, requested one round ahead
   struct Raw { float4 a, b, c, d; uint32_t m; };     // quad: a = v0 v1, b = v2 v3, m = meta | car polygon: a..d = 8 vertices, m = vertex count
   Raw nxt; nxt.a = nxt.b = nxt.c = nxt.d = make_float4(0.0f, 0.0f, 0.0f, 0.0f); nxt.m = 0u;
-  if (tid < view::RC) { nxt.a = QA[tid]; nxt.b = QB[tid]; nxt.m = QM[tid]; }
-  const int T = H->T, P = H->P;
+  P = ((const McrSlotHeader*)slot)->P;
   const int dbg = p.debug;
-  unsigned long long pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = (dbg & 32) ? __builtin_readcyclecounter() : 0ull;
+  unsigned long long pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = PHASES ? __builtin_readcyclecounter() : 0ull;
 
   __shared__ __attribute__((aligned(16))) uint32_t keyb[96 * KS];           // draw key per pixel, GL rows (0 = bottom)
   __shared__ __attribute__((aligned(16))) float4 rdat[RC][3];               // per record: slopes, lower consts, upper consts of 4 edges
@@ -131,28 +149,64 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
   __shared__ uint16_t tasks4[TASK4_CAP];                                    // record slot << 5 | group of 4 lines
   __shared__ uint32_t tfl[MCR_TILE_CAP / 2];                                // the env's tile flags (bit 8 / 24: recoloured)
   __shared__ uint32_t palc[32];
-  __shared__ float vrec[2][MCR_VIEWP_FLOATS];                               // view record of the agent being drawn / the next one
+  __shared__ float vrec[2][MCR_VIEWP_FLOATS];                               // view record of the view being drawn / the next one
   __shared__ float glo[20], ghi[20];
   __shared__ uint8_t glyphs[80];
   __shared__ int wsum[4];
+  __shared__ uint8_t vblk[2][NBLK];                                         // visible blocks of the view being drawn / the next one
+  __shared__ int nvb[2];
+  static_assert(MCR_TILE_CAP / 2 == VIEW_THREADS, "one tile-flag word per thread");
+  // Wavefront 3 lists, per view, the road_poly blocks (runs of MCR_QBLK consecutive entries; boxes from the track
+  // generator) the scene rectangle (obs x 0..96, y 12..96) can see: only their entries become candidates.  Separating-
+  // axis test both ways — the box in pixel space against the rectangle, the rectangle in world space against the box —
+  // with a pixel of slack.
+  auto list_blocks = [&](const uint8_t* __restrict__ sl, int vw, int buf) {
+    float4 bbox = make_float4(1.0f, 1.0f, -1.0f, -1.0f);
+    if (lane < NBLK) bbox = ((const float4*)(sl + MCR_OFF_QBLK))[lane];
+    const float* __restrict__ vp = p.viewp + (size_t)vw * MCR_VIEWP_FLOATS;
+    const float c0 = vp[VP_CAM + 0], c1 = vp[VP_CAM + 1], c2 = vp[VP_CAM + 2], c3 = vp[VP_CAM + 3], c4 = vp[VP_CAM + 4], c5 = vp[VP_CAM + 5];
+    const float v0 = vp[VP_INV + 0], v1 = vp[VP_INV + 1], v2 = vp[VP_INV + 2], v3 = vp[VP_INV + 3], v4 = vp[VP_INV + 4], v5 = vp[VP_INV + 5];
+    float pxl = BIG, pxh = -BIG, pyl = BIG, pyh = -BIG, wxl = BIG, wxh = -BIG, wyl = BIG, wyh = -BIG;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float X = (k & 1) ? bbox.z : bbox.x, Y = (k & 2) ? bbox.w : bbox.y;
+      const float px = __builtin_fmaf(c0, X, __builtin_fmaf(c1, Y, c4)), py = __builtin_fmaf(c2, X, __builtin_fmaf(c3, Y, c5));
+      pxl = fminf(pxl, px); pxh = fmaxf(pxh, px); pyl = fminf(pyl, py); pyh = fmaxf(pyh, py);
+      const float U = (k & 1) ? 96.0f : 0.0f, V = (k & 2) ? 96.0f : 12.0f;
+      const float wx = v0 * U + v1 * V + v2, wy = v3 * U + v4 * V + v5;
+      wxl = fminf(wxl, wx); wxh = fmaxf(wxh, wx); wyl = fminf(wyl, wy); wyh = fmaxf(wyh, wy);
+    }
+    const float mx = fabsf(v0) + fabsf(v1) + 0.05f, my = fabsf(v3) + fabsf(v4) + 0.05f;
+    const bool vis = bbox.x <= bbox.z && pxh >= -1.0f && pxl <= 97.0f && pyh >= 11.0f && pyl <= 97.0f &&
+                     bbox.z >= wxl - mx && bbox.x <= wxh + mx && bbox.w >= wyl - my && bbox.y <= wyh + my;
+    const unsigned long long mask = __ballot(vis);
+    if (vis) vblk[buf][__popcll(mask & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+    if (lane == 0) nvb[buf] = __popcll(mask);
+  };
 
-  // ---- per env: palette, glyphs, grass lattice, tile flags, first agent's view record
+  // ---- once per workgroup: palette, glyphs, grass lattice; the first env's tile flags, view record, block list
   if (tid < 32) palc[tid] = PALETTE_RGB[tid];
   if (tid >= 128 && tid < 128 + 77) glyphs[tid - 128] = ((const uint8_t*)LABEL_GLYPHS)[tid - 128];
-  if (tid < (T + 1) / 2) tfl[tid] = ((const uint32_t*)(p.tile_flags + (size_t)env * MCR_TILE_CAP))[tid];
+  tfl[tid] = ((const uint32_t*)(p.tile_flags + (size_t)env * MCR_TILE_CAP))[tid];
   if (tid >= 64 && tid < 64 + MCR_VIEWP_FLOATS) vrec[0][tid - 64] = p.viewp[(size_t)(env * N) * MCR_VIEWP_FLOATS + (tid - 64)];
+  if (wave == 3) list_blocks(slot, env * N, 0);
   // grass lattice as the reference builds it (:620-627): f32(k*x) and f32(k*x + k) for x = -20, -18, .., 18
   if (tid >= 224 && tid < 244) { const double k = MCR_PLAYFIELD / 20.0, x = 2.0 * (double)(tid - 224 - 10); glo[tid - 224] = (float)(k * x + 0); ghi[tid - 224] = (float)(k * x + k); }
   const float kx = 96.0f / 1000.0f, ky = 96.0f / 800.0f;
-  // `sb`: first candidate index of the view's specials (they sit at the END of the last round, see below)
-  auto fetch_raw = [&](int c, int sb) -> Raw {
+  // candidate c of a view (env e, episode slot sl with pe road_poly entries) whose visible blocks are
+  // vblk[buf][0 .. pv / QBLK): road_poly entry or special; `sb`: first candidate index of the view's specials (they sit
+  // at the END of the last round, see below)
+  auto quad_of = [&](int c, int buf) -> int { return (int)vblk[buf][c / MCR_QBLK] * MCR_QBLK + (c & (MCR_QBLK - 1)); };
+  auto fetch_raw = [&](int c, int pv, int sb, int buf, const uint8_t* __restrict__ sl, int pe, int e) -> Raw {
     Raw r; r.a = r.b = r.c = r.d = make_float4(0.0f, 0.0f, 0.0f, 0.0f); r.m = 0u;
-    if (c < P) { r.a = QA[c]; r.b = QB[c]; r.m = QM[c]; }
-    else if (c >= sb && c - sb < 14 * N) {
-      const int cc = (c - sb) / 14, sl = (c - sb) - cc * 14;
-      const int j = sl < 11 ? sl : sl - 1;                                  // slot 11 is the second half of polygon 10 (the 8-gon), slot 13 a pad
-      if (sl != 11 && sl != 13) {
-        const float* __restrict__ cp = p.carpoly + (size_t)(env * N + cc) * MCR_CARPOLY_FLOATS;
+    if (c < pv) {
+      const int q = quad_of(c, buf);
+      if (q < pe) { r.a = ((const float4*)(sl + MCR_OFF_QA))[q]; r.b = ((const float4*)(sl + MCR_OFF_QB))[q]; r.m = ((const uint32_t*)(sl + MCR_OFF_QMETA))[q]; }
+    } else if (c >= sb && c - sb < 14 * N) {
+      const int cc = (c - sb) / 14, sl14 = (c - sb) - cc * 14;
+      const int j = sl14 < 11 ? sl14 : sl14 - 1;                            // slot 11 is the second half of polygon 10 (the 8-gon), slot 13 a pad
+      if (sl14 != 11 && sl14 != 13) {
+        const float* __restrict__ cp = p.carpoly + (size_t)(e * N + cc) * MCR_CARPOLY_FLOATS;
         const float4* cv = (const float4*)(cp + j * 16);
         r.a = cv[0]; r.b = cv[1]; r.c = cv[2]; r.d = cv[3];
         r.m = (uint32_t)__float_as_int(cp[MCR_CARPOLY_NOFF + j]);
@@ -161,15 +215,31 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
     return r;
   };
 
+  int vs = 0;                                                               // views this workgroup has drawn
 #pragma nounroll
-  for (int agent = 0; agent < N; ++agent) {
+  for (;;) {
+  // the workgroup's next env, if any
+  const bool has_next = PERSIST && todo != 0ull;
+  int env_n = env; const uint8_t* __restrict__ slot_n = slot;
+  if (has_next) { const int k = UNI(__builtin_ctzll(todo)); todo &= todo - 1; env_n = __builtin_amdgcn_readlane(my_env, k); slot_n = slot_of(k); }
+  uint32_t tfl_n = 0u; int P_nv = 0;
+#pragma nounroll
+  for (int agent = 0; agent < N; ++agent, ++vs) {
     const int vw = env * N + agent;
-    const float* __restrict__ vr = vrec[agent & 1];
+    const int buf = vs & 1;
+    const float* __restrict__ vr = vrec[buf];
+    // the view after this one: the env's next agent, or agent 0 of the workgroup's next env
+    const bool last = agent + 1 == N;
+    const bool nv_ok = !last || has_next;
+    const int env_v = last ? env_n : env, vw_v = last ? env_n * N : vw + 1;
+    const uint8_t* __restrict__ slot_v = last ? slot_n : slot;
     PHASE_ACC(0);
-    __syncthreads();                                                        // this view's record is in LDS; the previous view's resolve is through with the key buffer
+    __syncthreads();                                                        // this view's record and block list are in LDS; the previous view's resolve is through with the key buffer
     PHASE_ACC(1);
-    // the next agent's view record travels while this one is drawn
-    if (agent + 1 < N && tid >= 64 && tid < 64 + MCR_VIEWP_FLOATS) vrec[(agent + 1) & 1][tid - 64] = p.viewp[(size_t)(vw + 1) * MCR_VIEWP_FLOATS + (tid - 64)];
+    // the next view's record, block list and (new env) tile flags / entry count travel while this one is drawn
+    if (nv_ok && tid >= 64 && tid < 64 + MCR_VIEWP_FLOATS) vrec[buf ^ 1][tid - 64] = p.viewp[(size_t)vw_v * MCR_VIEWP_FLOATS + (tid - 64)];
+    if (nv_ok && wave == 3) list_blocks(slot_v, vw_v, buf ^ 1);
+    if (last && has_next) { tfl_n = ((const uint32_t*)(p.tile_flags + (size_t)env_n * MCR_TILE_CAP))[tid]; P_nv = ((const McrSlotHeader*)slot_n)->P; }
     const float m00 = vr[VP_CAM + 0], m01 = vr[VP_CAM + 1], m10 = vr[VP_CAM + 2], m11 = vr[VP_CAM + 3], ctx = vr[VP_CAM + 4], cty = vr[VP_CAM + 5];
     const uint32_t old_flags = __float_as_uint(vr[VP_OLDFLAGS]);
     // grass squares the viewport can see / "is the whole viewport inside the playfield" (k_dynamics, from the inverse camera)
@@ -177,7 +247,7 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
     const bool inside_field = UNI(__float_as_int(vr[VP_GRASS + 4])) != 0;
     // key-buffer clear: HUD bar (window y < 100 = obs rows 0..11, :655-656) and the scene's base colour
     {
-      const uint32_t kbar = mk_key(IDX_BAR, PAL_BLACK), kbase = inside_field ? mk_key(IDX_PLAYFIELD, PAL_GRASS0) : 0u;
+      const uint32_t kbar = 0u, kbase = inside_field ? ((uint32_t)RANK_PLAYFIELD << 24) | palc[PAL_GRASS0] : 0u;   // black bar / black beyond the playfield
       uint4* k4 = (uint4*)keyb;
       for (int i = tid; i < 96 * KS / 4; i += VIEW_THREADS) {
         const uint32_t k = i < 12 * KS / 4 ? kbar : kbase;                  // 12 * 97 = 1164 words = 291 uint4: the split is aligned
@@ -188,19 +258,32 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
     // land on the wavefront the quads leave idle), the specials: 14 slots per car (its 12 Car.draw polygons, world
     // vertices from k_dynamics; the 8-gon hull polygon takes slots 10+11), 7 gauges, the flag, the playfield quad (only
     // when the view leaves it), the G light grass squares the viewport can see.
+    const int Pv = UNI(nvb[buf]) * MCR_QBLK;                                // road_poly candidates: the entries of the visible blocks
     const int G = nu * nv;
     const int F = 14 * N + 8 + (inside_field ? 0 : 1);
     const int nspec = (F + G + 1) & ~1;                                     // even: the 8-gon's slot pair never straddles two rounds
-    const int nround = (P + nspec + RC - 1) / RC;
+    const int nround = (Pv + nspec + RC - 1) / RC;
     const int SB = nround * RC - nspec;
-    if (tid < RC && tid >= SB) nxt = fetch_raw(tid, SB);                    // tiny tracks only: specials already in round 0
+    if (vs == 0 && tid < RC) nxt = fetch_raw(tid, Pv, SB, buf, slot, P, env);   // later views: requested while the previous one was drawn
 #pragma nounroll
     for (int rd = 0; rd < nround; ++rd) {
       const int c = rd * RC + tid;
       const Raw cur = nxt;
+      if (rd > 0) {                                                         // what the earlier rounds drew keeps its colour, below everything to come (but above the grass)
+        uint4* k4 = (uint4*)keyb;
+        for (int i = tid; i < 96 * KS / 4; i += VIEW_THREADS) {
+          uint4 k = k4[i];
+          k.x = k.x > (((uint32_t)RANK_FLAT << 24) | 0xffffffu) ? (k.x & 0xffffffu) | ((uint32_t)RANK_FLAT << 24) : k.x;
+          k.y = k.y > (((uint32_t)RANK_FLAT << 24) | 0xffffffu) ? (k.y & 0xffffffu) | ((uint32_t)RANK_FLAT << 24) : k.y;
+          k.z = k.z > (((uint32_t)RANK_FLAT << 24) | 0xffffffu) ? (k.z & 0xffffffu) | ((uint32_t)RANK_FLAT << 24) : k.z;
+          k.w = k.w > (((uint32_t)RANK_FLAT << 24) | 0xffffffu) ? (k.w & 0xffffffu) | ((uint32_t)RANK_FLAT << 24) : k.w;
+          k4[i] = k;
+        }
+      }
       const bool mine = tid < RC;
       uint32_t my_meta = 0u;                                                // a culled slot has no lines
-      if (mine && c < P) {
+      const int q = (mine && c < Pv) ? quad_of(c, buf) : P;
+      if (q < P) {
         // ---- road_poly entry
         const float wx[4] = {cur.a.x, cur.a.z, cur.b.x, cur.b.z}, wy[4] = {cur.a.y, cur.a.w, cur.b.y, cur.b.w};
         const uint32_t meta = cur.m;
@@ -216,7 +299,7 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
             uint32_t col = meta & 0xffu;
             if (tile1 && ((tfl[(tile1 - 1) >> 1] >> (((tile1 - 1) & 1u) * 16u)) & 0x100u)) col = MCR_COL_ROAD0;     // touched tile -> ROAD_COLOR (:102-104)
             const uint32_t pal = col == MCR_COL_ROAD0 ? PAL_ROAD0 : col == MCR_COL_ROAD1 ? PAL_ROAD1 : col == MCR_COL_ROAD2 ? PAL_ROAD2 : col == MCR_COL_KERB_WHITE ? PAL_WHITE : PAL_RED255;
-            my_meta = setup_poly(px, py, false, mk_key(IDX_ROAD + c, pal), i0, i1, j0, j1, rdat, tid);
+            my_meta = setup_poly(px, py, false, mk_key(RANK_SLOT0 + tid, pal), i0, i1, j0, j1, rdat, tid);
           }
         }
       } else if (mine && c >= SB && c - SB < F + G) {
@@ -226,7 +309,7 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
         float wx[8], wy[8];
         if (sidx < 14 * N) {                                                // Car.draw polygon
           const int cc = sidx / 14, sl = sidx - cc * 14;
-          const int j = sl < 11 ? sl : sl - 1, k = cc * 12 + j;
+          const int j = sl < 11 ? sl : sl - 1;
           const int n = (int)cur.m;
           if (sl != 11 && sl != 13 && n > 0 && !(dbg & 4)) {
             wx[0] = cur.a.x; wy[0] = cur.a.y; wx[1] = cur.a.z; wy[1] = cur.a.w; wx[2] = cur.b.x; wy[2] = cur.b.y; wx[3] = cur.b.z; wy[3] = cur.b.w;
@@ -234,7 +317,7 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
             uint32_t colr;
             if (j < 8) colr = (j & 1) ? PAL_WHEELWHITE : PAL_BLACK;
             else { colr = PAL_CAR0 + (cc & 7); if (p.use_ego_color) colr = (cc == agent) ? PAL_CAR0 + 0 : PAL_CAR0 + 1; }   // :402, :560-563
-            key = mk_key(IDX_CAR + k, colr);
+            key = mk_key(RANK_SLOT0 + tid, colr);
             nn = (n > 4 && sl == 10) ? 8 : 4;                               // only HULL_POLY3 has more than 4 vertices (mcr_create checks); k_dynamics pads to 8
           }
         } else if (sidx < F) {
@@ -244,23 +327,23 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
             if (gx1 > gx0 && gy1 > gy0) {
               px[0] = gx0; py[0] = gy0; px[1] = gx1; py[1] = gy0; px[2] = gx1; py[2] = gy1; px[3] = gx0; py[3] = gy1;
               const uint32_t col = h == 0 ? PAL_WHITE : h <= 2 ? PAL_BLUE255 : h <= 4 ? PAL_PURPLE : h == 5 ? PAL_GREEN255 : PAL_RED255;
-              key = mk_key(IDX_GAUGE + h, col); nn = -4; cminY = 0;
+              key = mk_key(RANK_SLOT0 + tid, col) | REC_HUD; nn = -4; cminY = 0;
             }
           } else if (h == 7) {                                              // backwards flag (:669-674): drawn with last step's flag
             if ((old_flags & 1u) && p.backwards_flag) {
               px[0] = 900.0f * kx; py[0] = 30.0f * ky; px[1] = 925.0f * kx; py[1] = 70.0f * ky; px[2] = 950.0f * kx; py[2] = 30.0f * ky; px[3] = px[2]; py[3] = py[2];
-              key = mk_key(IDX_FLAG, PAL_BLUE255); nn = -4; cminY = 0;
+              key = mk_key(RANK_SLOT0 + tid, PAL_BLUE255) | REC_HUD; nn = -4; cminY = 0;
             }
           } else {                                                          // playfield quad (:615-619), only when the view leaves it
             const float PF = (float)MCR_PLAYFIELD;
             wx[0] = -PF; wy[0] = PF; wx[1] = PF; wy[1] = PF; wx[2] = PF; wy[2] = -PF; wx[3] = -PF; wy[3] = -PF;
-            key = mk_key(IDX_PLAYFIELD, PAL_GRASS0); nn = 4;
+            key = mk_key(RANK_PLAYFIELD, PAL_GRASS0); nn = 4;
           }
         } else {                                                            // light grass square (:620-627)
           const int g = sidx - F, iv = g / nu, iu = g - iv * nu;
           const int tu = mu0 + iu + 10, tv = mv0 + iv + 10;
           wx[0] = ghi[tu]; wy[0] = glo[tv]; wx[1] = glo[tu]; wy[1] = glo[tv]; wx[2] = glo[tu]; wy[2] = ghi[tv]; wx[3] = ghi[tu]; wy[3] = ghi[tv];
-          key = mk_key(IDX_GRASS, PAL_GRASS1); nn = 4;
+          key = mk_key(RANK_GRASS, PAL_GRASS1); nn = 4;
         }
         const bool eight = nn == 8;
         if (nn > 0) {                                                       // camera transform (world -> pixel)
@@ -297,15 +380,22 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
       // next round's candidates (or round 0 of the next agent's view: the same quads): their HBM / L2 data travels
       // while this round's spans are drawn
       if (tid < RC) {
-        if (rd + 1 < nround) nxt = fetch_raw(c + RC, SB);
-        else if (agent + 1 < N) nxt = fetch_raw(tid, 1 << 30);
+        if (rd + 1 < nround) nxt = fetch_raw(c + RC, Pv, SB, buf, slot, P, env);
+        else if (nv_ok) {                                                   // round 0 of the next view (its record and block list are in LDS)
+          const float* __restrict__ vn = vrec[buf ^ 1];
+          const int pvn = UNI(nvb[buf ^ 1]) * MCR_QBLK;
+          const int gn = UNI(__float_as_int(vn[VP_GRASS + 1])) * UNI(__float_as_int(vn[VP_GRASS + 3]));
+          const int nsn = (14 * N + 8 + (UNI(__float_as_int(vn[VP_GRASS + 4])) ? 0 : 1) + gn + 1) & ~1;
+          const int sbn = (pvn + nsn + RC - 1) / RC * RC - nsn;
+          nxt = fetch_raw(tid, pvn, sbn, buf ^ 1, slot_v, last ? UNI(P_nv) : P, env_v);
+        }
       }
       // score label (:665-666): white glyph cells stamped with the top key; 16 x 4 pixel centres cover its window box
-      if (rd == 0 && wave == 2) {
+      if (rd + 1 == nround && wave == 2) {
         const int lx = 1 + (lane & 15), ly = 4 + (lane >> 4);
         const int value = UNI(__float_as_int(vr[VP_SCORE]));
         if (label_on(value, ((float)lx + 0.5f) * (1000.0f / 96.0f), ((float)ly + 0.5f) * (800.0f / 96.0f), glyphs))
-          atomicMax(&keyb[ly * KS + lx], mk_key(IDX_LABEL, PAL_WHITE));
+          atomicMax(&keyb[ly * KS + lx], ((uint32_t)RANK_LABEL << 24) | 0xffffffu);
       }
       int off = incl - g4;
       for (int w = 0; w < 4; ++w) if (w < wave) off += wsum[w];
@@ -338,20 +428,21 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
                 lo = fmaxf(lo, fmaxf(fmaxf(__builtin_fmaf(S2.x, v, L2.x), __builtin_fmaf(S2.y, v, L2.y)), fmaxf(__builtin_fmaf(S2.z, v, L2.z), __builtin_fmaf(S2.w, v, L2.w))));
                 hi = fminf(hi, fminf(fminf(__builtin_fmaf(S2.x, v, H2.x), __builtin_fmaf(S2.y, v, H2.y)), fminf(__builtin_fmaf(S2.z, v, H2.z), __builtin_fmaf(S2.w, v, H2.w))));
               }
-              key = meta & 0xffffu;
+              key = ((meta << 19) & 0xff000000u) | palc[meta & 31u];
               const bool row = (meta & REC_ROW) != 0u;
               // rows < 12 belong to the HUD: scene polygons stop at y = 12 (row scans are clipped by their line range)
-              const float cmin = (row || key >= mk_key(IDX_BAR, 0)) ? 0.0f : 12.0f;
+              const float cmin = (meta & (REC_ROW | REC_HUD)) ? 0.0f : 12.0f;
               lo = fmaxf(lo, cmin); hi = fminf(hi, 96.0f);
               const int a = (int)ceilf(lo - 0.5f), b = (int)floorf(hi - 0.5f);    // pixel centres a+.5 .. b+.5 lie in [lo, hi]
               len = b - a + 1;
-              addr = row ? line * KS + a : a * KS + line;
+              addr = (row ? line : a) * KS + (row ? a : line);
               stride = row ? 1 : KS;
             }
           }
-          for (int j = 0; __any(j < len); ++j) {
-            if (j < len) atomicMax(&keyb[addr], key);
-            addr += stride;
+          // a lane leaves the loop when its span is drawn (the wavefront iterates to its longest span)
+          if (len > 0) {
+            int j = 0;
+            do { atomicMax(&keyb[addr], key); addr += stride; } while (++j < len);
           }
         }
         PHASE_ACC(6);
@@ -363,33 +454,29 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
     // ---- resolve + packed RGB write-out: 4 pixels -> 12 bytes per lane, rows top-down (arr[::-1], :602)
     if (!(dbg & 8)) {
       uint32_t* __restrict__ out = (uint32_t*)(p.obs + (size_t)vw * (96 * 96 * 3));
-      // 9 groups of 4 pixels per thread, three at a time: the LDS round trips (keys, then palette) of a batch overlap
-#pragma unroll
-      for (int g0 = 0; g0 < 9; g0 += 3) {
-        uint32_t kk[3][4];
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-          const int g = (g0 + u) * VIEW_THREADS + tid, r = g / 24, x4 = (g - r * 24) * 4;
-          const uint32_t* kp = &keyb[(95 - r) * KS + x4];
-          kk[u][0] = kp[0]; kk[u][1] = kp[1]; kk[u][2] = kp[2]; kk[u][3] = kp[3];
-        }
-        uint32_t cc4[3][4];
-#pragma unroll
-        for (int u = 0; u < 3; ++u)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) cc4[u][i] = palc[kk[u][i] & 31u];
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-          const int g = (g0 + u) * VIEW_THREADS + tid;
-          uint3 w; w.x = cc4[u][0] | (cc4[u][1] << 24); w.y = (cc4[u][1] >> 8) | (cc4[u][2] << 16); w.z = (cc4[u][2] >> 16) | (cc4[u][3] << 8);
-          *(uint3*)(out + (size_t)g * 3) = w;
-        }
+      // 9 groups of 4 pixels per thread: the winners' RGB bytes are packed with three byte permutes
+#pragma unroll 3
+      for (int g0 = 0; g0 < 9; ++g0) {
+        const int g = g0 * VIEW_THREADS + tid, r = g / 24, x4 = (g - r * 24) * 4;
+        const uint32_t* kp = &keyb[(95 - r) * KS + x4];
+        const uint32_t c0 = kp[0], c1 = kp[1], c2 = kp[2], c3 = kp[3];
+        uint3 w;
+        w.x = __builtin_amdgcn_perm(c1, c0, 0x04020100u); w.y = __builtin_amdgcn_perm(c2, c1, 0x05040201u); w.z = __builtin_amdgcn_perm(c3, c2, 0x06050402u);
+        *(uint3*)(out + (size_t)g * 3) = w;
       }
     }
     PHASE_ACC(8);
-    if ((dbg & 32) && tid == 0 && stamps) {
+    if (PHASES && tid == 0 && stamps) {
       for (int i = 0; i < 9; ++i) { stamps[(size_t)vw * 16 + i] = pacc[i]; pacc[i] = 0; }
       stamps[(size_t)vw * 16 + 9] = (unsigned long long)nround;
+      // placement: wall clock (100 MHz) at the end of the view, workgroup | view number, HW_ID | XCC_ID
+      stamps[(size_t)vw * 16 + 10] = __builtin_amdgcn_s_memrealtime();
+      stamps[(size_t)vw * 16 + 11] = (unsigned long long)blockIdx.x | ((unsigned long long)vs << 32);
+      stamps[(size_t)vw * 16 + 12] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
     }
+  }
+  if (!has_next) break;
+  // hand-over: every thread is past the last barrier of the view's span fill, nobody reads the tile flags any more
+  env = env_n; slot = slot_n; P = UNI(P_nv); tfl[tid] = tfl_n;
   }
 }

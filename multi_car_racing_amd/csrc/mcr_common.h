@@ -71,7 +71,9 @@ struct McrSlotHeader {
 #define MCR_OFF_TNA (MCR_OFF_TVB + 16 * MCR_TILE_CAP)         // float4             n0 n1
 #define MCR_OFF_TNB (MCR_OFF_TNA + 16 * MCR_TILE_CAP)         // float4             n2 n3
 #define MCR_OFF_TCNT (MCR_OFF_TNB + 16 * MCR_TILE_CAP)        // u32    [TILE_CAP]  hull vertex count (3|4) | kerb<<8
-#define MCR_SLOT_BYTES (MCR_OFF_TCNT + 4 * MCR_TILE_CAP)
+#define MCR_QBLK 16                                           // road_poly entries per culling block of the raster
+#define MCR_OFF_QBLK (MCR_OFF_TCNT + 4 * MCR_TILE_CAP)        // float4 [QUAD_CAP / QBLK]  lo.xy hi.xy of each run of QBLK road_poly entries (empty: lo > hi)
+#define MCR_SLOT_BYTES (MCR_OFF_QBLK + 16 * (MCR_QUAD_CAP / MCR_QBLK))
 
 // quad colour ids (u8 RGB after the GL float->unorm8 conversion)
 enum { MCR_COL_ROAD0 = 0, MCR_COL_ROAD1 = 1, MCR_COL_ROAD2 = 2, MCR_COL_KERB_WHITE = 3, MCR_COL_KERB_RED = 4 };

@@ -6,6 +6,7 @@
 #include "k_collide.h"
 #include "k_view.h"
 #include "k_flags.h"
+#include "k_list_chain.h"
 #include "k_render.h"
 #include <hip/hip_runtime.h>
 #include <string>
@@ -78,6 +79,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   const size_t o_cc = carve(sizeof(uint32_t) * (size_t)B * (MCR_CC_MAX * MCR_CC_WORDS + 4));
   const size_t o_part = carve(B);
   const size_t o_dlist = carve(sizeof(int32_t) * ((size_t)B + 1));
+  const size_t o_rlist = carve(sizeof(int32_t) * ((size_t)B + 1));
   const size_t o_dstate = carve(BN);
   const size_t o_counters = carve(sizeof(unsigned long long) * 4);
   const size_t o_stage_ids = carve(sizeof(int32_t) * (size_t)B);
@@ -102,7 +104,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   P.cc_store = (uint32_t*)(base + o_cc); P.shapes = (const McrShapes*)(base + o_shapes); P.slots = base + o_slots;
   h->view_stamps = (unsigned long long*)(base + o_vscratch);
   P.viewp = (float*)(base + o_viewp);
-  P.part = base + o_part; P.dlist = (int32_t*)(base + o_dlist); P.defer_state = base + o_dstate; P.counters = (unsigned long long*)(base + o_counters); P.stats = (double*)(base + o_stats);
+  P.part = base + o_part; P.dlist = (int32_t*)(base + o_dlist); P.rlist = (int32_t*)(base + o_rlist); P.defer_state = base + o_dstate; P.counters = (unsigned long long*)(base + o_counters); P.stats = (double*)(base + o_stats);
   h->stage_ids = (int32_t*)(base + o_stage_ids); P.vcount = (int32_t*)(base + o_vorder); P.vorder = P.vcount + 2; P.dbg_stamps = (unsigned long long*)(base + o_stamps); P.clist = (int32_t*)(base + o_clist);
   P.carpoly = (float*)(base + o_carpoly);
   P.auto_reset = cfg->auto_reset; P.max_steps = cfg->max_episode_steps; P.car_contacts = cfg->car_contacts;
@@ -125,7 +127,10 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   P.env0 = 0; P.nenv = B; P.split = 0; P.role = 0;
   h->split = false; h->step_parity = 0;
   if (cfg->num_streams == 2) {
-    // highest priority: its few workgroups must not queue behind the main stream's saturating raster launch
+    // highest priority: their few workgroups must not queue behind the main stream's saturating raster launch.
+    // (Tried: giving the chains CUs of their own with hipExtStreamCreateWithCUMask — tools/ubench/cumask_probe.hip shows
+    // the mask layout — restores their stand-alone kernel times beside the raster, but every launch and event hop on a
+    // masked stream costs ~10 us more: 0.81 ms per step.)
     int prio_lo = 0, prio_hi = 0; (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     if (hipStreamCreateWithPriority(&h->s_side, hipStreamNonBlocking, prio_hi) == hipSuccess) {
       if (hipStreamCreateWithPriority(&h->s_defer, hipStreamNonBlocking, prio_hi) == hipSuccess) {
@@ -200,9 +205,15 @@ static hipEvent_t get_event(mcr_env* h) {
     if (tm_) { (void)hipEventRecord(tl_.b, st); h->pending.push_back(tl_); }                   \
   } while (0)
 
-// raster launch (k_view.h): one workgroup per env (its N agent views one after the other)
-static void launch_view(mcr_env* h, int kid, int grid, hipStream_t st, const McrParams& P, int only_just_reset) {
-  LAUNCH(kid, k_view, grid, VIEW_THREADS, st, P, h->view_stamps, only_just_reset);
+// raster launch (k_view.h).  Main launches: one workgroup per work slot.  List launches (role >= 2): MCR_LIST_GRID
+// persistent workgroups that walk the list (lane k of a wavefront holds a workgroup's k-th env, so never fewer than
+// slots / 64 workgroups).
+#define MCR_LIST_GRID 128
+static int list_grid(int slots) { return std::min(slots, std::max(MCR_LIST_GRID, (slots + 63) / 64)); }
+static void launch_view(mcr_env* h, int kid, int slots, hipStream_t st, const McrParams& P, int only_just_reset) {
+  if (P.role >= 2) { LAUNCH(kid, (k_view<false, true>), list_grid(slots), VIEW_THREADS, st, P, h->view_stamps, only_just_reset); }
+  else if (P.debug & 32) { LAUNCH(kid, (k_view<true, false>), slots, VIEW_THREADS, st, P, h->view_stamps, only_just_reset); }
+  else { LAUNCH(kid, (k_view<false, false>), slots, VIEW_THREADS, st, P, h->view_stamps, only_just_reset); }
 }
 
 // reset(): install -> collide(1) -> dynamics(1) -> view, in order on one stream
@@ -211,8 +222,8 @@ static void launch_reset(mcr_env* h, McrParams P, hipStream_t st) {
   const int dyn_blocks = (B * P.G + 63) / 64;
   P.split = 0; P.role = 0; P.use_vorder = 0;
   hipLaunchKernelGGL(k_install, dim3(dyn_blocks), dim3(64), 0, st, P);
-  LAUNCH_LDS(3, k_collide, B, 64, col::lds_bytes(N), st, P, 1);
-  LAUNCH(4, k_dynamics, dyn_blocks, 64, st, P, 1);
+  LAUNCH_LDS(3, k_collide<false>, B, 64, col::lds_bytes(N), st, P, 1);
+  LAUNCH(4, k_dynamics<false>, dyn_blocks, 64, st, P, 1);
   if (P.obs) launch_view(h, 2, B, st, P, 1);
 }
 
@@ -230,65 +241,68 @@ static void launch_reset(mcr_env* h, McrParams P, hipStream_t st) {
 static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags) {
   const int B = P.B, N = P.N;
   const int dyn_blocks = (B * P.G + 63) / 64;
-  const int side_blocks = (B + MCR_SIDE_ENVS_PER_WAVE - 1) / MCR_SIDE_ENVS_PER_WAVE;   // list launches: few envs per wavefront
+  // list launches (contact / deferred / re-spawned envs): small grids whose workgroups walk the device-side lists
+  const int lg_col = std::min(B, MCR_LIST_GRID), lg_dyn = std::min((B + MCR_SIDE_ENVS_PER_WAVE - 1) / MCR_SIDE_ENVS_PER_WAVE, MCR_LIST_GRID / MCR_SIDE_ENVS_PER_WAVE);
   const bool draw = P.obs != nullptr;
-  P.role = 0; P.split = h->split ? 1 : 0; P.defer_after = 0;
+  P.role = 0; P.split = h->split ? 1 : 0; P.defer_after = 0; P.respawn_list = 0;
   if (h->split) {      // the contact list is double-buffered by step parity; no memset on the critical path
     int32_t* base = h->P.clist;
     P.clist = base + (size_t)(h->step_parity) * (B + 1); P.clist_next = base + (size_t)(h->step_parity ^ 1) * (B + 1);
     h->step_parity ^= 1;
   }
-  LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), st, P, 0);
+  LAUNCH_LDS(0, k_collide<false>, B, 64, col::lds_bytes(N), st, P, 0);
   P.split = 0;
-  if (h->split) {
-    P.defer_after = MCR_DEFER_AFTER;
-    (void)hipEventRecord(h->ev_fork, st);
-    (void)hipStreamWaitEvent(h->s_side, h->ev_fork, 0);
-    P.role = 2;
-    LAUNCH(5, k_dynamics, side_blocks, 64, h->s_side, P, 0);
-    if (P.auto_reset) {   // a contact env that ended its episode takes its reset pass (:408) right here, in its own chain
-      LAUNCH_LDS(7, k_collide, B, 64, col::lds_bytes(N), h->s_side, P, 1);
-      LAUNCH(7, k_dynamics, side_blocks, 64, h->s_side, P, 1);
-    }
-    if (draw) launch_view(h, 6, B, h->s_side, P, 0);
-    if (view_flags) hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, h->s_side, P);      // bookkeeping of the contact envs
-    P.role = 1;
-  }
-  LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 0);
-  if (h->split) {
-    (void)hipEventRecord(h->ev_fork2, st);
-    (void)hipStreamWaitEvent(h->s_defer, h->ev_fork2, 0);
-    P.role = 3;
-    LAUNCH(7, k_dynamics, side_blocks, 64, h->s_defer, P, 0);
+  if (!h->split) {
+    // single stream: collide -> dynamics -> reset pass of the re-spawned envs (:408) -> raster -> bookkeeping, all envs
+    LAUNCH(1, k_dynamics<false>, dyn_blocks, 64, st, P, 0);
     if (P.auto_reset) {
-      LAUNCH_LDS(7, k_collide, B, 64, col::lds_bytes(N), h->s_defer, P, 1);
-      LAUNCH(7, k_dynamics, side_blocks, 64, h->s_defer, P, 1);
+      LAUNCH_LDS(3, k_collide<false>, B, 64, col::lds_bytes(N), st, P, 1);
+      LAUNCH(4, k_dynamics<false>, dyn_blocks, 64, st, P, 1);
     }
-    if (draw) launch_view(h, 7, B, h->s_defer, P, 0);
-    if (view_flags) hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, h->s_defer, P);     // ... of the resumed envs
-    (void)hipEventRecord(h->ev_join2, h->s_defer);
-    (void)hipEventRecord(h->ev_join, h->s_side);
-    P.role = 1;
+    P.use_vorder = 1;
+    if (draw) launch_view(h, 2, B, st, P, 0);
+    P.use_vorder = 0;
+    if (view_flags) hipLaunchKernelGGL(k_flags<false>, dim3(B * N), dim3(64), 0, st, P);
+    return;
   }
-  if (P.auto_reset) {   // envs re-spawned by pass 0 take the action-less first step of their new episode (:408)
-    LAUNCH_LDS(3, k_collide, B, 64, col::lds_bytes(N), st, P, 1);
-    LAUNCH(4, k_dynamics, dyn_blocks, 64, st, P, 1);
+  // Three chains that meet again at the end (k_list_chain.h: the list chains are one fused launch + their raster):
+  //   st      : collide(all) -+-> dynamics(main envs, 2 position sweeps) -+-> reset pass of the envs it re-spawned -> raster(main envs) -+
+  //   s_side  :               +-> chain(contact envs) -> their raster ----+-> bookkeeping of the main envs ----------------------------+
+  //   s_defer :                                                           +-> chain(resume the deferred envs) -> their raster ---------+
+  // Contact envs: a wavefront holding a touching car<->car pair takes 2-4x as long as the others.  Deferred envs: the
+  // few whose position loop is still iterating after 2 sweeps (a slow marginal crawl that would hold the whole main
+  // launch for up to 60).  The bookkeeping of the main envs (:446-495; k_flags.h, one wavefront per car) needs the poses
+  // only: it runs while the GPU is nearly idle (reset pass, start of the resume chain).  Tried and measured: closing the
+  // step after the raster (31 us on the critical path), beside the raster (fragments its wavefront slots: 134 -> 158 us),
+  // on a fourth stream (a fifth HIP stream slows every queue down).
+  P.defer_after = MCR_DEFER_AFTER; P.respawn_list = P.auto_reset ? 1 : 0; P.list_envs_per_block = MCR_SIDE_ENVS_PER_WAVE;
+  (void)hipEventRecord(h->ev_fork, st);
+  (void)hipStreamWaitEvent(h->s_side, h->ev_fork, 0);
+  P.role = 2;
+  LAUNCH_LDS(5, k_list_chain, lg_dyn, 64, col::lds_bytes(N), h->s_side, P, view_flags);
+  if (draw) launch_view(h, 6, B, h->s_side, P, 0);
+  P.role = 1;
+  LAUNCH(1, k_dynamics<false>, dyn_blocks, 64, st, P, 0);
+  (void)hipEventRecord(h->ev_fork2, st);
+  (void)hipStreamWaitEvent(h->s_defer, h->ev_fork2, 0);
+  (void)hipStreamWaitEvent(h->s_side, h->ev_fork2, 0);
+  P.role = 3;
+  LAUNCH_LDS(7, k_list_chain, lg_dyn, 64, col::lds_bytes(N), h->s_defer, P, view_flags);
+  if (draw) launch_view(h, 7, B, h->s_defer, P, 0);
+  (void)hipEventRecord(h->ev_join2, h->s_defer);
+  P.role = 1;
+  if (view_flags) hipLaunchKernelGGL(k_flags<false>, dim3(B * N), dim3(64), 0, h->s_side, P);
+  (void)hipEventRecord(h->ev_join, h->s_side);
+  if (P.auto_reset) {   // the envs the main dynamics re-spawned are in vorder too: the main raster draws them
+    P.role = 4; P.list_envs_per_block = 1;
+    LAUNCH_LDS(3, k_reset_list, lg_col, 64, col::lds_bytes(N), st, P);
+    P.role = 1; P.list_envs_per_block = MCR_SIDE_ENVS_PER_WAVE;
   }
   P.use_vorder = 1;
   if (draw) launch_view(h, 2, B, st, P, 0);
   P.use_vorder = 0;
-  if (h->split) {
-    (void)hipStreamWaitEvent(st, h->ev_join, 0);
-    (void)hipStreamWaitEvent(st, h->ev_join2, 0);
-  }
-  // The bookkeeping (:446-495; k_flags.h, one wavefront per car) of the main envs — of every env in single-stream mode —
-  // closes the step on the caller's stream.  Tried and measured: beside the raster on the side stream (fragments the
-  // raster's wavefront slots: 134 -> 158 us), behind the contact chain on the side stream (the step then waits for the
-  // longest contact chain), on a fourth stream beside the reset pass (a fifth HIP stream slows every queue down).
-  if (view_flags) {
-    P.role = h->split ? 1 : 0;
-    hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, st, P);
-  }
+  (void)hipStreamWaitEvent(st, h->ev_join, 0);
+  (void)hipStreamWaitEvent(st, h->ev_join2, 0);
 }
 
 extern "C" int mcr_reset(mcr_env* h, const uint8_t* d_env_mask, uint8_t* d_obs, void* stream) {

@@ -386,6 +386,20 @@ extern "C" int mcr_episode_generate(uint32_t* mt_track, int num_agents, int cw, 
       ++q;
     }
   }
+  // bounding boxes of the runs of MCR_QBLK consecutive road_poly entries (the raster skips the runs a view cannot see)
+  {
+    float* QK = (float*)(blob + MCR_OFF_QBLK);
+    for (int b = 0; b < MCR_QUAD_CAP / MCR_QBLK; ++b) {
+      float lox = MCR_MAXFLT, loy = MCR_MAXFLT, hix = -MCR_MAXFLT, hiy = -MCR_MAXFLT;
+      for (int e = b * MCR_QBLK; e < (b + 1) * MCR_QBLK && e < P; ++e)
+        for (int k = 0; k < 2; ++k) {
+          const float* v = (k ? QB : QA) + e * 4;
+          lox = fminf(lox, fminf(v[0], v[2])); hix = fmaxf(hix, fmaxf(v[0], v[2]));
+          loy = fminf(loy, fminf(v[1], v[3])); hiy = fmaxf(hiy, fmaxf(v[1], v[3]));
+        }
+      QK[b * 4 + 0] = lox; QK[b * 4 + 1] = loy; QK[b * 4 + 2] = hix; QK[b * 4 + 3] = hiy;
+    }
+  }
   // spawn poses (:366-406)
   const double pos_x = lap[0].x, pos_y = lap[0].y;
   for (int car = 0; car < num_agents; ++car) {

@@ -25,6 +25,9 @@ struct McrParams {
   int32_t* clist_next;          // the other buffer (steps alternate): its count is zeroed by this step's main k_dynamics
   int32_t split;                // k_collide pass 0 fills part/clist
   int32_t* dlist;               // [1+B] count + env ids deferred by the main k_dynamics (zeroed by k_collide pass 0)
+  int32_t* rlist;               // [1+B] count + env ids the main k_dynamics re-spawned in this step (zeroed by k_collide pass 0); filled when respawn_list
+  int32_t respawn_list;         // the host runs the main envs' reset pass as a list launch (role 4)
+  int32_t list_envs_per_block;  // list launches: envs a workgroup (= a wavefront) takes at a time, 1 .. MCR_SIDE_ENVS_PER_WAVE
   uint8_t* defer_state;         // [BN] per car: 0 keep iterating, 1 position loop solved, 2 failed at a fixed point
   double* stats;                // [2] rollout statistics accumulated on the device: episodes finished, sum of their returns over all agents
   unsigned long long* counters; // [4] diagnostics: 0 envs deferred, 1 envs resumed, 2 contact envs routed to the side stream
@@ -62,14 +65,15 @@ __device__ __forceinline__ int mcr_label_value(double reward) { return (reward >
 // 8 vertices (x0 y0 .. x7 y7) and slot header words live in carpoly_n: vertex count (0 = not drawn)
 #define MCR_CARPOLY_FLOATS (12 * 16 + 16)
 #define MCR_CARPOLY_NOFF (12 * 16)
-// Env handled by work slot `s` of a launch (slot = env index for roles 0/1, clist position for role 2); returns
+// Env handled by work slot `s` of a launch (slot = env index for roles 0/1; position in the contact / deferred / re-spawn
+// list for roles 2 / 3 / 4); returns
 // p.env0 + p.nenv ("no env") for slots that are not this launch's business.
 __device__ __forceinline__ int mcr_env_of_slot(const McrParams& p, int s) {
   const int end = p.env0 + p.nenv;
   if (s < 0) return end;
   if (p.role == 2) return s < p.clist[0] ? p.clist[1 + s] : end;
   if (p.role == 3) return s < p.dlist[0] ? p.dlist[1 + s] : end;
-  if (p.role == 4) { const int nc = p.clist[0]; return s < nc ? p.clist[1 + s] : (s - nc < p.dlist[0] ? p.dlist[1 + s - nc] : end); }
+  if (p.role == 4) return s < p.rlist[0] ? p.rlist[1 + s] : end;
   const int env = p.env0 + s;
   if (env >= end) return end;
   return (p.role == 1 && p.part[env]) ? end : env;
@@ -79,10 +83,16 @@ __device__ __forceinline__ int mcr_env_of_slot(const McrParams& p, int s) {
 // constraints (DYN_VC_POOL = MCR_SIDE_ENVS_PER_WAVE * MCR_CC_MAX) can never overflow, however the envs are packed.
 #define MCR_SIDE_ENVS_PER_WAVE 2
 #define MCR_DEFER_AFTER 2          // position sweeps the main dynamics launch grants an env before deferring it (99.86 % need 1)
-__device__ __forceinline__ int mcr_dyn_slot(const McrParams& p) {
+__device__ __forceinline__ int mcr_dyn_slot(const McrParams& p, int blk) {
   const int grp = (int)threadIdx.x / p.G;
-  if (p.role >= 2) return grp < MCR_SIDE_ENVS_PER_WAVE ? (int)blockIdx.x * MCR_SIDE_ENVS_PER_WAVE + grp : -1;
-  return ((int)blockIdx.x * 64 + (int)threadIdx.x) / p.G;
+  if (p.role >= 2) return grp < p.list_envs_per_block ? blk * p.list_envs_per_block + grp : -1;
+  return (blk * 64 + (int)threadIdx.x) / p.G;
 }
+// List launches (role >= 2: the contact / deferred envs, a few per step, how many only the device knows) run a small
+// grid whose workgroups walk the list: the (virtual) block indices blockIdx, blockIdx + gridDim, .. below this bound.
+// A grid sized for the worst case would queue thousands of empty workgroups behind the raster that saturates the LDS
+// of every CU.  Main launches have exactly one block index per workgroup.
+__device__ __forceinline__ int mcr_list_len(const McrParams& p) { return p.role == 2 ? p.clist[0] : p.role == 3 ? p.dlist[0] : p.role == 4 ? p.rlist[0] : 0; }
+__device__ __forceinline__ int mcr_virtual_blocks(const McrParams& p, int slots_per_block) { return (mcr_list_len(p) + slots_per_block - 1) / slots_per_block; }
 #define MCR_CC_MAX 24           // touching car<->car fixture pairs kept per env (warm start)
 #define MCR_CC_WORDS 20         // u32 words per stored manifold
