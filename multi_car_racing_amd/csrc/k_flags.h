@@ -34,10 +34,40 @@ __device__ __forceinline__ void flags_block(const McrParams& p, const int blk) {
   const uint32_t* __restrict__ QM = (const uint32_t*)(slot + MCR_OFF_QMETA);
   const double* __restrict__ TX = (const double*)(slot + MCR_OFF_TRACK_X); const double* __restrict__ TY = (const double*)(slot + MCR_OFF_TRACK_Y);
 
-  // pass 1 over road_poly: on-grass + f32 distance to every tile's track point (~ midpoint of the tile's leading edge)
+  // Only the road_poly blocks (runs of MCR_QBLK consecutive entries; boxes from the track generator, as in the raster)
+  // that can hold the nearest track point — or the car itself — are scanned.  Per block: a lower bound of the distance to
+  // anything in it (distance to the box) and, for full blocks (they hold at least 8 tiles, whose track point lies on the
+  // tile's leading edge, inside the box), an upper bound of the distance to its nearest track point (distance to the
+  // box's farthest corner).  A block whose lower bound exceeds the smallest upper bound cannot matter.
+  unsigned long long visit;
+  {
+    float4 bb = make_float4(1.0f, 1.0f, -1.0f, -1.0f);
+    if (lane < MCR_QUAD_CAP / MCR_QBLK) bb = ((const float4*)(slot + MCR_OFF_QBLK))[lane];
+    const bool nonempty = bb.x <= bb.z;
+    const float lx = fmaxf(fmaxf(bb.x - fpx, fpx - bb.z), 0.0f), ly = fmaxf(fmaxf(bb.y - fpy, fpy - bb.w), 0.0f);
+    const float hx = fmaxf(fabsf(fpx - bb.x), fabsf(fpx - bb.z)), hy = fmaxf(fabsf(fpy - bb.y), fabsf(fpy - bb.w));
+    const float lb2 = lx * lx + ly * ly;
+    float ub2 = (nonempty && (lane + 1) * MCR_QBLK <= P) ? hx * hx + hy * hy : MCR_MAXFLT;
+    for (int o = 32; o > 0; o >>= 1) ub2 = fminf(ub2, __shfl_xor(ub2, o));
+    const float reach = ub2 < 1e30f ? sqrtf(ub2) * (1.0f + 1e-5f) + 0.01f : 1e18f;
+    visit = __ballot(nonempty && lb2 <= reach * reach);
+  }
+  // the visited blocks' entries, four blocks at a time: lane -> entry q (or -1)
+  auto next_entries = [&](unsigned long long& m) -> int {
+    int b[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { b[g] = m ? (int)__builtin_ctzll(m) : -1; m &= m - 1ull; }
+    const int g = lane >> 4;
+    const int blk_ = g == 0 ? b[0] : g == 1 ? b[1] : g == 2 ? b[2] : b[3];
+    const int q = blk_ * MCR_QBLK + (lane & (MCR_QBLK - 1));
+    return (blk_ >= 0 && q < P) ? q : -1;
+  };
+  // pass 1: on-grass + f32 distance to every tile's track point (~ midpoint of the tile's leading edge)
   bool inside = false;
   float dmin = MCR_MAXFLT;
-  for (int q = lane; q < P; q += 64) {
+  for (unsigned long long m = visit; m;) {
+    const int q = next_entries(m);
+    if (q < 0) continue;
     const float4 a = QA[q], b = QB[q];
     const uint32_t meta = QM[q];
     const uint32_t tile1 = (meta >> 8) & 0x3ffu, owner1 = meta >> 18;
@@ -57,7 +87,9 @@ __device__ __forceinline__ void flags_block(const McrParams& p, const int blk) {
   const float band = sqrtf(dmin) * (1.0f + 1e-5f) + 2e-3f;
   const float thr = band * band;
   double bd = 1e300; int bi = 0x7fffffff;
-  for (int q = lane; q < P; q += 64) {
+  for (unsigned long long m = visit; m;) {
+    const int q = next_entries(m);
+    if (q < 0) continue;
     const uint32_t tile1 = (QM[q] >> 8) & 0x3ffu;
     if (!tile1) continue;
     const float4 a = QA[q];

@@ -462,7 +462,11 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
         const uint32_t c0 = kp[0], c1 = kp[1], c2 = kp[2], c3 = kp[3];
         uint3 w;
         w.x = __builtin_amdgcn_perm(c1, c0, 0x04020100u); w.y = __builtin_amdgcn_perm(c2, c1, 0x05040201u); w.z = __builtin_amdgcn_perm(c3, c2, 0x06050402u);
-        *(uint3*)(out + (size_t)g * 3) = w;
+        // streaming store: the frames of a step (226 MB at B = 4096, N = 2) are written once and read by nobody on the
+        // device — they must not evict the state the step's latency-bound chains live on from L2 / MALL
+        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+        u32x3 wv; wv.x = w.x; wv.y = w.y; wv.z = w.z;
+        __builtin_nontemporal_store(wv, (u32x3*)(out + (size_t)g * 3));
       }
     }
     PHASE_ACC(8);
