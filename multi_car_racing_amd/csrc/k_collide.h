@@ -327,17 +327,8 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   if (pass == 0 && p.split && lane == 0 && nn_final > 0) { p.part[env] = 1; p.clist[1 + atomicAdd(&p.clist[0], 1)] = env; atomicAdd(&p.counters[2], 1ull); }
 }
 
-// LIST: the launches of roles >= 2 — a small grid whose workgroups walk the device-side list (mcr_kernels.h); they are
-// short latency-bound chains beside a raster that fills every CU, so their wavefronts take issue priority.  The main
-// launch is one workgroup per env (a loop around the body costs the main kernel registers: two instantiations).
-template <bool LIST>
+// one workgroup per env (the list launches of roles >= 2 call collide_block from k_list_chain.h)
 __global__ __launch_bounds__(64) void k_collide(McrParams p, int pass) {
-  if (!LIST) {
-    if (pass == 0 && blockIdx.x == 0 && threadIdx.x == 0) { p.vcount[0] = 0; p.vcount[1] = 0; p.dlist[0] = 0; p.rlist[0] = 0; }     // refilled by k_dynamics
-    collide_block(p, pass, (int)blockIdx.x);
-  } else {
-    __builtin_amdgcn_s_setprio(3);
-    const int nb = mcr_virtual_blocks(p, 1);
-    for (int blk = blockIdx.x; blk < nb; blk += gridDim.x) { collide_block(p, pass, blk); __syncthreads(); }
-  }
+  if (pass == 0 && blockIdx.x == 0 && threadIdx.x == 0) { p.vcount[0] = 0; p.vcount[1] = 0; p.dlist[0] = 0; p.rlist[0] = 0; }     // refilled by k_dynamics
+  collide_block(p, pass, (int)blockIdx.x);
 }

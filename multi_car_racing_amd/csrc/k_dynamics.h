@@ -922,9 +922,10 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
       // one, so their workgroups go FIRST (front of vorder) and cannot end up as the launch's tail
       // (only the main launch fills the list: envs of the contact / resume launches are drawn by launches of their own, and
       // an append from those streams would race with the main raster launch that is reading the counts)
-      // A re-spawned env of the main launch: with respawn_list its reset pass is a list launch (role 4)
+      // A re-spawned env of the main launch: with respawn_list its reset pass and first observation are list launches
+      // (role 4) of their own, beside the main raster
       if (p.role < 2 && respawn && p.respawn_list) p.rlist[1 + atomicAdd(&p.rlist[0], 1)] = env;
-      if (p.role < 2 && (respawn || !(done && p.auto_reset))) {
+      else if (p.role < 2 && (respawn || !(done && p.auto_reset))) {
         const bool heavy = respawn || es.t + 1.0 / MCR_FPS < 1.0;
         if (heavy) p.vorder[atomicAdd(&p.vcount[0], 1)] = env;
         else p.vorder[p.B - 1 - atomicAdd(&p.vcount[1], 1)] = env;
@@ -1107,17 +1108,10 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
 
 }
 
-// LIST: the launches of roles >= 2, see k_collide
-template <bool LIST>
+// main launches (roles 0 / 1): 64 / G envs per wavefront (the list launches of roles >= 2 call dynamics_block from k_list_chain.h)
 __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
-  if (!LIST) {
-    if (p.role == 1 && mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) p.clist_next[0] = 0;   // every reader of it finished last step
-    dynamics_block(p, mode, (int)blockIdx.x);
-  } else {
-    __builtin_amdgcn_s_setprio(3);
-    const int nb = mcr_virtual_blocks(p, p.list_envs_per_block);
-    for (int blk = blockIdx.x; blk < nb; blk += gridDim.x) { dynamics_block(p, mode, blk); __syncthreads(); }
-  }
+  if (p.role == 1 && mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) p.clist_next[0] = 0;   // every reader of it finished last step
+  dynamics_block(p, mode, (int)blockIdx.x);
 }
 
 __global__ void k_mark_staged(McrParams p, const int32_t* __restrict__ ids, int n) {

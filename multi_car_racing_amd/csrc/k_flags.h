@@ -128,13 +128,5 @@ __device__ __forceinline__ void flags_block(const McrParams& p, const int blk) {
   p.caru[CU_FLAGS * BN + ci] = f;
 }
 
-// LIST: the launches of roles >= 2, see k_collide
-template <bool LIST>
-__global__ __launch_bounds__(64) void k_flags(McrParams p) {
-  if (!LIST) flags_block(p, (int)blockIdx.x);
-  else {
-    __builtin_amdgcn_s_setprio(3);
-    const int nb = mcr_list_len(p) * p.N;
-    for (int blk = blockIdx.x; blk < nb; blk += gridDim.x) flags_block(p, blk);
-  }
-}
+// one wavefront per car (the list launches of roles >= 2 call flags_block from k_list_chain.h)
+__global__ __launch_bounds__(64) void k_flags(McrParams p) { flags_block(p, (int)blockIdx.x); }

@@ -222,8 +222,8 @@ static void launch_reset(mcr_env* h, McrParams P, hipStream_t st) {
   const int dyn_blocks = (B * P.G + 63) / 64;
   P.split = 0; P.role = 0; P.use_vorder = 0;
   hipLaunchKernelGGL(k_install, dim3(dyn_blocks), dim3(64), 0, st, P);
-  LAUNCH_LDS(3, k_collide<false>, B, 64, col::lds_bytes(N), st, P, 1);
-  LAUNCH(4, k_dynamics<false>, dyn_blocks, 64, st, P, 1);
+  LAUNCH_LDS(3, k_collide, B, 64, col::lds_bytes(N), st, P, 1);
+  LAUNCH(4, k_dynamics, dyn_blocks, 64, st, P, 1);
   if (P.obs) launch_view(h, 2, B, st, P, 1);
 }
 
@@ -250,31 +250,29 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     P.clist = base + (size_t)(h->step_parity) * (B + 1); P.clist_next = base + (size_t)(h->step_parity ^ 1) * (B + 1);
     h->step_parity ^= 1;
   }
-  LAUNCH_LDS(0, k_collide<false>, B, 64, col::lds_bytes(N), st, P, 0);
+  LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), st, P, 0);
   P.split = 0;
   if (!h->split) {
     // single stream: collide -> dynamics -> reset pass of the re-spawned envs (:408) -> raster -> bookkeeping, all envs
-    LAUNCH(1, k_dynamics<false>, dyn_blocks, 64, st, P, 0);
+    LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 0);
     if (P.auto_reset) {
-      LAUNCH_LDS(3, k_collide<false>, B, 64, col::lds_bytes(N), st, P, 1);
-      LAUNCH(4, k_dynamics<false>, dyn_blocks, 64, st, P, 1);
+      LAUNCH_LDS(3, k_collide, B, 64, col::lds_bytes(N), st, P, 1);
+      LAUNCH(4, k_dynamics, dyn_blocks, 64, st, P, 1);
     }
     P.use_vorder = 1;
     if (draw) launch_view(h, 2, B, st, P, 0);
     P.use_vorder = 0;
-    if (view_flags) hipLaunchKernelGGL(k_flags<false>, dim3(B * N), dim3(64), 0, st, P);
+    if (view_flags) hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, st, P);
     return;
   }
-  // Three chains that meet again at the end (k_list_chain.h: the list chains are one fused launch + their raster):
-  //   st      : collide(all) -+-> dynamics(main envs, 2 position sweeps) -+-> reset pass of the envs it re-spawned -> raster(main envs) -+
-  //   s_side  :               +-> chain(contact envs) -> their raster ----+-> bookkeeping of the main envs ----------------------------+
-  //   s_defer :                                                           +-> chain(resume the deferred envs) -> their raster ---------+
+  // Three chains that meet again at the end (k_list_chain.h: a list chain is one fused launch + its raster):
+  //   st      : collide(all) -+-> dynamics(main envs, 2 position sweeps) -+-> bookkeeping(main envs) -> raster(main envs) ------+
+  //   s_side  :               +-> chain(contact envs) -> their raster ----+-> reset pass(re-spawned envs) -> their raster ------+
+  //   s_defer :                                                           +-> chain(resume the deferred envs) -> their raster --+
   // Contact envs: a wavefront holding a touching car<->car pair takes 2-4x as long as the others.  Deferred envs: the
   // few whose position loop is still iterating after 2 sweeps (a slow marginal crawl that would hold the whole main
-  // launch for up to 60).  The bookkeeping of the main envs (:446-495; k_flags.h, one wavefront per car) needs the poses
-  // only: it runs while the GPU is nearly idle (reset pass, start of the resume chain).  Tried and measured: closing the
-  // step after the raster (31 us on the critical path), beside the raster (fragments its wavefront slots: 134 -> 158 us),
-  // on a fourth stream (a fifth HIP stream slows every queue down).
+  // launch for up to 60).  Re-spawned envs (auto-reset, ~B/1000 per step): their reset pass would hold the raster of
+  // everybody else (they are not in the main raster's list, see k_dynamics).
   P.defer_after = MCR_DEFER_AFTER; P.respawn_list = P.auto_reset ? 1 : 0; P.list_envs_per_block = MCR_SIDE_ENVS_PER_WAVE;
   (void)hipEventRecord(h->ev_fork, st);
   (void)hipStreamWaitEvent(h->s_side, h->ev_fork, 0);
@@ -282,7 +280,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   LAUNCH_LDS(5, k_list_chain, lg_dyn, 64, col::lds_bytes(N), h->s_side, P, view_flags);
   if (draw) launch_view(h, 6, B, h->s_side, P, 0);
   P.role = 1;
-  LAUNCH(1, k_dynamics<false>, dyn_blocks, 64, st, P, 0);
+  LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 0);
   (void)hipEventRecord(h->ev_fork2, st);
   (void)hipStreamWaitEvent(h->s_defer, h->ev_fork2, 0);
   (void)hipStreamWaitEvent(h->s_side, h->ev_fork2, 0);
@@ -291,13 +289,17 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   if (draw) launch_view(h, 7, B, h->s_defer, P, 0);
   (void)hipEventRecord(h->ev_join2, h->s_defer);
   P.role = 1;
-  if (view_flags) hipLaunchKernelGGL(k_flags<false>, dim3(B * N), dim3(64), 0, h->s_side, P);
-  (void)hipEventRecord(h->ev_join, h->s_side);
-  if (P.auto_reset) {   // the envs the main dynamics re-spawned are in vorder too: the main raster draws them
-    P.role = 4; P.list_envs_per_block = 1;
-    LAUNCH_LDS(3, k_reset_list, lg_col, 64, col::lds_bytes(N), st, P);
+  if (P.auto_reset) {   // the envs the main dynamics re-spawned: reset pass (:408, ~50 us of serial solver work) and first observation
+    P.role = 4; P.list_envs_per_block = 1;                         // one env per workgroup: they run side by side
+    LAUNCH_LDS(3, k_reset_list, lg_col, 64, col::lds_bytes(N), h->s_side, P);
+    if (draw) launch_view(h, 4, B, h->s_side, P, 0);
     P.role = 1; P.list_envs_per_block = MCR_SIDE_ENVS_PER_WAVE;
   }
+  (void)hipEventRecord(h->ev_join, h->s_side);
+  // The bookkeeping of the main envs (:446-495; k_flags.h, one wavefront per car) needs the poses only.  It runs right
+  // before the raster, and those ~16 us are what the list chains — forked off at the same moment — need to get their
+  // wavefronts placed: a chain that starts beside a raster that already fills every CU runs 2-3x slower (measured).
+  if (view_flags) hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, st, P);
   P.use_vorder = 1;
   if (draw) launch_view(h, 2, B, st, P, 0);
   P.use_vorder = 0;
