@@ -1,9 +1,9 @@
 """Summarise gpurun_out/prof_<round>/ into profiles/<round>_*.md|json (tracked).
 
 A step of the default configuration issues several launches of the same kernel (main chain, contact side stream,
-reset passes), so launches are labelled by their position in the step: on the caller's queue the order is
-collide dynamics collide(reset) dynamics(reset) view [collide dynamics view](late reset of contact envs);
-on the side queue dynamics view; on the third queue dynamics(resume) view."""
+resume stream), so launches are labelled by queue and position in the step: on the caller's queue collide, dynamics,
+bookkeeping, view; on the side queue chain(contact envs), view, reset pass(re-spawned envs), view; on the third queue
+chain(resume), view."""
 import json, os, sys
 import pandas as pd
 
@@ -19,55 +19,51 @@ except Exception as e:
     b = {}
     lines.append(f"(bench_plain missing: {e})\n")
 
+KERNELS = ("k_collide", "k_dynamics", "k_view", "k_flags", "k_list_chain", "k_reset_list", "k_install", "fillBuffer", "copyBuffer")
 def kname(s):
-    for k in ("k_collide", "k_dynamics", "k_view", "k_install", "fillBuffer", "copyBuffer"):
+    for k in KERNELS:
         if k in s: return k
     return s[:60]
 
-MAIN_ORDER = {"k_collide": ["collide", "collide (reset pass)", "collide (late reset, contact envs)"],
-              "k_dynamics": ["dynamics (main envs)", "dynamics (reset pass)", "dynamics (late reset, contact envs)"],
-              "k_view": ["view (main envs)", "view (late reset, contact envs)"]}
-SIDE_ORDER = {"k_dynamics": ["dynamics (contact envs, side stream)"], "k_view": ["view (contact envs, side stream)"]}
-DEFER_ORDER = {"k_dynamics": ["dynamics (resume of deferred envs, third stream)"], "k_view": ["view (deferred envs, third stream)"]}
+# launches of a step by queue, in launch order (mcr_hip.hip: launch_step)
+MAIN_ORDER = {"k_collide": ["collide (all envs)"], "k_dynamics": ["dynamics (main envs)"], "k_flags": ["bookkeeping (main envs)"], "k_view": ["view (main envs)"]}
+SIDE_ORDER = {"k_list_chain": ["chain (contact envs, side stream)"], "k_reset_list": ["reset pass (re-spawned envs, side stream)"],
+              "k_view": ["view (contact envs, side stream)", "view (re-spawned envs, side stream)"]}
+DEFER_ORDER = {"k_list_chain": ["chain (resume of deferred envs, third stream)"], "k_view": ["view (deferred envs, third stream)"]}
+STEP_KERNELS = ("k_collide", "k_dynamics", "k_view", "k_flags", "k_list_chain", "k_reset_list")
 
 def label(df, order_col):
-    """adds column Label for the launches of the last STEPS steps.  A step is three k_collide launches on the caller's
-    queue (pass 0, reset pass, late reset pass of the contact envs); steps are counted back from the end of the run
-    (the pre-roll's masked resets add launches of their own further up)."""
+    """adds column Label for the launches of the last STEPS steps.  A step starts with its k_collide launch on the
+    caller's queue; steps are counted back from the end of the run (reset() and the pre-roll's masked resets add launches
+    of their own further up)."""
     df = df.sort_values(order_col).reset_index(drop=True)
     df["K"] = df["Kernel_Name"].map(kname)
     df["Label"] = None
     col = df.index[df.K == "k_collide"].tolist()
     if not col:
         return df
-    qcount = df.loc[col, "Queue_Id"].value_counts()
-    main_q = qcount.index[0]
-    # of the two internal queues, the contact side stream is the one whose k_dynamics launches take longer in total
-    dq = df[(df.K == "k_dynamics") & (df.Queue_Id != main_q)]
-    side_q = None
-    if len(dq):
-        if "End_Timestamp" in dq.columns: side_q = (dq.End_Timestamp - dq.Start_Timestamp).groupby(dq.Queue_Id).sum().idxmax()
-        else: side_q = dq.Queue_Id.value_counts().index[0]
+    main_q = df.loc[col, "Queue_Id"].value_counts().index[0]
+    rq = df[df.K == "k_reset_list"].Queue_Id.value_counts()
+    side_q = rq.index[0] if len(rq) else None                 # the side stream is the one that carries the reset pass
     col = [i for i in col if df.at[i, "Queue_Id"] == main_q]
-    if len(col) < 3 * STEPS:
+    if len(col) < STEPS:
         return df
-    starts = col[-3 * STEPS::3] + [len(df)]
+    starts = col[-STEPS:] + [len(df)]
     for a, e in zip(starts[:-1], starts[1:]):
         seen = {}
         for i in range(a, e):
             k = df.at[i, "K"]
-            if k not in ("k_collide", "k_dynamics", "k_view"): continue
+            if k not in STEP_KERNELS: continue
             q = df.at[i, "Queue_Id"]
-            on_main = q == main_q
             key = (k, q); n = seen.get(key, 0); seen[key] = n + 1
-            names = (MAIN_ORDER if on_main else (SIDE_ORDER if q == side_q else DEFER_ORDER)).get(k, [])
+            names = (MAIN_ORDER if q == main_q else (SIDE_ORDER if q == side_q else DEFER_ORDER)).get(k, [])
             df.at[i, "Label"] = names[n] if n < len(names) else f"{k} #{n}"
     return df
 
 st = pd.read_csv(f"{src}/stats/s_kernel_stats.csv")
 st["Kernel"] = st["Name"].map(kname)
 lines.append("## `--kernel-trace --stats` (kernel_stats.csv, whole process incl. pre-roll; every launch of a kernel pooled)\n")
-lines.append(st[["Kernel", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"]].head(8).to_markdown(index=False) + "\n")
+lines.append(st[["Kernel", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"]].head(9).to_markdown(index=False) + "\n")
 kt = label(pd.read_csv(f"{src}/stats/s_kernel_trace.csv"), "Start_Timestamp")
 kt["us"] = (kt["End_Timestamp"] - kt["Start_Timestamp"]) / 1e3
 g = kt[kt.Label.notna()].groupby("Label").us.agg(["count", "mean", "median", "min", "max"]).round(1)
@@ -81,18 +77,18 @@ for name, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     c = label(pd.read_csv(f"{src}/{name}/p_counter_collection.csv"), "Dispatch_Id")
     gsel = c[(c.Label == "view (main envs)") & (c.Counter_Name == ctr)]
     traffic[ctr] = float(gsel.Counter_Value.mean())
-    side = c[(c.Label == "view (contact envs, side stream)") & (c.Counter_Name == ctr)]
-    traffic[ctr + "_side"] = float(side.Counter_Value.mean()) if len(side) else 0.0
+    side = c[(c.K == "k_view") & c.Label.notna() & (c.Label != "view (main envs)") & (c.Counter_Name == ctr)]
+    traffic[ctr + "_side"] = float(side.Counter_Value.sum() / STEPS) if len(side) else 0.0
 # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB; MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reads exactly 1/2 of
 # the bytes of a wide coalesced stream -> x2; WRITE_SIZE is taken as reported (uncalibrated).
 fetch_b = (traffic["FETCH_SIZE"] + traffic["FETCH_SIZE_side"]) * 1024 * 2
 write_b = (traffic["WRITE_SIZE"] + traffic["WRITE_SIZE_side"]) * 1024
-lines.append("\n## HBM traffic of the raster (PMC, separate passes; main launch + the side stream's launch for the contact envs)\n")
+lines.append("\n## HBM traffic of the raster (PMC, separate passes; main launch + the list launches for the contact / deferred / re-spawned envs)\n")
 lines.append(f"FETCH_SIZE mean {traffic['FETCH_SIZE']:.0f} + {traffic['FETCH_SIZE_side']:.0f} KB/step (x2 gfx950 correction -> {fetch_b/1e6:.1f} MB), WRITE_SIZE mean {traffic['WRITE_SIZE']:.0f} + {traffic['WRITE_SIZE_side']:.0f} KB/step ({write_b/1e6:.1f} MB)\n")
 alg = b.get("roofline", {}).get("algorithmic_bytes_per_launch")
 lines.append(f"HBM bytes per step ~ {(fetch_b+write_b)/1e6:.1f} MB vs algorithmic {alg/1e6 if alg else float('nan'):.1f} MB\n")
 json.dump({"hbm_bytes_per_launch": fetch_b + write_b, "fetch_bytes_corrected": fetch_b, "write_bytes": write_b,
-           "raw_kb": traffic, "round": R, "note": "FETCH_SIZE x2 (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; main raster launch + side-stream raster launch of a step"},
+           "raw_kb": traffic, "round": R, "note": "FETCH_SIZE x2 (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; main raster launch + the list launches (contact / deferred / re-spawned envs) of a step"},
           open("profiles/view_traffic.json", "w"))
 sq = label(pd.read_csv(f"{src}/pmc_sq/p_counter_collection.csv"), "Dispatch_Id")
 sq = sq[sq.Label.notna()]
