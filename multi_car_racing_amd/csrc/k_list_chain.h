@@ -42,3 +42,11 @@ __global__ __launch_bounds__(64) void k_list_chain(McrParams p, const int with_f
     __syncthreads();
   }
 }
+
+// the bookkeeping of a list's cars as a launch of its own (one wavefront per car at a time): what the chains use when an
+// env has more than two cars — inside k_list_chain the cars of a block take their turns one after the other
+__global__ __launch_bounds__(64) void k_flags_list(McrParams p) {
+  __builtin_amdgcn_s_setprio(3);
+  const int nb = mcr_list_len(p) * p.N;
+  for (int blk = blockIdx.x; blk < nb; blk += gridDim.x) flags_block(p, blk);
+}

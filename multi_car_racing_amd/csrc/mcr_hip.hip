@@ -276,8 +276,13 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   P.defer_after = MCR_DEFER_AFTER; P.respawn_list = P.auto_reset ? 1 : 0; P.list_envs_per_block = MCR_SIDE_ENVS_PER_WAVE;
   (void)hipEventRecord(h->ev_fork, st);
   (void)hipStreamWaitEvent(h->s_side, h->ev_fork, 0);
+  // bookkeeping of a chain's cars: fused into the chain for N <= 2 (2 envs x N cars take their turns on one wavefront),
+  // a list launch of its own beyond that
+  const int fuse_flags = (view_flags && N <= 2) ? 1 : 0;
+  const int lg_flags = std::min(B * N, 4 * MCR_LIST_GRID);
   P.role = 2;
-  LAUNCH_LDS(5, k_list_chain, lg_dyn, 64, col::lds_bytes(N), h->s_side, P, view_flags);
+  LAUNCH_LDS(5, k_list_chain, lg_dyn, 64, col::lds_bytes(N), h->s_side, P, fuse_flags);
+  if (view_flags && !fuse_flags) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, h->s_side, P);
   if (draw) launch_view(h, 6, B, h->s_side, P, 0);
   P.role = 1;
   LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 0);
@@ -285,17 +290,21 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   (void)hipStreamWaitEvent(h->s_defer, h->ev_fork2, 0);
   (void)hipStreamWaitEvent(h->s_side, h->ev_fork2, 0);
   P.role = 3;
-  LAUNCH_LDS(7, k_list_chain, lg_dyn, 64, col::lds_bytes(N), h->s_defer, P, view_flags);
+  LAUNCH_LDS(7, k_list_chain, lg_dyn, 64, col::lds_bytes(N), h->s_defer, P, fuse_flags);
+  if (view_flags && !fuse_flags) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, h->s_defer, P);
   if (draw) launch_view(h, 7, B, h->s_defer, P, 0);
-  (void)hipEventRecord(h->ev_join2, h->s_defer);
   P.role = 1;
   if (P.auto_reset) {   // the envs the main dynamics re-spawned: reset pass (:408, ~50 us of serial solver work) and first observation
+    // on the stream whose chain is the shorter one: with two cars per env the contact list is nearly always empty (chain:
+    // 6 us median), with more cars it is the long one (N = 8: 600 us) and the resume chain (90-140 us) the short one
+    hipStream_t sr = N <= 2 ? h->s_side : h->s_defer;
     P.role = 4; P.list_envs_per_block = 1;                         // one env per workgroup: they run side by side
-    LAUNCH_LDS(3, k_reset_list, lg_col, 64, col::lds_bytes(N), h->s_side, P);
-    if (draw) launch_view(h, 4, B, h->s_side, P, 0);
+    LAUNCH_LDS(3, k_reset_list, lg_col, 64, col::lds_bytes(N), sr, P);
+    if (draw) launch_view(h, 4, B, sr, P, 0);
     P.role = 1; P.list_envs_per_block = MCR_SIDE_ENVS_PER_WAVE;
   }
   (void)hipEventRecord(h->ev_join, h->s_side);
+  (void)hipEventRecord(h->ev_join2, h->s_defer);
   // The bookkeeping of the main envs (:446-495; k_flags.h, one wavefront per car) needs the poses only.  It runs right
   // before the raster, and those ~16 us are what the list chains — forked off at the same moment — need to get their
   // wavefronts placed: a chain that starts beside a raster that already fills every CU runs 2-3x slower (measured).
