@@ -49,6 +49,9 @@ typedef struct mcr_config {
                               * or a position loop still iterating after 2 sweeps) run it + their raster on internal streams, concurrently
                               * with the others; results are bit-identical in both modes */
   double h_ratio;            /* :159 */
+  int32_t skid_particles;    /* 1: keep the skid particles of gym car_dynamics.Car (step(): "Skid trace", _create_particle) so that
+                              * mcr_render can draw them (Car.draw(viewer, True), :564); 0: not tracked (observations never show them) */
+  int32_t reserved0;
 } mcr_config;
 
 const char* mcr_last_error(void);

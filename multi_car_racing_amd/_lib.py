@@ -17,7 +17,8 @@ class Config(ctypes.Structure):
     _fields_ = [("num_envs", ctypes.c_int32), ("num_agents", ctypes.c_int32), ("device", ctypes.c_int32),
                 ("obs_enabled", ctypes.c_int32), ("auto_reset", ctypes.c_int32), ("backwards_flag", ctypes.c_int32),
                 ("use_ego_color", ctypes.c_int32), ("car_contacts", ctypes.c_int32), ("max_episode_steps", ctypes.c_int32),
-                ("num_streams", ctypes.c_int32), ("h_ratio", ctypes.c_double)]
+                ("num_streams", ctypes.c_int32), ("h_ratio", ctypes.c_double),
+                ("skid_particles", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
 
 
 # every symbol include/mcr.h declares: name -> (restype, argtypes)

@@ -501,6 +501,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
     const double WHEEL_RAD = MCR_WHEEL_R * MCR_SIZE;
     const double KF = 205000 * MCR_SIZE * MCR_SIZE;
     float fx[4], fy[4];
+    uint32_t skid = 0;                                           // bit k: wheel k skids ("Skid trace" of Car.step, particles only)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       double wsteer = (k < 2) ? steer : 0.0;
@@ -531,6 +532,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
       double p_force = -vs;
       f_force *= KF; p_force *= KF;
       double force = sqrt(f_force * f_force + p_force * p_force);
+      if (fabs(force) > 2.0 * friction_limit) skid |= 1u << k;
       if (fabs(force) > friction_limit) {
         f_force /= force; p_force /= force;
         force = friction_limit;
@@ -540,6 +542,10 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
       omega[k] = om;
       fx[k] = (float)(p_force * side0 + f_force * forw0);
       fy[k] = (float)(p_force * side1 + f_force * forw1);
+    }
+    if (p.particles) {                                           // w.position: the wheel bodies have their origin at the centre
+      uint32_t* pc = p.particles + (size_t)ci * MCR_PART_WORDS;
+      for (int k = 0; k < 4; ++k) mcr_particle_step(pc, k, ((skid >> k) & 1u) != 0u, !((onroad >> (4 + k)) & 1u), b[k + 1].cx, b[k + 1].cy);
     }
 
     // ---- b2Island::Solve: integrate velocities
@@ -956,6 +962,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
     for (int k = 0; k < 4; ++k) { J[k].ix = J[k].iy = J[k].iz = J[k].im = 0.0f; J[k].limit = 0; omega[k] = 0; phase[k] = 0; }
     gas[0] = gas[1] = 0; steer = 0; brake = 0; onroad = 0;
     reward = 0; prev_reward = 0; tvc = 0; flags = 0; epret = 0;
+    if (p.particles) mcr_particles_clear(p.particles + (size_t)ci * MCR_PART_WORDS);
     p.caru[CU_ONROAD * BN + ci] = 0;
     p.caru[CU_TVC * BN + ci] = 0;
   }
@@ -1153,6 +1160,7 @@ __global__ __launch_bounds__(64) void k_install(McrParams p) {
   p.card[(CD_GAS + 0) * BN + ci] = 0.0; p.card[(CD_GAS + 1) * BN + ci] = 0.0; p.card[CD_STEER * BN + ci] = 0.0; p.card[CD_BRAKE * BN + ci] = 0.0;
   p.card[CD_REWARD * BN + ci] = 0.0; p.card[CD_PREV_REWARD * BN + ci] = 0.0; p.card[CD_EPRET * BN + ci] = 0.0;
   p.caru[CU_LIMIT * BN + ci] = 0; p.caru[CU_ONROAD * BN + ci] = 0; p.caru[CU_TVC * BN + ci] = 0; p.caru[CU_FLAGS * BN + ci] = 0;
+  if (p.particles) mcr_particles_clear(p.particles + (size_t)ci * MCR_PART_WORDS);
   if (agent == 0) {
     McrEnvState* E = &p.env[env];
     E->slot = es.slot ^ 1; E->staged_ready = 0; E->consumed = es.consumed + 1; E->resetting = 1; E->just_reset = 1; E->active = 1; E->frozen = 0;

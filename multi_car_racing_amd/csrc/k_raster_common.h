@@ -12,7 +12,7 @@ namespace view {
 
 // palette (one index per pixel until the write-out)
 enum { PAL_BLACK = 0, PAL_GRASS0, PAL_GRASS1, PAL_ROAD0, PAL_ROAD1, PAL_ROAD2, PAL_WHITE, PAL_RED255, PAL_WHEELWHITE,
-       PAL_CAR0, PAL_BLUE255 = PAL_CAR0 + 8, PAL_PURPLE, PAL_GREEN255, PAL_COUNT };
+       PAL_CAR0, PAL_BLUE255 = PAL_CAR0 + 8, PAL_PURPLE, PAL_GREEN255, PAL_MUD, PAL_COUNT };
 
 __device__ __forceinline__ uint32_t rgb(uint32_t r, uint32_t g, uint32_t b) { return r | (g << 8) | (b << 16); }
 // GL float colour -> unorm8: round-to-nearest of c*255 evaluated on the f32 value
@@ -32,6 +32,7 @@ __device__ __forceinline__ uint32_t palette_rgb(int i) {
     case PAL_BLUE255: return rgb(0, 0, 255);
     case PAL_PURPLE: return rgb(c8(0.2), 0, 255);
     case PAL_GREEN255: return rgb(0, 255, 0);
+    case PAL_MUD: return rgb(c8(0.4), c8(0.4), 0);           // gym car_dynamics MUD_COLOR (skid particles on grass; on road: WHEEL_COLOR = black)
     default: break;
   }
   if (i >= PAL_CAR0 && i < PAL_CAR0 + 8) {   // CAR_COLORS (:67-70)
@@ -48,7 +49,7 @@ __device__ __forceinline__ uint32_t palette_rgb(int i) {
 static __device__ const uint32_t PALETTE_RGB[32] = {
     0x000000u, 0x66cc66u, 0x66e566u, 0x666666u, 0x696969u, 0x6b6b6bu, 0xffffffu, 0x0000ffu, 0x4d4d4du,
     0x0000ccu, 0xcc0000u, 0x00cc00u, 0xcccc00u, 0xccccccu, 0x000000u, 0xcc00ccu, 0x00ccccu,
-    0xff0000u, 0xff0033u, 0x00ff00u, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    0xff0000u, 0xff0033u, 0x00ff00u, 0x006666u, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 // oriented edge equations of a convex polygon given pixel-space vertices; returns false if degenerate
 __device__ __forceinline__ bool edge_setup(const float* px, const float* py, int n, float* e /*[n*3]*/) {

@@ -3,8 +3,8 @@
 // a straightforward tile rasteriser (16x16 pixels per workgroup, road quads culled per tile in chunks of 256 through
 // LDS, painter's order == highest draw index wins) that reuses the camera, HUD rectangles and car polygons the last
 // k_dynamics left in HBM.  Same sampling rule as k_view: pixel centres, inside <=> all oriented edge functions >= 0.
-// The score label (:665-666) is the build's bitmap font (k_raster_common.h).  NOT reproduced: skid particles
-// (Car.draw(viewer, True), :564 — GL wide lines).
+// The score label (:665-666) is the build's bitmap font (k_raster_common.h).  Skid particles (Car.draw(viewer, True), :564)
+// are drawn when the handle tracks them (mcr_config.skid_particles): 5-pixel-wide rectangles around the segments.
 #pragma once
 #include "k_raster_common.h"
 
@@ -126,13 +126,65 @@ __global__ __launch_bounds__(256) void k_render_frame(McrParams p, int env, int 
     cinfo[k] = info;
   }
   __syncthreads();
-  for (int k = 0; k < N * 12; ++k) {
-    const uint32_t ci2 = cinfo[k];
-    if (!ci2) continue;
-    const float4* r = &car8[k * 6];
-    if (inside4(r[0], r[1], r[2], cx, cy) && inside4(r[3], r[4], r[5], cx, cy)) best = (int)(((uint32_t)(CAR_KEY + k) << 5) | (ci2 & 31u));
-  }
   if (best >= 0) col = (uint32_t)best & 31u;
+  // Car.draw per car, in car order (:559-564): its skid particles first (draw_particles = mode != 'state_pixels'; gym draws
+  // each as a GL_LINE_STRIP of width 5 — here every segment is the 5-pixel-wide rectangle around it, no caps or joins:
+  // GL's own wide-line rasterisation is implementation-defined), then its wheels and hull
+  for (int c = 0; c < N; ++c) {
+    if (p.particles) {
+      const uint32_t* __restrict__ pc = p.particles + (size_t)(env * N + c) * MCR_PART_WORDS;
+      const int created = (int)pc[0], first = created > MCR_PART_MAX ? created - MCR_PART_MAX : 0;
+      const int nseg = (created - first) * (MCR_PART_PTS - 1);
+      int pbest = -1;
+      for (int base = 0; base < nseg; base += 256) {
+        if (tid == 0) ecount = 0;
+        __syncthreads();
+        const int sidx = base + tid;
+        bool keep = false; float e[12]; uint32_t key = 0;
+        if (sidx < nseg) {
+          const int ord = sidx / (MCR_PART_PTS - 1), i = sidx - ord * (MCR_PART_PTS - 1);
+          const int sl = (first + ord) % MCR_PART_MAX;
+          const uint32_t info = pc[17 + sl];
+          if (i + 1 < (int)(info & 255u)) {
+            const uint32_t* pt = pc + MCR_PART_HDR + (sl * MCR_PART_PTS + i) * 2;
+            const float ax = __uint_as_float(pt[0]), ay = __uint_as_float(pt[1]), bx = __uint_as_float(pt[2]), by = __uint_as_float(pt[3]);
+            const float pax = __builtin_fmaf(m00, ax, __builtin_fmaf(m01, ay, ctx)), pay = __builtin_fmaf(m10, ax, __builtin_fmaf(m11, ay, cty));
+            const float pbx = __builtin_fmaf(m00, bx, __builtin_fmaf(m01, by, ctx)), pby = __builtin_fmaf(m10, bx, __builtin_fmaf(m11, by, cty));
+            const float dx = pbx - pax, dy = pby - pay, len = sqrtf(dx * dx + dy * dy);
+            if (len > 0.0f) {
+              const float nx = -dy / len * 2.5f, ny = dx / len * 2.5f;
+              const float qx[4] = {pax + nx, pax - nx, pbx - nx, pbx + nx}, qy[4] = {pay + ny, pay - ny, pby - ny, pby + ny};
+              const float x0 = fminf(fminf(qx[0], qx[1]), fminf(qx[2], qx[3])), x1 = fmaxf(fmaxf(qx[0], qx[1]), fmaxf(qx[2], qx[3]));
+              const float y0 = fminf(fminf(qy[0], qy[1]), fminf(qy[2], qy[3])), y1 = fmaxf(fmaxf(qy[0], qy[1]), fmaxf(qy[2], qy[3]));
+              if (!(x0 > bx1 || x1 < bx0 || y0 > by1 || y1 < by0) && edge_setup(qx, qy, 4, e)) {
+                keep = true;
+                key = ((uint32_t)sidx << 5) | (((info >> 8) & 1u) ? PAL_MUD : PAL_BLACK);
+              }
+            }
+          }
+        }
+        const unsigned long long mask = __ballot(keep);
+        if (mask) {
+          int at = 0;
+          if (lane == 0) at = atomicAdd(&ecount, __popcll(mask));
+          at = __shfl(at, 0) + __popcll(mask & ((1ull << lane) - 1ull));
+          if (keep) { ent[at][0] = make_float4(e[0], e[1], e[2], e[3]); ent[at][1] = make_float4(e[4], e[5], e[6], e[7]); ent[at][2] = make_float4(e[8], e[9], e[10], e[11]); ekey[at] = key; }
+        }
+        __syncthreads();
+        const int n = ecount;
+        for (int s2 = 0; s2 < n; ++s2)
+          if (inside4(ent[s2][0], ent[s2][1], ent[s2][2], cx, cy) && (int)ekey[s2] > pbest) pbest = (int)ekey[s2];
+        __syncthreads();
+      }
+      if (pbest >= 0) col = (uint32_t)pbest & 31u;
+    }
+    for (int k = c * 12; k < c * 12 + 12; ++k) {
+      const uint32_t ci2 = cinfo[k];
+      if (!ci2) continue;
+      const float4* r = &car8[k * 6];
+      if (inside4(r[0], r[1], r[2], cx, cy) && inside4(r[3], r[4], r[5], cx, cy)) col = ci2 & 31u;
+    }
+  }
   // render_indicators (:634-674) in window space: bar of 5h = 1/8 of the height, gauges, backwards flag
   {
     const float kx = (float)W / 1000.0f, ky = (float)H / 800.0f;

@@ -91,6 +91,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   const size_t o_viewp = carve(sizeof(float) * MCR_VIEWP_FLOATS * BN);
   const size_t o_carpoly = carve(sizeof(float) * MCR_CARPOLY_FLOATS * BN);
   const size_t o_vscratch = carve(sizeof(unsigned long long) * 16 * BN);
+  const size_t o_particles = carve(cfg->skid_particles ? sizeof(uint32_t) * MCR_PART_WORDS * BN : 0);
   const size_t o_slots = carve((size_t)B * 2 * MCR_SLOT_BYTES);
   h->slab_bytes = off;
   if (hipMalloc(&h->slab, off) != hipSuccess) { g_err = "hipMalloc failed"; delete h; return MCR_ERR_HIP; }
@@ -107,6 +108,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   P.part = base + o_part; P.dlist = (int32_t*)(base + o_dlist); P.rlist = (int32_t*)(base + o_rlist); P.defer_state = base + o_dstate; P.counters = (unsigned long long*)(base + o_counters); P.stats = (double*)(base + o_stats);
   h->stage_ids = (int32_t*)(base + o_stage_ids); P.vcount = (int32_t*)(base + o_vorder); P.vorder = P.vcount + 2; P.dbg_stamps = (unsigned long long*)(base + o_stamps); P.clist = (int32_t*)(base + o_clist);
   P.carpoly = (float*)(base + o_carpoly);
+  P.particles = cfg->skid_particles ? (uint32_t*)(base + o_particles) : nullptr;
   P.auto_reset = cfg->auto_reset; P.max_steps = cfg->max_episode_steps; P.car_contacts = cfg->car_contacts;
   P.backwards_flag = cfg->backwards_flag; P.use_ego_color = cfg->use_ego_color; P.h_ratio = cfg->h_ratio;
   McrShapes S; mcr_build_shapes(&S);
@@ -503,8 +505,8 @@ extern "C" int mcr_get_env_state(mcr_env* h, double* reward, int32_t* tvc, uint8
 
 // ---------------------------------------------------------------------------- full state snapshot / restore
 namespace {
-struct BlobLayout { size_t carf, card, caru, es, touch, tflags, cc, viewp, carpoly, slot, total; };
-BlobLayout blob_layout(int N) {
+struct BlobLayout { size_t carf, card, caru, es, touch, tflags, cc, viewp, carpoly, slot, particles, total; };
+BlobLayout blob_layout(int N, bool with_particles) {
   BlobLayout L; size_t o = 16;                                         // header: magic, N, reserved
   L.carf = o; o += sizeof(float) * CF_COUNT * N;
   o = (o + 7) & ~(size_t)7; L.card = o; o += sizeof(double) * CD_COUNT * N;
@@ -516,13 +518,14 @@ BlobLayout blob_layout(int N) {
   L.viewp = o; o += sizeof(float) * MCR_VIEWP_FLOATS * N;
   L.carpoly = o; o += sizeof(float) * MCR_CARPOLY_FLOATS * N;
   o = (o + 15) & ~(size_t)15; L.slot = o; o += MCR_SLOT_BYTES;
+  L.particles = o; if (with_particles) o += sizeof(uint32_t) * MCR_PART_WORDS * N;
   L.total = o;
   return L;
 }
 const uint32_t BLOB_MAGIC = 0x3152434du;   // "MCR1"
 }  // namespace
 
-extern "C" size_t mcr_state_blob_bytes(const mcr_env* h) { return h ? blob_layout(h->P.N).total : 0; }
+extern "C" size_t mcr_state_blob_bytes(const mcr_env* h) { return h ? blob_layout(h->P.N, h->P.particles != nullptr).total : 0; }
 
 extern "C" int mcr_get_state_blob(mcr_env* h, int env, void* blob_out) {
   if (!h || !blob_out) { g_err = "null argument"; return MCR_ERR_ARG; }
@@ -530,7 +533,7 @@ extern "C" int mcr_get_state_blob(mcr_env* h, int env, void* blob_out) {
   if (!h->any_reset) { g_err = "state snapshot before reset()"; return MCR_ERR_STATE; }
   HIPCHK(hipDeviceSynchronize());
   const McrParams& P = h->P; const int N = P.N; const size_t BN = P.BN;
-  const BlobLayout L = blob_layout(N);
+  const BlobLayout L = blob_layout(N, P.particles != nullptr);
   uint8_t* b = (uint8_t*)blob_out;
   memset(b, 0, L.total);
   ((uint32_t*)b)[0] = BLOB_MAGIC; ((uint32_t*)b)[1] = (uint32_t)N;
@@ -547,6 +550,7 @@ extern "C" int mcr_get_state_blob(mcr_env* h, int env, void* blob_out) {
   HIPCHK(hipMemcpy(b + L.viewp, P.viewp + (size_t)env * N * MCR_VIEWP_FLOATS, sizeof(float) * MCR_VIEWP_FLOATS * N, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(b + L.carpoly, P.carpoly + (size_t)env * N * MCR_CARPOLY_FLOATS, sizeof(float) * MCR_CARPOLY_FLOATS * N, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(b + L.slot, P.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES, MCR_SLOT_BYTES, hipMemcpyDeviceToHost));
+  if (P.particles) HIPCHK(hipMemcpy(b + L.particles, P.particles + (size_t)env * N * MCR_PART_WORDS, sizeof(uint32_t) * MCR_PART_WORDS * N, hipMemcpyDeviceToHost));
   return MCR_OK;
 }
 
@@ -557,7 +561,7 @@ extern "C" int mcr_set_state_blob(mcr_env* h, int env, const void* blob) {
   const uint8_t* b = (const uint8_t*)blob;
   if (((const uint32_t*)b)[0] != BLOB_MAGIC || ((const uint32_t*)b)[1] != (uint32_t)N) { g_err = "not a state blob of this num_agents"; return MCR_ERR_ARG; }
   HIPCHK(hipDeviceSynchronize());
-  const BlobLayout L = blob_layout(N);
+  const BlobLayout L = blob_layout(N, P.particles != nullptr);
   HIPCHK(hipMemcpy2D(P.carf + (size_t)env * N, sizeof(float) * BN, b + L.carf, sizeof(float) * N, sizeof(float) * N, CF_COUNT, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy2D(P.card + (size_t)env * N, sizeof(double) * BN, b + L.card, sizeof(double) * N, sizeof(double) * N, CD_COUNT, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy2D(P.caru + (size_t)env * N, sizeof(uint32_t) * BN, b + L.caru, sizeof(uint32_t) * N, sizeof(uint32_t) * N, CU_COUNT, hipMemcpyHostToDevice));
@@ -575,6 +579,7 @@ extern "C" int mcr_set_state_blob(mcr_env* h, int env, const void* blob) {
   HIPCHK(hipMemcpy(P.viewp + (size_t)env * N * MCR_VIEWP_FLOATS, b + L.viewp, sizeof(float) * MCR_VIEWP_FLOATS * N, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(P.carpoly + (size_t)env * N * MCR_CARPOLY_FLOATS, b + L.carpoly, sizeof(float) * MCR_CARPOLY_FLOATS * N, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(P.slots + ((size_t)env * 2 + cur.slot) * MCR_SLOT_BYTES, b + L.slot, MCR_SLOT_BYTES, hipMemcpyHostToDevice));
+  if (P.particles) HIPCHK(hipMemcpy(P.particles + (size_t)env * N * MCR_PART_WORDS, b + L.particles, sizeof(uint32_t) * MCR_PART_WORDS * N, hipMemcpyHostToDevice));
   h->any_reset = true;
   return MCR_OK;
 }

@@ -26,6 +26,7 @@ struct McrParams {
   int32_t split;                // k_collide pass 0 fills part/clist
   int32_t* dlist;               // [1+B] count + env ids deferred by the main k_dynamics (zeroed by k_collide pass 0)
   int32_t* rlist;               // [1+B] count + env ids the main k_dynamics re-spawned in this step (zeroed by k_collide pass 0); filled when respawn_list
+  uint32_t* particles;          // [B*N][MCR_PART_WORDS] skid particles of gym Car.step / _create_particle (drawn by render('rgb_array') only); null: not tracked
   int32_t respawn_list;         // the host runs the main envs' reset pass as a list launch (role 4)
   int32_t list_envs_per_block;  // list launches: envs a workgroup (= a wavefront) takes at a time, 1 .. MCR_SIDE_ENVS_PER_WAVE
   uint8_t* defer_state;         // [BN] per car: 0 keep iterating, 1 position loop solved, 2 failed at a fixed point
@@ -94,5 +95,49 @@ __device__ __forceinline__ int mcr_dyn_slot(const McrParams& p, int blk) {
 // of every CU.  Main launches have exactly one block index per workgroup.
 __device__ __forceinline__ int mcr_list_len(const McrParams& p) { return p.role == 2 ? p.clist[0] : p.role == 3 ? p.dlist[0] : p.role == 4 ? p.rlist[0] : 0; }
 __device__ __forceinline__ int mcr_virtual_blocks(const McrParams& p, int slots_per_block) { return (mcr_list_len(p) + slots_per_block - 1) / slots_per_block; }
+// Skid particles (gym car_dynamics.Car: step() item "Skid trace", _create_particle, draw(viewer, True); call site
+// multi_car_racing.py:564).  Per car: a ring of the last MCR_PART_MAX particles, each a polyline of up to MCR_PART_PTS
+// wheel positions; per wheel: skid_start and the particle it is extending.  Words of a car's block:
+//   [0] particles created so far (particle id = creation index, ring slot = id % MCR_PART_MAX, alive: id >= created - MAX)
+//   [1..4] wheel k: id of w.skid_particle (-1: None)   [5..8] wheel k: len(w.skid_particle.poly) | grass << 8 | (skid_start is not None) << 9
+//   [9..16] wheel k: skid_start x, y (f32 bits)          [17..46] ring slot: points | grass << 8
+//   [48 ..] ring slot s, point i: x, y (f32 bits) at 48 + (s * MCR_PART_PTS + i) * 2
+#define MCR_PART_MAX 30
+#define MCR_PART_PTS 30
+#define MCR_PART_HDR 48
+#define MCR_PART_WORDS (MCR_PART_HDR + MCR_PART_MAX * MCR_PART_PTS * 2)
+__device__ __forceinline__ void mcr_particles_clear(uint32_t* pc) {          // Car.__init__: particles = [], wheels without skid state
+  pc[0] = 0u;
+  for (int k = 0; k < 4; ++k) { pc[1 + k] = 0xffffffffu; pc[5 + k] = 0u; }
+  for (int s = 0; s < MCR_PART_MAX; ++s) pc[17 + s] = 0u;
+}
+// one wheel's "Skid trace" block of Car.step: `skid` = abs(force) > 2 * friction_limit, `grass` = the wheel touches no tile
+__device__ __noinline__ void mcr_particle_step(uint32_t* pc, int k, bool skid, bool grass, float x, float y) {
+  if (!skid) { pc[1 + k] = 0xffffffffu; pc[5 + k] = 0u; return; }           // w.skid_start = None; w.skid_particle = None
+  const int cur = (int)pc[1 + k];
+  const uint32_t st = pc[5 + k];
+  const int len = (int)(st & 255u);
+  if (cur >= 0 && (((st >> 8) & 1u) != 0u) == grass && len < MCR_PART_PTS) {  // extend the wheel's particle (drawn only while it is among the last 30)
+    const int created = (int)pc[0];
+    if (cur >= created - MCR_PART_MAX) {
+      const int sl = cur % MCR_PART_MAX;
+      pc[MCR_PART_HDR + (sl * MCR_PART_PTS + len) * 2] = __float_as_uint(x); pc[MCR_PART_HDR + (sl * MCR_PART_PTS + len) * 2 + 1] = __float_as_uint(y);
+      pc[17 + sl] = (uint32_t)(len + 1) | (grass ? 256u : 0u);
+    }
+    pc[5 + k] = (st & ~255u) | (uint32_t)(len + 1);
+  } else if (!((st >> 9) & 1u)) {                                            // w.skid_start = w.position
+    pc[9 + 2 * k] = __float_as_uint(x); pc[10 + 2 * k] = __float_as_uint(y);
+    pc[5 + k] = st | 512u;
+  } else {                                                                   // _create_particle(w.skid_start, w.position, grass)
+    const int id = (int)pc[0];
+    const int sl = id % MCR_PART_MAX;
+    pc[MCR_PART_HDR + sl * MCR_PART_PTS * 2] = pc[9 + 2 * k]; pc[MCR_PART_HDR + sl * MCR_PART_PTS * 2 + 1] = pc[10 + 2 * k];
+    pc[MCR_PART_HDR + sl * MCR_PART_PTS * 2 + 2] = __float_as_uint(x); pc[MCR_PART_HDR + sl * MCR_PART_PTS * 2 + 3] = __float_as_uint(y);
+    pc[17 + sl] = 2u | (grass ? 256u : 0u);
+    pc[0] = (uint32_t)(id + 1);
+    pc[1 + k] = (uint32_t)id;
+    pc[5 + k] = 2u | (grass ? 256u : 0u);                                    // skid_start = None
+  }
+}
 #define MCR_CC_MAX 24           // touching car<->car fixture pairs kept per env (warm start)
 #define MCR_CC_WORDS 20         // u32 words per stored manifold

@@ -78,7 +78,7 @@ class MultiCarRacing:
         self._dev = torch.device("cuda", device)
         torch.cuda.set_device(self._dev)
         cfg = _lib.Config(1, self.num_agents, device, 1, 0, int(bool(backwards_flag)), int(bool(use_ego_color)),
-                          int(bool(car_contacts)), 0, 0, float(h_ratio))
+                          int(bool(car_contacts)), 0, 0, float(h_ratio), 1, 0)   # skid particles on: render("rgb_array") draws them
         self._h = ctypes.c_void_p()
         _lib.check(self.L.mcr_create(ctypes.byref(cfg), ctypes.byref(self._h)), "mcr_create")
         N = self.num_agents

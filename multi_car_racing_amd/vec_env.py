@@ -48,7 +48,8 @@ class VecMultiCarRacing:
     def __init__(self, num_envs, num_agents=2, device=None, seed=0, env_offset=0, direction="CCW",
                  use_random_direction=True, backwards_flag=True, h_ratio=0.25, use_ego_color=False,
                  obs=True, auto_reset=True, max_episode_steps=1000, car_contacts=True,
-                 gen_threads=None, async_refill=True, streams=None, refill_lag=8, world_size=1, graph=None):
+                 gen_threads=None, async_refill=True, streams=None, refill_lag=8, world_size=1, graph=None,
+                 skid_particles=False):
         if not torch.cuda.is_available():
             raise _lib.McrError("VecMultiCarRacing needs a HIP device: the step path has no CPU fallback")
         self.L = _lib.load()
@@ -75,7 +76,7 @@ class VecMultiCarRacing:
         self.hold_refills = False     # tests: withhold staging to exercise the freeze/thaw path
         cfg = _lib.Config(self.B, self.N, self.device.index or 0, int(self.obs_enabled), int(self.auto_reset),
                           int(backwards_flag), int(use_ego_color), int(car_contacts), int(max_episode_steps), int(streams),
-                          float(h_ratio))
+                          float(h_ratio), int(bool(skid_particles)), 0)
         self.h = ctypes.c_void_p()
         _lib.check(self.L.mcr_create(ctypes.byref(cfg), ctypes.byref(self.h)), "mcr_create")
         if graph is None:             # hipGraph replay of the step: measured r02 at B=4096 — 0.433 vs 0.435 ms per step, i.e. the gaps

@@ -343,7 +343,7 @@ class OracleEnv:
         return obs, amb
 
     def render_size(self, width, height):
-        """render('rgb_array')-style frame of the CURRENT state at width x height (no skid particles, no score label);
+        """render('rgb_array')-style frame of the CURRENT state at width x height (with skid particles and score label);
         returns (frames [N,H,W,3], ambiguity mask [N,H,W])."""
         obs = np.zeros((self.N, height, width, 3), np.uint8)
         amb = np.zeros((self.N, height, width), np.uint8)

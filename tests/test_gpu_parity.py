@@ -339,12 +339,61 @@ def test_side_stream_is_bit_identical_to_single_stream(torch_cuda, B, N):
     a1.close(); a2.close()
 
 
+def test_rgb_array_skid_particles_match_oracle(torch_cuda, oracle):
+    """Car.draw(viewer, True) (:564): the skid particles of gym's Car.step ("Skid trace": skid_start, _create_particle,
+    30 points per particle, the last 30 particles per car, road / mud colour) drawn into render('rgb_array') frames.
+    Full throttle then locked brakes with the wheels turned, first on the road, then on the grass; a masked reset in
+    between (new Car: no particles).  Exact outside the oracle's ambiguity mask at 600x400 and 133x77."""
+    torch = torch_cuda
+    B, N, seed = 2, 2, 33
+    env = _make(B, N, seed, contacts=True, skid_particles=True, auto_reset=True); env.reset()
+    plain = _make(B, N, seed, contacts=True, auto_reset=True); plain.reset()   # same rollout, particles not tracked
+    streams, orcs = [], []
+    for e in range(B):
+        sd = (seed + e) % 2 ** 32
+        tr, gr = np.random.RandomState(sd), np.random.RandomState((sd + 2 ** 31) % 2 ** 32)
+        o = oracle.OracleEnv(N, car_contacts=True); o.reset(oracle.new_episode(N, tr, gr, use_random_direction=False))
+        streams.append((tr, gr)); orcs.append(o)
+    rng = np.random.RandomState(3)
+    differs = 0; mud = 0
+    for k in range(260):
+        a = np.zeros((B, N, 3), np.float32)
+        ph = k % 130
+        if ph < 45: a[..., 1] = 1.0                                       # accelerate along the track
+        elif ph < 70: a[..., 0] = 0.6 if k < 130 else -0.6; a[..., 2] = 0.9; a[..., 1] = 1.0   # lock the brakes while turning
+        else: a[..., 1] = 1.0; a[..., 0] = 0.8 * np.sign(np.sin(0.3 * k))  # slalom under power: off the road, skids on grass
+        a[1] = np.clip(a[1] + rng.uniform(-0.1, 0.1, (N, 3)).astype(np.float32), [-1, 0, 0], [1, 1, 1])
+        ta = torch.from_numpy(a).cuda()
+        _, _, done, _ = env.step(ta); plain.step(ta)
+        assert not bool(done.any()), "the scripted rollout is not meant to end an episode"
+        for e, o in enumerate(orcs):
+            o.step(a[e], render=False)
+        if k == 140:                                                      # reset(): new cars, empty particle lists
+            mask = torch.tensor([1, 0], dtype=torch.uint8, device="cuda")
+            env.reset_envs(mask); plain.reset_envs(mask)
+            orcs[0].reset(oracle.new_episode(N, *streams[0], use_random_direction=False))
+        if k in (30, 69, 100, 129, 141, 200, 259):
+            for (w, h) in ((600, 400), (133, 77)):
+                for e, o in enumerate(orcs):
+                    got = env.render_rgb(e, w, h).cpu().numpy()
+                    want, amb = o.render_size(w, h)
+                    bad = ((got != want).any(-1) & (amb == 0)).sum()
+                    assert bad == 0, f"step {k} env {e} {w}x{h}: {bad} unambiguous pixels differ"
+                    assert ((got != want).any(-1)).sum() <= 0.004 * N * w * h
+                    if w == 600:
+                        differs += int((got != plain.render_rgb(e, w, h).cpu().numpy()).any())
+                        mud += int(((got[..., 0] == 102) & (got[..., 1] == 102) & (got[..., 2] == 0)).sum())
+    assert differs >= 4, "the rollout drew no skid particles"
+    assert mud > 0, "no particle on grass (MUD_COLOR) was drawn"
+    env.close(); plain.close()
+
+
 def test_rgb_array_render_matches_oracle(torch_cuda, oracle):
     """render('rgb_array') (:573-604, 600x400 viewport) and an odd-sized viewport: exact outside the oracle's ambiguity
     mask during the zoom-in, mid-episode, with touched tiles, the backwards flag and ego colours."""
     torch = torch_cuda
     B, N, seed = 2, 3, 21
-    env = _make(B, N, seed, contacts=True, use_ego_color=True); env.reset()
+    env = _make(B, N, seed, contacts=True, use_ego_color=True, skid_particles=True); env.reset()   # particles: part of rgb_array frames (:564)
     orcs = _oracles(oracle, B, N, seed, contacts=True, use_ego_color=True)
     rng = np.random.RandomState(12)
     checked = 0
