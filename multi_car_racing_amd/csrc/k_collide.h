@@ -180,10 +180,31 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
     ncand = 0;
     __syncthreads();
   };
-  for (int base = 0; base < T; base += 64) {
-    const int t = base + lane;
+  // Only the blocks of MCR_TBLK consecutive tiles (boxes from the track generator) that a car's box meets can hold a
+  // new contact, and only those that held a touching tile after the last pass can lose one: the pass looks at the union
+  // (typically 1-3 of ~18 blocks) instead of every tile of the track.
+  uint32_t visit;
+  {
+    float4 kb = make_float4(1.0f, 1.0f, -1.0f, -1.0f);
+    if (lane < MCR_TILE_CAP / MCR_TBLK) kb = ((const float4*)(slot + MCR_OFF_TBLK))[lane];
+    bool near = false;
+    for (int c = 0; c < N; ++c) near = near || !(kb.x > cbox[c][2] || kb.z < cbox[c][0] || kb.y > cbox[c][3] || kb.w < cbox[c][1]);
+    visit = (uint32_t)__ballot(near && kb.x <= kb.z) | (pass == 1 ? 0u : es.touch_blocks);
+  }
+  // the visited blocks' tiles, four blocks at a time: lane -> tile t (or -1)
+  auto next_tiles = [&](uint32_t& m) -> int {
+    int b[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { b[g] = m ? (int)__builtin_ctz(m) : -1; m &= m - 1u; }
+    const int g = lane >> 4;
+    const int kb = g == 0 ? b[0] : g == 1 ? b[1] : g == 2 ? b[2] : b[3];
+    const int t = kb * MCR_TBLK + (lane & (MCR_TBLK - 1));
+    return (kb >= 0 && t < T) ? t : -1;
+  };
+  for (uint32_t vm = visit; vm;) {
+    const int t = next_tiles(vm);
     float4 bb = make_float4(MCR_MAXFLT, MCR_MAXFLT, -MCR_MAXFLT, -MCR_MAXFLT);
-    if (t < T) bb = TAABB[t];
+    if (t >= 0) bb = TAABB[t];
     for (int c = 0; c < N; ++c) {
       const bool hit = !(bb.x > cbox[c][2] || bb.z < cbox[c][0] || bb.y > cbox[c][3] || bb.w < cbox[c][1]);
       const unsigned long long m = __ballot(hit);
@@ -197,10 +218,10 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   flush();
 
   // ---- phase C: per-tile contact state, begin events, reward replay (lane = tile)
-  uint32_t or_bits = 0;
-  for (int base = 0; base < T; base += 64) {
-    const int t = base + lane;
-    const bool valid = t < T;
+  uint32_t or_bits = 0, new_blocks = 0;
+  for (uint32_t vm = visit; vm;) {
+    const int t = next_tiles(vm);
+    const bool valid = t >= 0;
     uint32_t newbits = 0;
     uint32_t old = 0; uint32_t fl = 0;
     if (valid) {
@@ -228,7 +249,10 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
     }
     if (valid) { touch[t] = newbits; tflags[t] = (uint16_t)fl; }
     or_bits |= newbits;
+    if (newbits) new_blocks |= 1u << (t / MCR_TBLK);
   }
+  for (int o = 1; o < 64; o <<= 1) new_blocks |= (uint32_t)__shfl_xor((int)new_blocks, o);
+  if (lane == 0) p.env[env].touch_blocks = new_blocks;
   for (int o = 1; o < 64; o <<= 1) or_bits |= (uint32_t)__shfl_xor((int)or_bits, o);
   if (lane < N) {
     const int ci = env * N + lane;

@@ -73,7 +73,9 @@ struct McrSlotHeader {
 #define MCR_OFF_TCNT (MCR_OFF_TNB + 16 * MCR_TILE_CAP)        // u32    [TILE_CAP]  hull vertex count (3|4) | kerb<<8
 #define MCR_QBLK 16                                           // road_poly entries per culling block of the raster
 #define MCR_OFF_QBLK (MCR_OFF_TCNT + 4 * MCR_TILE_CAP)        // float4 [QUAD_CAP / QBLK]  lo.xy hi.xy of each run of QBLK road_poly entries (empty: lo > hi)
-#define MCR_SLOT_BYTES (MCR_OFF_QBLK + 16 * (MCR_QUAD_CAP / MCR_QBLK))
+#define MCR_TBLK 16                                           // tiles per culling block of the contact pass
+#define MCR_OFF_TBLK (MCR_OFF_QBLK + 16 * (MCR_QUAD_CAP / MCR_QBLK))   // float4 [TILE_CAP / TBLK]  lo.xy hi.xy of each run of TBLK tile sensor AABBs (empty: lo > hi)
+#define MCR_SLOT_BYTES (MCR_OFF_TBLK + 16 * (MCR_TILE_CAP / MCR_TBLK))
 
 // quad colour ids (u8 RGB after the GL float->unorm8 conversion)
 enum { MCR_COL_ROAD0 = 0, MCR_COL_ROAD1 = 1, MCR_COL_ROAD2 = 2, MCR_COL_KERB_WHITE = 3, MCR_COL_KERB_RED = 4 };
@@ -118,6 +120,8 @@ struct McrEnvState {
   int32_t resetting;       // episode installed; the action-less step of reset() (:408) is still pending
   int32_t just_reset;      // the obs being produced is a first observation (a7 bookkeeping is skipped, :435)
   int32_t frozen;          // auto-reset found no staged episode when this env finished: inactive until the host stages one (then it thaws)
+  uint32_t touch_blocks;   // bit b: some tile of block b (MCR_TBLK tiles) had a wheel on it after the last contact pass (k_collide looks at those + the ones near a car)
+  int32_t pad0;
 };
 
 // fixtures of one car in body-local coordinates (host builds them with its b2PolygonShape::Set

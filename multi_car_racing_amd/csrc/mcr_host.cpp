@@ -400,6 +400,17 @@ extern "C" int mcr_episode_generate(uint32_t* mt_track, int num_agents, int cw, 
       QK[b * 4 + 0] = lox; QK[b * 4 + 1] = loy; QK[b * 4 + 2] = hix; QK[b * 4 + 3] = hiy;
     }
   }
+  // ... and of the runs of MCR_TBLK consecutive tile sensor AABBs (the contact pass skips the runs no car is near)
+  {
+    float* TK = (float*)(blob + MCR_OFF_TBLK);
+    for (int b = 0; b < MCR_TILE_CAP / MCR_TBLK; ++b) {
+      float lox = MCR_MAXFLT, loy = MCR_MAXFLT, hix = -MCR_MAXFLT, hiy = -MCR_MAXFLT;
+      for (int t = b * MCR_TBLK; t < (b + 1) * MCR_TBLK && t < T; ++t) {
+        lox = fminf(lox, TA[t * 4 + 0]); loy = fminf(loy, TA[t * 4 + 1]); hix = fmaxf(hix, TA[t * 4 + 2]); hiy = fmaxf(hiy, TA[t * 4 + 3]);
+      }
+      TK[b * 4 + 0] = lox; TK[b * 4 + 1] = loy; TK[b * 4 + 2] = hix; TK[b * 4 + 3] = hiy;
+    }
+  }
   // spawn poses (:366-406)
   const double pos_x = lap[0].x, pos_y = lap[0].y;
   for (int car = 0; car < num_agents; ++car) {
