@@ -4,7 +4,8 @@ import os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "_lib", "libmcr_hip.so")
-SOURCES = ["mcr_hip.hip", "mcr_host.cpp"]
+# translation units and their extra flags (mcr_view.hip explains why the raster is built without the SLP vectoriser)
+SOURCES = [("mcr_hip.hip", []), ("mcr_view.hip", ["-fno-slp-vectorize"]), ("mcr_host.cpp", [])]
 
 
 def deps():
@@ -14,7 +15,7 @@ def deps():
     return out + [os.path.join(HERE, "..", "include", "mcr.h")]
 
 # -ffp-contract=off: host (x86-64) and gfx950 must round identically (numerics)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-value"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value"]
 
 
 def needs_build():
@@ -29,7 +30,20 @@ def build(force=False, verbose=False):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    objdir = os.path.join(os.path.dirname(LIB), "obj")
+    os.makedirs(objdir, exist_ok=True)
+    objs, procs = [], []
+    for src, extra in SOURCES:                       # the translation units compile side by side
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc] + FLAGS + extra + ["-c", "-o", obj, os.path.join(CSRC, src)]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

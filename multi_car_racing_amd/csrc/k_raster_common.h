@@ -154,7 +154,8 @@ __device__ inline bool point_in_road_poly_f64(const uint8_t* __restrict__ slot, 
     X[0] = x1 - TW * c1; Y[0] = y1 - TW * s1; X[1] = x1 + TW * c1; Y[1] = y1 + TW * s1;
     X[2] = x2 + TW * c2; Y[2] = y2 + TW * s2; X[3] = x2 - TW * c2; Y[3] = y2 - TW * s2;
   } else {
-    const double side = dyn::np_sign(TB[u] - TB[t]);
+    const double db = TB[u] - TB[t];
+    const double side = db > 0.0 ? 1.0 : (db < 0.0 ? -1.0 : 0.0);          // np.sign
     const double w0 = side * TW, w1 = side * (TW + TBW);
     X[0] = x1 + w0 * c1; Y[0] = y1 + w0 * s1; X[1] = x1 + w1 * c1; Y[1] = y1 + w1 * s1;
     X[2] = x2 + w1 * c2; Y[2] = y2 + w1 * s2; X[3] = x2 + w0 * c2; Y[3] = y2 + w0 * s2;

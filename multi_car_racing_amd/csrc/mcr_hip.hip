@@ -4,7 +4,7 @@
 #include "mcr_kernels.h"
 #include "k_dynamics.h"
 #include "k_collide.h"
-#include "k_view.h"
+#include "k_raster_common.h"
 #include "k_flags.h"
 #include "k_list_chain.h"
 #include "k_render.h"
@@ -207,15 +207,18 @@ static hipEvent_t get_event(mcr_env* h) {
     if (tm_) { (void)hipEventRecord(tl_.b, st); h->pending.push_back(tl_); }                   \
   } while (0)
 
+void mcr_view_launch(int variant, int grid, hipStream_t st, const McrParams& P, unsigned long long* stamps, int only_just_reset);   // mcr_view.hip
 // raster launch (k_view.h).  Main launches: one workgroup per work slot.  List launches (role >= 2): MCR_LIST_GRID
 // persistent workgroups that walk the list (lane k of a wavefront holds a workgroup's k-th env, so never fewer than
 // slots / 64 workgroups).
 #define MCR_LIST_GRID 128
 static int list_grid(int slots) { return std::min(slots, std::max(MCR_LIST_GRID, (slots + 63) / 64)); }
 static void launch_view(mcr_env* h, int kid, int slots, hipStream_t st, const McrParams& P, int only_just_reset) {
-  if (P.role >= 2) { LAUNCH(kid, (k_view<false, true>), list_grid(slots), VIEW_THREADS, st, P, h->view_stamps, only_just_reset); }
-  else if (P.debug & 32) { LAUNCH(kid, (k_view<true, false>), slots, VIEW_THREADS, st, P, h->view_stamps, only_just_reset); }
-  else { LAUNCH(kid, (k_view<false, false>), slots, VIEW_THREADS, st, P, h->view_stamps, only_just_reset); }
+  TimedLaunch tl; const bool tm = (h->timing >> kid) & 1;
+  if (tm) { tl.id = kid; tl.a = get_event(h); tl.b = get_event(h); (void)hipEventRecord(tl.a, st); }
+  if (P.role >= 2) mcr_view_launch(2, list_grid(slots), st, P, h->view_stamps, only_just_reset);
+  else mcr_view_launch((P.debug & 32) ? 1 : 0, slots, st, P, h->view_stamps, only_just_reset);
+  if (tm) { (void)hipEventRecord(tl.b, st); h->pending.push_back(tl); }
 }
 
 // reset(): install -> collide(1) -> dynamics(1) -> view, in order on one stream

@@ -1,0 +1,15 @@
+// mcr_view.hip — the raster kernel (k_view.h) as a translation unit of its own: it is built with -fno-slp-vectorize.
+// The SLP vectoriser pairs independent f32 operations into v_pk_* instructions, which on gfx950 issue at 0.55x the rate of
+// the scalar forms (profiles/r02_ubench_issue_rates.txt) and need their operands in adjacent registers: for the raster
+// that costs 6 VGPRs it does not have (168 + 40 B of scratch vs 162 and none) and 5 us per launch.  The rigid-body
+// kernels keep the default (k_dynamics is 7 us FASTER with the packed forms: fewer instructions on a single wavefront
+// per SIMD).  build.py carries the per-file flags.
+#include "mcr_kernels.h"
+#include "k_view.h"
+
+// variant: 0 main launch, 1 main launch with the per-phase clocks (debug bit 5), 2 list launch (persistent workgroups)
+void mcr_view_launch(int variant, int grid, hipStream_t st, const McrParams& P, unsigned long long* stamps, int only_just_reset) {
+  if (variant == 2) hipLaunchKernelGGL((k_view<false, true>), dim3(grid), dim3(VIEW_THREADS), 0, st, P, stamps, only_just_reset);
+  else if (variant == 1) hipLaunchKernelGGL((k_view<true, false>), dim3(grid), dim3(VIEW_THREADS), 0, st, P, stamps, only_just_reset);
+  else hipLaunchKernelGGL((k_view<false, false>), dim3(grid), dim3(VIEW_THREADS), 0, st, P, stamps, only_just_reset);
+}
