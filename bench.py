@@ -138,16 +138,21 @@ def main():
     env = ShardedVecEnv(B * world, N, seed=0, rank=rank, world_size=world, device=dev, obs=bool(args.obs),
                         auto_reset=True, use_random_direction=True, streams=args.streams, graph=bool(args.graph))
     env.reset()
-    # synthetic actions, generated ON THE DEVICE every step by a counter-based stream keyed (seed, global env, agent, t)
-    # (SURVEY 8d): i.i.d. steer~U(-1,1), gas~U(0,1), brake~U(0,1); one 3 us kernel inside the timed region
+    # synthetic actions, generated ON THE DEVICE by a counter-based stream keyed (seed, global env, agent, t):
+    # i.i.d. steer~U(-1,1), gas~U(0,1), brake~U(0,1); one small kernel per ACT_BLOCK steps inside the timed region (the
+    # stream is a pure function of t, so a block of steps can be drawn at once; two buffers: the GPU may still be
+    # reading the previous block when the host enqueues the next one — same stream, so no hazard, but kept simple)
     g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
-    act = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+    ACT_BLOCK = 16
+    act = [torch.empty((ACT_BLOCK, B, N, 3), dtype=torch.float32, device=dev) for _ in range(2)]
     tstep = [0]
 
     def next_actions():
-        env.env.synth_actions(tstep[0], seed=args.action_seed, out=act)
-        tstep[0] += 1
-        return act
+        t = tstep[0]; tstep[0] += 1
+        blk, j = divmod(t, ACT_BLOCK)
+        if j == 0:
+            env.env.synth_actions(t, seed=args.action_seed, out=act[blk & 1], steps=ACT_BLOCK)
+        return act[blk & 1][j]
     # Steady state before anything is timed: a real rollout has its episodes ending at different steps, not all
     # B TimeLimits expiring in the same step (which would put B host track generations into one burst).  One
     # un-timed TimeLimit period in which every env is reset once, at a step drawn without replacement, leaves the
@@ -217,9 +222,9 @@ def main():
     if args.obs and nl[2] > 0:
         avg_ms = ms[2] / nl[2]
         # the timed launch is the main raster launch: envs routed to the internal streams (car<->car contact, deferred
-        # position loops; ~17 of 4096 per step) are drawn by small launches of their own and do not count here
+        # position loops, re-spawns; ~21 of 4096 per step) are drawn by small launches of their own and do not count here
         ctr1 = env.env.debug_counters()
-        off_main = float((ctr1[0] - ctr0[0]) + (ctr1[2] - ctr0[2])) / K
+        off_main = (float((ctr1[0] - ctr0[0]) + (ctr1[2] - ctr0[2])) + float(episodes)) / K   # deferred + contact + re-spawned envs of this rank
         main_envs = max(B - off_main, 1.0)
         achieved = bytes_per_env_step * main_envs / (avg_ms * 1e-3) / 1e9
         # HBM bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE need runs of their own:

@@ -158,6 +158,8 @@ int mcr_set_state_blob(mcr_env* h, int env, const void* blob);
  * bounds, multi_car_racing.py:162-165).  Device version writes d_actions [B,N,3] f32 on `stream`; the host twin produces
  * the same values for the CPU baseline. */
 int mcr_synth_actions(mcr_env* h, float* d_actions, uint64_t seed, uint32_t t, uint32_t env_offset, void* stream);
+/* the same stream for steps t0 .. t0 + nsteps - 1 in one launch: d_actions [nsteps][num_envs][num_agents][3] */
+int mcr_synth_actions_block(mcr_env* h, float* d_actions, uint64_t seed, uint32_t t0, int nsteps, uint32_t env_offset, void* stream);
 void mcr_synth_actions_host(float* out, int num_envs, int num_agents, uint64_t seed, uint32_t t, uint32_t env_offset);
 
 /* ---- instrumentation for bench.py: HIP-event timing of the kernels enqueued by mcr_step, recorded on the

@@ -62,6 +62,7 @@ SYMBOLS = {
     "mcr_get_state_blob": (_i, [_vp, _i, _vp]),
     "mcr_set_state_blob": (_i, [_vp, _i, _vp]),
     "mcr_synth_actions": (_i, [_vp, _vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _vp]),
+    "mcr_synth_actions_block": (_i, [_vp, _vp, ctypes.c_uint64, ctypes.c_uint32, _i, ctypes.c_uint32, _vp]),
     "mcr_synth_actions_host": (None, [_vp, _i, _i, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32]),
 }
 

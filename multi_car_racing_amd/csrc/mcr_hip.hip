@@ -381,19 +381,24 @@ extern "C" int mcr_set_step_graph(mcr_env* h, int enable) {
   return MCR_OK;
 }
 
+// blockIdx.y = step offset: out[nsteps][n_cars][3]
 __global__ void k_synth_actions(float* __restrict__ out, int n_cars, int N, unsigned long long seed, unsigned t, unsigned env_offset) {
   const int ci = blockIdx.x * blockDim.x + threadIdx.x;
   if (ci >= n_cars) return;
   float a[3];
-  mcr_synth_action(seed, env_offset + (unsigned)(ci / N), (unsigned)(ci % N), t, a);
-  out[ci * 3] = a[0]; out[ci * 3 + 1] = a[1]; out[ci * 3 + 2] = a[2];
+  mcr_synth_action(seed, env_offset + (unsigned)(ci / N), (unsigned)(ci % N), t + blockIdx.y, a);
+  float* o = out + ((size_t)blockIdx.y * n_cars + ci) * 3;
+  o[0] = a[0]; o[1] = a[1]; o[2] = a[2];
 }
-extern "C" int mcr_synth_actions(mcr_env* h, float* d_actions, uint64_t seed, uint32_t t, uint32_t env_offset, void* stream) {
-  if (!h || !d_actions) { g_err = "null argument"; return MCR_ERR_ARG; }
-  hipLaunchKernelGGL(k_synth_actions, dim3((h->P.BN + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_actions, h->P.BN, h->P.N,
-                     (unsigned long long)seed, t, env_offset);
+extern "C" int mcr_synth_actions_block(mcr_env* h, float* d_actions, uint64_t seed, uint32_t t0, int nsteps, uint32_t env_offset, void* stream) {
+  if (!h || !d_actions || nsteps < 1 || nsteps > 65535) { g_err = "bad argument"; return MCR_ERR_ARG; }
+  hipLaunchKernelGGL(k_synth_actions, dim3((h->P.BN + 255) / 256, nsteps), dim3(256), 0, (hipStream_t)stream, d_actions, h->P.BN, h->P.N,
+                     (unsigned long long)seed, t0, env_offset);
   HIPCHK(hipGetLastError());
   return MCR_OK;
+}
+extern "C" int mcr_synth_actions(mcr_env* h, float* d_actions, uint64_t seed, uint32_t t, uint32_t env_offset, void* stream) {
+  return mcr_synth_actions_block(h, d_actions, seed, t, 1, env_offset, stream);
 }
 
 extern "C" int mcr_render(mcr_env* h, int env, int width, int height, uint8_t* d_out, void* stream) {

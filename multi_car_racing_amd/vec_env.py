@@ -340,14 +340,15 @@ class VecMultiCarRacing:
         _lib.check(self.L.mcr_set_state_blob(self.h, int(e), _lib.ptr(blob)), "mcr_set_state_blob")
         self._has_reset = self._has_reset or True
 
-    def synth_actions(self, t, seed=0, out=None):
-        """Counter-based synthetic actions for step t (bench/tests): device tensor [B,N,3] f32, a pure function of
-        (seed, global env index, agent, t)."""
+    def synth_actions(self, t, seed=0, out=None, steps=None):
+        """Counter-based synthetic actions (bench/tests): a pure function of (seed, global env index, agent, t).  Step t as a
+        device tensor [B,N,3] f32, or — with `steps` — the steps t .. t+steps-1 in one launch as [steps,B,N,3]."""
+        n = 1 if steps is None else int(steps)
         if out is None:
-            out = torch.empty((self.B, self.N, 3), dtype=torch.float32, device=self.device)
+            out = torch.empty(((self.B, self.N, 3) if steps is None else (n, self.B, self.N, 3)), dtype=torch.float32, device=self.device)
         st = torch.cuda.current_stream(self.device)
-        _lib.check(self.L.mcr_synth_actions(self.h, ctypes.c_void_p(out.data_ptr()), ctypes.c_uint64(int(seed)), ctypes.c_uint32(int(t) & 0xffffffff),
-                                            ctypes.c_uint32(self.env_offset), ctypes.c_void_p(st.cuda_stream)), "mcr_synth_actions")
+        _lib.check(self.L.mcr_synth_actions_block(self.h, ctypes.c_void_p(out.data_ptr()), ctypes.c_uint64(int(seed)), ctypes.c_uint32(int(t) & 0xffffffff),
+                                                  n, ctypes.c_uint32(self.env_offset), ctypes.c_void_p(st.cuda_stream)), "mcr_synth_actions_block")
         return out
 
     def positions(self):

@@ -529,6 +529,9 @@ def test_synth_actions_device_equals_host_twin(torch_cuda, lib):
         h = np.zeros((37, 3, 3), np.float32)
         env.L.mcr_synth_actions_host(lib.ptr(h), 37, 3, ctypes.c_uint64(9), ctypes.c_uint32(t), ctypes.c_uint32(500))
         assert np.array_equal(d, h), t
+    blk = env.synth_actions(997, seed=9, steps=5).cpu().numpy()          # a block of steps in one launch == step by step
+    for j in range(5):
+        assert np.array_equal(blk[j], env.synth_actions(997 + j, seed=9).cpu().numpy()), j
     env.close()
 
 
