@@ -115,29 +115,36 @@ __device__ __forceinline__ void joint_velocity(Joint& J, Body& A, Body& B, float
   // Cdot1 = vB + cross(wB, rB) - vA - cross(wA, rA)   with rB == 0
   const float c1x = (vBx - vAx) - (-wA * J.rAy);
   const float c1y = (vBy - vAy) - (wA * J.rAx);
-  if (J.limit != 0) {
+  // Box2D's two branches (limit active: 3x3 solve, and a 2x2 re-solve when the limit impulse would change sign; limit
+  // inactive: 2x2 solve) share the 2x2 solve and the application of the impulse here — same expressions and operand
+  // order per lane, but a wavefront whose lanes disagree about the limit state (front wheels of a batch of cars with
+  // random steering: nearly always) no longer runs both copies of them.
+  const bool lim = J.limit != 0;
+  float impx = 0.0f, impy = 0.0f, impz = 0.0f;
+  float rhsx = -c1x, rhsy = -c1y;
+  bool two = !lim;
+  if (lim) {
     float c2 = wB - wA;
     float sx, sy, sz; solve33(J, c1x, c1y, c2, sx, sy, sz);
-    float impx = -sx, impy = -sy, impz = -sz;
+    impx = -sx; impy = -sy; impz = -sz;
     float newImpulse = J.iz + impz;
     bool reduce = (J.limit == 1) ? (newImpulse < 0.0f) : (newImpulse > 0.0f);
     if (reduce) {
-      float rhsx = -c1x + J.iz * J.ezx, rhsy = -c1y + J.iz * J.ezy;
-      float rx, ry; solve22(J, rhsx, rhsy, rx, ry);
-      impx = rx; impy = ry; impz = -J.iz;
-      J.ix += rx; J.iy += ry; J.iz = 0.0f;
-    } else { J.ix += impx; J.iy += impy; J.iz += impz; }
-    vAx = vAx - mA * impx; vAy = vAy - mA * impy;
-    wA -= iA * ((J.rAx * impy - J.rAy * impx) + impz);
-    vBx = vBx + mB * impx; vBy = vBy + mB * impy;
-    wB += iB * impz;
-  } else {
-    float ix, iy; solve22(J, -c1x, -c1y, ix, iy);
-    J.ix += ix; J.iy += iy;
-    vAx = vAx - mA * ix; vAy = vAy - mA * iy;
-    wA -= iA * (J.rAx * iy - J.rAy * ix);
-    vBx = vBx + mB * ix; vBy = vBy + mB * iy;
+      rhsx = -c1x + J.iz * J.ezx; rhsy = -c1y + J.iz * J.ezy;
+      impz = -J.iz;
+      J.iz = 0.0f;
+      two = true;
+    } else J.iz += impz;
   }
+  if (two) solve22(J, rhsx, rhsy, impx, impy);
+  J.ix += impx; J.iy += impy;
+  vAx = vAx - mA * impx; vAy = vAy - mA * impy;
+  {
+    const float t = J.rAx * impy - J.rAy * impx;
+    wA -= iA * (lim ? t + impz : t);
+  }
+  vBx = vBx + mB * impx; vBy = vBy + mB * impy;
+  if (lim) wB += iB * impz;
   A.vx = vAx; A.vy = vAy; A.w = wA; B.vx = vBx; B.vy = vBy; B.w = wB;
 }
 
