@@ -5,13 +5,13 @@ kt = pd.read_csv(sys.argv[1]).sort_values("Start_Timestamp").reset_index(drop=Tr
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 ns = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 def kname(s):
-    for k in ("k_collide", "k_dynamics", "k_view", "k_flags", "k_synth", "k_install", "copyBuffer", "fillBuffer"):
+    for k in ("k_collide", "k_dynamics", "k_view", "k_flags", "k_list_chain", "k_reset_list", "k_synth", "k_install", "copyBuffer", "fillBuffer"):
         if k in s: return k
     return s[:30]
 kt["K"] = kt["Kernel_Name"].map(kname)
-# a step starts at each k_collide launched with the largest grid right after a fill (memset) or a view; find pass-0 collides:
+# a step starts at each k_collide launch that does not follow a k_install (that one belongs to reset() / reset_envs())
 col = kt.index[(kt.K == "k_collide")].tolist()
-starts = [i for j, i in enumerate(col) if j == 0 or kt.K[col[j - 1]:i].isin(["k_synth"]).any()]
+starts = [i for i in col if i == 0 or kt.K[i - 1] != "k_install"]
 sel = starts[-back:-back + ns + 1]
 qcol = "Queue_Id" if "Queue_Id" in kt.columns else None
 for a, b in zip(sel[:-1], sel[1:]):
