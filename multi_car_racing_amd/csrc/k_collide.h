@@ -256,9 +256,7 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   for (int o = 1; o < 64; o <<= 1) or_bits |= (uint32_t)__shfl_xor((int)or_bits, o);
   if (lane < N) {
     const int ci = env * N + lane;
-    uint32_t prev = p.caru[CU_ONROAD * BN + ci] & 0xFu;
-    uint32_t cur = (or_bits >> (4 * lane)) & 0xFu;
-    p.caru[CU_ONROAD * BN + ci] = (prev << 4) | cur;
+    p.caru[CU_ONROAD_NEW * BN + ci] = (or_bits >> (4 * lane)) & 0xFu;
     double r = 0.0; int tv = 0;
 #pragma unroll
     for (int c = 0; c < MCR_MAX_AGENTS; ++c) if (c == lane) { r = reward[c]; tv = tvc[c]; }

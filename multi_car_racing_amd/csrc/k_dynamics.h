@@ -501,7 +501,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
       brake = a2;
     }
 
-    // ---- Car.step(dt): tyre model, f64.  Friction uses the PREVIOUS Collide's contact set (bits 4..7).
+    // ---- Car.step(dt): tyre model, f64.  Friction uses the PREVIOUS Collide's contact set (CU_ONROAD).
     const double ENGINE_POWER = 100000000 * MCR_SIZE * MCR_SIZE;
     const double WHEEL_MOI = 4000 * MCR_SIZE * MCR_SIZE;
     const double FRICTION_LIMIT = 1000000 * MCR_SIZE * MCR_SIZE;
@@ -518,7 +518,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
       double val = fabs(wsteer - jangle);
       J[k].motorSpeed = (float)(dir * fmin(50.0 * val, 3.0));
       double friction_limit = FRICTION_LIMIT * 0.6;
-      if ((onroad >> (4 + k)) & 1u) friction_limit = fmax(friction_limit, FRICTION_LIMIT * 1.0);
+      if ((onroad >> k) & 1u) friction_limit = fmax(friction_limit, FRICTION_LIMIT * 1.0);
       Rot q = rot_of(b[k + 1].a);
       double forw0 = (double)(-q.s), forw1 = (double)q.c, side0 = (double)q.c, side1 = (double)q.s;
       double vx = (double)b[k + 1].vx, vy = (double)b[k + 1].vy;
@@ -552,7 +552,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
     }
     if (p.particles) {                                           // w.position: the wheel bodies have their origin at the centre
       uint32_t* pc = p.particles + (size_t)ci * MCR_PART_WORDS;
-      for (int k = 0; k < 4; ++k) mcr_particle_step(pc, k, ((skid >> k) & 1u) != 0u, !((onroad >> (4 + k)) & 1u), b[k + 1].cx, b[k + 1].cy);
+      for (int k = 0; k < 4; ++k) mcr_particle_step(pc, k, ((skid >> k) & 1u) != 0u, !((onroad >> k) & 1u), b[k + 1].cx, b[k + 1].cy);
     }
 
     // ---- b2Island::Solve: integrate velocities
@@ -970,7 +970,6 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
     gas[0] = gas[1] = 0; steer = 0; brake = 0; onroad = 0;
     reward = 0; prev_reward = 0; tvc = 0; flags = 0; epret = 0;
     if (p.particles) mcr_particles_clear(p.particles + (size_t)ci * MCR_PART_WORDS);
-    p.caru[CU_ONROAD * BN + ci] = 0;
     p.caru[CU_TVC * BN + ci] = 0;
   }
   // ---- write back
@@ -989,6 +988,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
     p.card[(CD_OMEGA + k) * BN + ci] = omega[k]; p.card[(CD_PHASE + k) * BN + ci] = phase[k];
   }
   p.caru[CU_LIMIT * BN + ci] = lim;
+  p.caru[CU_ONROAD * BN + ci] = respawn ? 0u : p.caru[CU_ONROAD_NEW * BN + ci];       // this step's Collide is what the next Car.step sees
   p.card[(CD_GAS + 0) * BN + ci] = gas[0]; p.card[(CD_GAS + 1) * BN + ci] = gas[1];
   p.card[CD_STEER * BN + ci] = steer; p.card[CD_BRAKE * BN + ci] = brake;
   if (mode == 0) {
@@ -1166,7 +1166,7 @@ __global__ __launch_bounds__(64) void k_install(McrParams p) {
   }
   p.card[(CD_GAS + 0) * BN + ci] = 0.0; p.card[(CD_GAS + 1) * BN + ci] = 0.0; p.card[CD_STEER * BN + ci] = 0.0; p.card[CD_BRAKE * BN + ci] = 0.0;
   p.card[CD_REWARD * BN + ci] = 0.0; p.card[CD_PREV_REWARD * BN + ci] = 0.0; p.card[CD_EPRET * BN + ci] = 0.0;
-  p.caru[CU_LIMIT * BN + ci] = 0; p.caru[CU_ONROAD * BN + ci] = 0; p.caru[CU_TVC * BN + ci] = 0; p.caru[CU_FLAGS * BN + ci] = 0;
+  p.caru[CU_LIMIT * BN + ci] = 0; p.caru[CU_ONROAD * BN + ci] = 0; p.caru[CU_ONROAD_NEW * BN + ci] = 0; p.caru[CU_TVC * BN + ci] = 0; p.caru[CU_FLAGS * BN + ci] = 0;
   if (p.particles) mcr_particles_clear(p.particles + (size_t)ci * MCR_PART_WORDS);
   if (agent == 0) {
     McrEnvState* E = &p.env[env];

@@ -104,10 +104,12 @@ enum {
 // u32 fields  caru[field][B*N]
 enum {
   CU_LIMIT = 0,       // 2 bits per joint
-  CU_ONROAD = 1,      // bits 0..3 current Collide, bits 4..7 previous Collide (what Car.step reads)
+  CU_ONROAD = 1,      // bits 0..3: wheel k has a tile under it, as of the Collide of the step that ENDED last = what Car.step reads
+                      // (len(w.tiles) > 0: the listener's sets change inside world.Step, after Car.step)
   CU_TVC = 2,         // tile_visited_count
   CU_FLAGS = 3,       // bit0 driving_backward, bit1 driving_on_grass
-  CU_COUNT = 4
+  CU_ONROAD_NEW = 4,  // the same bits as this step's Collide found them (k_collide writes, the step's k_dynamics promotes them to CU_ONROAD)
+  CU_COUNT = 5
 };
 // per-env state
 struct McrEnvState {
