@@ -351,6 +351,5 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
 
 // one workgroup per env (the list launches of roles >= 2 call collide_block from k_list_chain.h)
 __global__ __launch_bounds__(64) void k_collide(McrParams p, int pass) {
-  if (pass == 0 && blockIdx.x == 0 && threadIdx.x == 0) { p.vcount[0] = 0; p.vcount[1] = 0; p.dlist[0] = 0; p.rlist[0] = 0; }     // refilled by k_dynamics
   collide_block(p, pass, (int)blockIdx.x);
 }

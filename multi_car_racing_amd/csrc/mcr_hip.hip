@@ -78,13 +78,13 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   const size_t o_tflags = carve(sizeof(uint16_t) * MCR_TILE_CAP * (size_t)B);
   const size_t o_cc = carve(sizeof(uint32_t) * (size_t)B * (MCR_CC_MAX * MCR_CC_WORDS + 4));
   const size_t o_part = carve(B);
-  const size_t o_dlist = carve(sizeof(int32_t) * ((size_t)B + 1));
-  const size_t o_rlist = carve(sizeof(int32_t) * ((size_t)B + 1));
+  const size_t o_dlist = carve(sizeof(int32_t) * 2 * ((size_t)B + 1));      // x2: the lists of a step live in the buffers of its parity
+  const size_t o_rlist = carve(sizeof(int32_t) * 2 * ((size_t)B + 1));
   const size_t o_dstate = carve(BN);
   const size_t o_counters = carve(sizeof(unsigned long long) * 4);
   const size_t o_stage_ids = carve(sizeof(int32_t) * (size_t)B);
   const size_t o_stats = carve(sizeof(double) * 2);
-  const size_t o_vorder = carve(sizeof(int32_t) * ((size_t)B + 2));
+  const size_t o_vorder = carve(sizeof(int32_t) * 2 * ((size_t)B + 2));
   const size_t o_stamps = carve(sizeof(unsigned long long) * 8 * ((((size_t)B * G + 63) / 64) + 2 * (size_t)B));
   const size_t o_clist = carve(sizeof(int32_t) * 2 * ((size_t)B + 1));
   const size_t o_shapes = carve(sizeof(McrShapes));
@@ -250,9 +250,13 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   const int lg_col = std::min(B, MCR_LIST_GRID), lg_dyn = std::min((B + MCR_SIDE_ENVS_PER_WAVE - 1) / MCR_SIDE_ENVS_PER_WAVE, MCR_LIST_GRID / MCR_SIDE_ENVS_PER_WAVE);
   const bool draw = P.obs != nullptr;
   P.role = 0; P.split = h->split ? 1 : 0; P.defer_after = 0; P.respawn_list = 0;
-  if (h->split) {      // the contact list is double-buffered by step parity; no memset on the critical path
-    int32_t* base = h->P.clist;
-    P.clist = base + (size_t)(h->step_parity) * (B + 1); P.clist_next = base + (size_t)(h->step_parity ^ 1) * (B + 1);
+  {   // the device-side lists of a step are double-buffered by step parity: no memset, and nobody zeroes a list somebody reads
+    const size_t par = (size_t)h->step_parity, oth = par ^ 1;
+    P.clist = h->P.clist + par * (B + 1); P.clist_next = h->P.clist + oth * (B + 1);
+    P.dlist = h->P.dlist + par * (B + 1); P.rlist = h->P.rlist + par * (B + 1);
+    P.vcount = h->P.vcount + par * (B + 2); P.vorder = P.vcount + 2;
+    P.next_counts[0] = h->P.dlist + oth * (B + 1); P.next_counts[1] = h->P.rlist + oth * (B + 1);
+    P.next_counts[2] = h->P.vcount + oth * (B + 2); P.next_counts[3] = P.next_counts[2] + 1;
     h->step_parity ^= 1;
   }
   LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), st, P, 0);
@@ -347,10 +351,10 @@ extern "C" int mcr_step(mcr_env* h, const float* d_actions, uint8_t* d_obs, doub
     // contact-list parity: it can be replayed as a hipGraph (measured r02: 0.4 % faster — the gaps between the step's
     // dependent kernels are GPU-side drain/start-up, not host launch cost — so VecMultiCarRacing leaves it off).  Any change of an argument
     // (other buffers, another stream, debug switches) re-captures.
-    const int par = h->split ? h->step_parity : 0;
+    const int par = h->step_parity;
     mcr_env::StepGraph& G = h->sg[par];
     if (G.valid && G.st == st && G.view_flags == vf && memcmp(&G.P, &P, sizeof(P)) == 0) {
-      if (h->split) h->step_parity ^= 1;               // what launch_step does on the host side
+      h->step_parity ^= 1;                              // what launch_step does on the host side
       HIPCHK(hipGraphLaunch(G.exec, st));
       return MCR_OK;
     }

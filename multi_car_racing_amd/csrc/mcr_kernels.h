@@ -23,6 +23,8 @@ struct McrParams {
   uint8_t* part;                // [B] 1: env belongs to the side stream this step (written by k_collide pass 0)
   int32_t* clist;               // [1+B] count, then the env ids of the side-stream envs (any order); this step's buffer
   int32_t* clist_next;          // the other buffer (steps alternate): its count is zeroed by this step's main k_dynamics
+  int32_t* next_counts[4];      // the counts of the OTHER parity's deferred / re-spawn / raster-order lists (the lists of a step live in the
+                                // buffers of its parity): zeroed by this step's main k_dynamics — every reader of them finished last step
   int32_t split;                // k_collide pass 0 fills part/clist
   int32_t* dlist;               // [1+B] count + env ids deferred by the main k_dynamics (zeroed by k_collide pass 0)
   int32_t* rlist;               // [1+B] count + env ids the main k_dynamics re-spawned in this step (zeroed by k_collide pass 0); filled when respawn_list
