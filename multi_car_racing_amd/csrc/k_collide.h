@@ -345,8 +345,9 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
     if (lane == 0) { store[0] = (uint32_t)nn; store[1] = base > MCR_CC_MAX ? 1u : 0u; }
     nn_final = nn;
   } else if (lane == 0 && pass == 1) store[0] = 0;
-  // side-stream partition: envs whose dynamics chain is going to be long (a touching car<->car pair)
-  if (pass == 0 && p.split && lane == 0 && nn_final > 0) { p.part[env] = 1; p.clist[1 + atomicAdd(&p.clist[0], 1)] = env; atomicAdd(&p.counters[2], 1ull); }
+  // side-stream partition: envs whose car boxes overlap — every touching car<->car pair (a long dynamics chain) is among
+  // them, and the criterion needs nothing but the entry poses (the main dynamics can evaluate it by itself)
+  if (pass == 0 && p.split && lane == 0 && any_pair) { p.part[env] = 1; p.clist[1 + atomicAdd(&p.clist[0], 1)] = env; atomicAdd(&p.counters[2], 1ull); }
 }
 
 // one workgroup per env (the list launches of roles >= 2 call collide_block from k_list_chain.h)

@@ -433,7 +433,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
   __shared__ int xisl[64], xact[64], xjok[64], xcok[64];
   __shared__ float xms[64];
   const int g = blk * 64 + threadIdx.x;
-  const int env = mcr_env_of_slot(p, mcr_dyn_slot(p, blk)), agent = g % p.G;
+  const int env = mcr_env_of_slot(p, mcr_dyn_slot(p, blk), true), agent = g % p.G;
   const int env_end = p.env0 + p.nenv;
   bool lane_ok = env < env_end && agent < p.N;
   const int ci = lane_ok ? env * p.N + agent : 0;
@@ -825,6 +825,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
   if (defer_cap > 0) {
     int dfr = unfinished ? 1 : 0;
     for (int o = 1; o < p.G; o <<= 1) dfr |= __shfl_xor(dfr, o);          // env-wide: its cars finish the step together
+    if (!dfr && lane_ok && agent == 0) p.dpart[env] = 0;                  // (the mark of an earlier step's deferral)
     if (dfr && run) {
       // park the post-velocity-phase state exactly as the resume launch's prologue reloads it
 #pragma unroll
@@ -843,7 +844,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
       p.caru[CU_LIMIT * BN + ci] = lim;
       p.card[(CD_GAS + 0) * BN + ci] = gas[0]; p.card[(CD_GAS + 1) * BN + ci] = gas[1];
       p.card[CD_STEER * BN + ci] = steer; p.card[CD_BRAKE * BN + ci] = brake;
-      if (agent == 0) { p.part[env] = 2; p.dlist[1 + atomicAdd(&p.dlist[0], 1)] = env; atomicAdd(&p.counters[0], 1ull); }   // main reset pass / raster skip it
+      if (agent == 0) { p.dpart[env] = 1; p.dlist[1 + atomicAdd(&p.dlist[0], 1)] = env; atomicAdd(&p.counters[0], 1ull); }   // the main launches after this one skip it
     }
     if (dfr) { run = false; lane_ok = false; }                            // nothing below is this launch's business
   }

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
     if (p.role >= 2) { e = mcr_env_of_slot(p, s); if (e >= p.env0 + p.nenv) e = -1; }
     else if (p.use_vorder) { const int nh = p.vcount[0], nn = p.vcount[1]; if (s < nh + nn) e = p.vorder[s < nh ? s : p.B - 1 - (s - nh)]; }
     else if (s < p.nenv) e = p.env0 + s;
-    if (e >= 0 && p.role == 1 && p.part[e]) e = -1;
+    if (e >= 0 && p.role == 1 && (p.part[e] || p.dpart[e])) e = -1;
     if (e >= 0) {
       const McrEnvState es = p.env[e];
       // side-stream raster: a contact env re-spawned by this step's dynamics is drawn after its reset pass

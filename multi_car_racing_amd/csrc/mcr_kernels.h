@@ -28,6 +28,7 @@ struct McrParams {
   int32_t split;                // k_collide pass 0 fills part/clist
   int32_t* dlist;               // [1+B] count + env ids deferred by the main k_dynamics (zeroed by k_collide pass 0)
   int32_t* rlist;               // [1+B] count + env ids the main k_dynamics re-spawned in this step (zeroed by k_collide pass 0); filled when respawn_list
+  uint8_t* dpart;               // [B] 1: the main k_dynamics deferred this env in this step (written for every env it handles)
   uint32_t* particles;          // [B*N][MCR_PART_WORDS] skid particles of gym Car.step / _create_particle (drawn by render('rgb_array') only); null: not tracked
   int32_t respawn_list;         // the host runs the main envs' reset pass as a list launch (role 4)
   int32_t list_envs_per_block;  // list launches: envs a workgroup (= a wavefront) takes at a time, 1 .. MCR_SIDE_ENVS_PER_WAVE
@@ -71,7 +72,7 @@ __device__ __forceinline__ int mcr_label_value(double reward) { return (reward >
 // Env handled by work slot `s` of a launch (slot = env index for roles 0/1; position in the contact / deferred / re-spawn
 // list for roles 2 / 3 / 4); returns
 // p.env0 + p.nenv ("no env") for slots that are not this launch's business.
-__device__ __forceinline__ int mcr_env_of_slot(const McrParams& p, int s) {
+__device__ __forceinline__ int mcr_env_of_slot(const McrParams& p, int s, bool main_dynamics = false) {
   const int end = p.env0 + p.nenv;
   if (s < 0) return end;
   if (p.role == 2) return s < p.clist[0] ? p.clist[1 + s] : end;
@@ -79,7 +80,9 @@ __device__ __forceinline__ int mcr_env_of_slot(const McrParams& p, int s) {
   if (p.role == 4) return s < p.rlist[0] ? p.rlist[1 + s] : end;
   const int env = p.env0 + s;
   if (env >= end) return end;
-  return (p.role == 1 && p.part[env]) ? end : env;
+  // role 1 = the main launches: not the contact envs (k_collide's mark) and — for everybody but the main dynamics, which
+  // sets that mark itself — not the envs the main dynamics deferred
+  return (p.role == 1 && (p.part[env] || (!main_dynamics && p.dpart[env]))) ? end : env;
 }
 // Work slot of a k_dynamics lane.  Roles 0/1: 64/G consecutive envs per wavefront.  Role 2 (side stream, every env
 // holds car<->car contacts): MCR_SIDE_ENVS_PER_WAVE envs per wavefront, so that the wavefront's LDS pool of contact
