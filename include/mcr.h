@@ -181,6 +181,9 @@ int mcr_debug_read_dynamics_stamps(mcr_env* h, uint64_t* out, int n_u64);
  * [2] contact envs routed to the side stream, [3] env-steps frozen because the host had not staged the next episode yet
  * (a healthy rollout keeps this at 0) */
 int mcr_debug_read_counters(mcr_env* h, uint64_t* out4);
+/* the three-chain step decides one step ahead which envs hold a touching car<->car pair (the main dynamics launch runs
+ * beside the contact pass); the contact pass counts the envs where it disagrees: must stay 0 */
+int mcr_debug_read_verdict_mismatches(mcr_env* h, uint64_t* out1);
 /* number of touching car<->car fixture pairs (stored manifolds) per env after the last collide pass */
 int mcr_debug_read_contact_counts(mcr_env* h, int32_t* out /*[num_envs]*/);
 #define MCR_TIMING_SLOTS 8

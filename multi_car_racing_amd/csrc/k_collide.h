@@ -86,7 +86,6 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   using namespace col;
   const int env = mcr_env_of_slot(p, blk), lane = threadIdx.x;
   if (env >= p.env0 + p.nenv) return;
-  if (pass == 0 && p.split && lane == 0) p.part[env] = 0;
   const McrEnvState es = p.env[env];
   if (!es.active) return;
   if (pass == 1 && !es.resetting) return;
@@ -256,12 +255,22 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   for (int o = 1; o < 64; o <<= 1) or_bits |= (uint32_t)__shfl_xor((int)or_bits, o);
   if (lane < N) {
     const int ci = env * N + lane;
-    p.caru[CU_ONROAD_NEW * BN + ci] = (or_bits >> (4 * lane)) & 0xFu;
+    const uint32_t onr = (or_bits >> (4 * lane)) & 0xFu;
     double r = 0.0; int tv = 0;
 #pragma unroll
     for (int c = 0; c < MCR_MAX_AGENTS; ++c) if (c == lane) { r = reward[c]; tv = tvc[c]; }
-    p.card[CD_REWARD * BN + ci] = r;
-    p.caru[CU_TVC * BN + ci] = (uint32_t)tv;
+    if (pass == 0 && p.cc_mode) {
+      // the main dynamics, running beside this launch (possibly on another XCD, behind another L2), reads these three words
+      // of the car: device-scope stores and loads (write-through / L2-bypassing) instead of a release fence per workgroup —
+      // a fence writes the XCD's whole dirty L2 back (measured: 4096 of them take the launch from 24 to 146 us)
+      __hip_atomic_store((unsigned long long*)&p.card[CD_REWARD * BN + ci], (unsigned long long)__double_as_longlong(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&p.caru[CU_TVC * BN + ci], (uint32_t)tv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&p.caru[CU_ONROAD_NEW * BN + ci], onr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      p.card[CD_REWARD * BN + ci] = r;
+      p.caru[CU_TVC * BN + ci] = (uint32_t)tv;
+      p.caru[CU_ONROAD_NEW * BN + ci] = onr;
+    }
   }
 
   // ---- car<->car manifolds (b2Contact::Update for the dynamic pairs) at the same entry poses.
@@ -345,9 +354,18 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
     if (lane == 0) { store[0] = (uint32_t)nn; store[1] = base > MCR_CC_MAX ? 1u : 0u; }
     nn_final = nn;
   } else if (lane == 0 && pass == 1) store[0] = 0;
-  // side-stream partition: envs whose car boxes overlap — every touching car<->car pair (a long dynamics chain) is among
-  // them, and the criterion needs nothing but the entry poses (the main dynamics can evaluate it by itself)
-  if (pass == 0 && p.split && lane == 0 && any_pair) { p.part[env] = 1; p.clist[1 + atomicAdd(&p.clist[0], 1)] = env; atomicAdd(&p.counters[2], 1ull); }
+  // side-stream partition: envs whose dynamics chain is going to be long (a touching car<->car pair).  The verdict the
+  // main launches go by (p.part: mcr_touch_verdict, evaluated by last step's bookkeeping on the same poses) must agree:
+  // counters[4] counts disagreements (tests and bench assert 0).
+  if (pass == 0 && p.split && lane == 0) {
+    if (nn_final > 0) { p.clist[1 + atomicAdd(&p.clist[0], 1)] = env; atomicAdd(&p.counters[2], 1ull); }
+    if ((nn_final > 0) != (p.part[env] != 0)) atomicAdd(&p.counters[4], 1ull);
+  }
+  if (pass == 0 && p.cc_mode) {            // the main dynamics, running beside this launch, may read this env's results now
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // the stores above have completed (no cache write-back: they were write-through)
+    __syncthreads();
+    if (lane == 0) __hip_atomic_store(&p.collide_epoch[env], p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // one workgroup per env (the list launches of roles >= 2 call collide_block from k_list_chain.h)

@@ -490,6 +490,8 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
     steer = p.card[CD_STEER * BN + ci]; brake = p.card[CD_BRAKE * BN + ci];
     onroad = p.caru[CU_ONROAD * BN + ci];
 
+  }
+  if (run) {
     if (!resume) {
     // ---- controls (:418-424) — the reference negates the steering input
     if (mode == 0 && p.actions) {
@@ -571,7 +573,10 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
   const int leader_lane = lane - agent;
   uint32_t* store = p.cc_store + (size_t)(env < env_end ? env : 0) * (MCR_CC_MAX * MCR_CC_WORDS + 4);
   int ccn = 0;
-  if (run && p.car_contacts && p.N > 1) ccn = (int)store[0];
+  // (cc_mode: the main launch's envs are those whose verdict — mcr_touch_verdict, evaluated by last step's bookkeeping on the
+  // same poses with the same arithmetic — says that no car<->car fixture pair touches: k_collide, running beside this
+  // launch, finds none either; its store[0] is not read)
+  if (run && p.car_contacts && p.N > 1 && !(p.cc_mode && mode == 0 && p.role == 1)) ccn = (int)store[0];
   const bool wave_cc = __any(ccn > 0) != 0;
   DYN_STAMP(1);
   int pool_base = 0;
@@ -876,7 +881,21 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
   bool done = false, trunc = false, respawn = false;
   double step_reward = 0.0, reward = 0.0, prev_reward = 0.0, epret = 0.0;
   uint32_t tvc = 0, flags = 0;
-  if (run) { reward = p.card[CD_REWARD * BN + ci]; prev_reward = p.card[CD_PREV_REWARD * BN + ci]; tvc = p.caru[CU_TVC * BN + ci]; flags = p.caru[CU_FLAGS * BN + ci]; }
+  if (p.cc_mode && mode == 0 && p.role == 1 && run)               // k_collide pass 0 runs beside this launch: wait until it is through with this env
+    for (int spin = 0; spin < (1 << 24) && __hip_atomic_load(&p.collide_epoch[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch; ++spin)
+      __builtin_amdgcn_s_sleep(8);                                  // (bounded: ~3 s; k_collide was enqueued before this launch and takes ~25 us)
+  const bool cc_wait = p.cc_mode && mode == 0 && p.role == 1;
+  uint32_t onroad_new = 0;
+  if (run && cc_wait) {                                           // k_collide's three words of this car: device-scope loads (see k_collide)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    reward = __longlong_as_double((long long)__hip_atomic_load((unsigned long long*)&p.card[CD_REWARD * BN + ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    tvc = __hip_atomic_load(&p.caru[CU_TVC * BN + ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    onroad_new = __hip_atomic_load(&p.caru[CU_ONROAD_NEW * BN + ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    prev_reward = p.card[CD_PREV_REWARD * BN + ci]; flags = p.caru[CU_FLAGS * BN + ci];
+  } else if (run) {
+    reward = p.card[CD_REWARD * BN + ci]; prev_reward = p.card[CD_PREV_REWARD * BN + ci]; tvc = p.caru[CU_TVC * BN + ci]; flags = p.caru[CU_FLAGS * BN + ci];
+    onroad_new = p.caru[CU_ONROAD_NEW * BN + ci];
+  }
   const double reward_shown = reward;      // the score label is drawn (:431) before this step's -0.1 (:437)
   int T = 0;
   if (env < env_end && es.active) T = ((const McrSlotHeader*)(p.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES))->T;
@@ -930,7 +949,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
         E->t = es.t + 1.0 / MCR_FPS;
         if (p.actions) E->steps = es.steps + 1;
         E->just_reset = 0;
-        if (done && p.auto_reset) { E->active = 0; E->frozen = 1; }   // no staged episode yet (host refill late): frozen until it arrives, see `thaw`
+        if (done && p.auto_reset) { E->active = 0; E->frozen = 1; if (p.part_next) { p.part[env] = 0; p.part_next[env] = 0; } }   // no staged episode yet (host refill late): frozen until it arrives, see `thaw` (a frozen env is the main launch's)
       }
       // raster launch order: zoomed-out frames (first second of an episode, :540-542) cost several times a normal
       // one, so their workgroups go FIRST (front of vorder) and cannot end up as the launch's tail
@@ -989,7 +1008,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
     p.card[(CD_OMEGA + k) * BN + ci] = omega[k]; p.card[(CD_PHASE + k) * BN + ci] = phase[k];
   }
   p.caru[CU_LIMIT * BN + ci] = lim;
-  p.caru[CU_ONROAD * BN + ci] = respawn ? 0u : p.caru[CU_ONROAD_NEW * BN + ci];       // this step's Collide is what the next Car.step sees
+  p.caru[CU_ONROAD * BN + ci] = respawn ? 0u : onroad_new;                          // this step's Collide is what the next Car.step sees
   p.card[(CD_GAS + 0) * BN + ci] = gas[0]; p.card[(CD_GAS + 1) * BN + ci] = gas[1];
   p.card[CD_STEER * BN + ci] = steer; p.card[CD_BRAKE * BN + ci] = brake;
   if (mode == 0) {

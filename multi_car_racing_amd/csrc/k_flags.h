@@ -12,6 +12,7 @@
 //   heading vs track direction (:449-495) by one lane.
 #pragma once
 #include "k_raster_common.h"
+#include "k_touch.h"
 
 __device__ __forceinline__ void flags_block(const McrParams& p, const int blk) {
   const int lane = threadIdx.x;
@@ -21,6 +22,12 @@ __device__ __forceinline__ void flags_block(const McrParams& p, const int blk) {
   if (env >= p.env0 + p.nenv) return;
   const int ci = env * N + blk % N;
   const McrEnvState es = p.env[env];
+  // the wavefront of an env's first car also evaluates the env's touch verdict for the NEXT step (k_touch.h): the poses
+  // this step ended with are the ones the next contact pass sees
+  if (p.part_next && blk % N == 0) {
+    const bool v = es.active ? mcr_touch_verdict(p, env) : false;
+    if (lane == 0) p.part_next[env] = v ? 1 : 0;
+  }
   if (!es.active || es.just_reset) return;                   // reset() -> step(None) skips the block (:435); a re-spawned car keeps its zeroed flags
   const uint8_t* __restrict__ slot = p.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES;
   const McrSlotHeader* H = (const McrSlotHeader*)slot;

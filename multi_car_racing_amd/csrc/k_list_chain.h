@@ -24,7 +24,19 @@ __device__ __forceinline__ void list_reset_pass(const McrParams& p, const int bl
 __global__ __launch_bounds__(64) void k_reset_list(McrParams p) {
   __builtin_amdgcn_s_setprio(3);
   const int nb = mcr_virtual_blocks(p, p.list_envs_per_block);
-  for (int blk = blockIdx.x; blk < nb; blk += gridDim.x) list_reset_pass(p, blk);
+  for (int blk = blockIdx.x; blk < nb; blk += gridDim.x) {
+    list_reset_pass(p, blk);
+    // the next step's touch verdict of the re-spawned envs (their cars take no bookkeeping in this step: first observation)
+    if (p.part_next) {
+      __threadfence();
+      for (int k = 0; k < p.list_envs_per_block; ++k) {
+        const int env = mcr_env_of_slot(p, blk * p.list_envs_per_block + k);
+        if (env >= p.env0 + p.nenv) continue;
+        const bool v = p.env[env].active ? mcr_touch_verdict(p, env) : false;
+        if (threadIdx.x == 0) p.part_next[env] = v ? 1 : 0;
+      }
+    }
+  }
 }
 
 // roles 2 / 3: dynamics (for role 3: the rest of it) -> reset pass if the episode ended -> bookkeeping (k_flags.h)

@@ -135,7 +135,7 @@ struct McrShapes {
   float hull_invMass, hull_invI, hull_lcx, hull_lcy;
   float wheel_invMass, wheel_invI;
   float anchor_x[4], anchor_y[4];     // revolute joint localAnchorA
-  float pad[2];
+  float pad[2];                       // [0] hull radius around its centre of mass, [1] wheel radius (coarse car<->car test, k_touch.h)
 };
 
 // ------------------------------------------------------------------ synthetic action stream (bench / tests)

@@ -48,12 +48,13 @@ struct mcr_env {
   int step_parity;            // which contact-list buffer the next step fills
   int32_t* stage_ids;         // [B] device scratch of mcr_stage_episodes
   hipStream_t s_side, s_defer; // internal streams: the contact envs' chain, the deferred envs' chain
-  hipEvent_t ev_fork, ev_join, ev_fork2, ev_join2;
+  hipEvent_t ev_fork, ev_join, ev_fork2, ev_join2, ev_col;
   unsigned long long* view_stamps;   // [BN][16] phase clocks of the rasteriser (debug bit 5)
   // hipGraph of one step (mcr_set_step_graph): one per contact-list parity, re-captured when any argument changes
   struct StepGraph { bool valid; McrParams P; hipStream_t st; int view_flags; hipGraph_t graph; hipGraphExec_t exec; };
   StepGraph sg[2];
   int use_graph;              // 0 off, 1 on, -1 capture failed once: stay off
+  bool verdict_fresh;         // the touch verdicts (k_touch.h) of the next step's entry poses are in place (last step's bookkeeping wrote them)
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -63,7 +64,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   if (cfg->num_envs < 1 || cfg->num_agents < 1 || cfg->num_agents > MCR_MAX_AGENTS) { g_err = "num_envs/num_agents out of range"; return MCR_ERR_ARG; }
   HIPCHK(hipSetDevice(cfg->device));
   mcr_env* h = new mcr_env();
-  h->cfg = *cfg; h->timing = 0; h->any_reset = false; h->use_graph = 0; h->sg[0].valid = h->sg[1].valid = false;
+  h->cfg = *cfg; h->timing = 0; h->any_reset = false; h->use_graph = 0; h->verdict_fresh = false; h->sg[0].valid = h->sg[1].valid = false;
   for (int i = 0; i < MCR_TIMING_SLOTS; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
   const int B = cfg->num_envs, N = cfg->num_agents;
   int G = 1; while (G < N) G <<= 1;
@@ -77,12 +78,13 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   const size_t o_touch = carve(sizeof(uint32_t) * MCR_TILE_CAP * (size_t)B);
   const size_t o_tflags = carve(sizeof(uint16_t) * MCR_TILE_CAP * (size_t)B);
   const size_t o_cc = carve(sizeof(uint32_t) * (size_t)B * (MCR_CC_MAX * MCR_CC_WORDS + 4));
-  const size_t o_part = carve(B);
+  const size_t o_part = carve(2 * (size_t)B);                 // x2: the touch verdicts of a step live in the buffer of its parity
   const size_t o_dpart = carve(B);
+  const size_t o_epoch = carve(sizeof(int32_t) * (size_t)B);
   const size_t o_dlist = carve(sizeof(int32_t) * 2 * ((size_t)B + 1));      // x2: the lists of a step live in the buffers of its parity
   const size_t o_rlist = carve(sizeof(int32_t) * 2 * ((size_t)B + 1));
   const size_t o_dstate = carve(BN);
-  const size_t o_counters = carve(sizeof(unsigned long long) * 4);
+  const size_t o_counters = carve(sizeof(unsigned long long) * 8);
   const size_t o_stage_ids = carve(sizeof(int32_t) * (size_t)B);
   const size_t o_stats = carve(sizeof(double) * 2);
   const size_t o_vorder = carve(sizeof(int32_t) * 2 * ((size_t)B + 2));
@@ -106,7 +108,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   P.cc_store = (uint32_t*)(base + o_cc); P.shapes = (const McrShapes*)(base + o_shapes); P.slots = base + o_slots;
   h->view_stamps = (unsigned long long*)(base + o_vscratch);
   P.viewp = (float*)(base + o_viewp);
-  P.part = base + o_part; P.dpart = base + o_dpart; P.dlist = (int32_t*)(base + o_dlist); P.rlist = (int32_t*)(base + o_rlist); P.defer_state = base + o_dstate; P.counters = (unsigned long long*)(base + o_counters); P.stats = (double*)(base + o_stats);
+  P.part = base + o_part; P.dpart = base + o_dpart; P.collide_epoch = (int32_t*)(base + o_epoch); P.dlist = (int32_t*)(base + o_dlist); P.rlist = (int32_t*)(base + o_rlist); P.defer_state = base + o_dstate; P.counters = (unsigned long long*)(base + o_counters); P.stats = (double*)(base + o_stats);
   h->stage_ids = (int32_t*)(base + o_stage_ids); P.vcount = (int32_t*)(base + o_vorder); P.vorder = P.vcount + 2; P.dbg_stamps = (unsigned long long*)(base + o_stamps); P.clist = (int32_t*)(base + o_clist);
   P.carpoly = (float*)(base + o_carpoly);
   P.particles = cfg->skid_particles ? (uint32_t*)(base + o_particles) : nullptr;
@@ -139,6 +141,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
       if (hipStreamCreateWithPriority(&h->s_defer, hipStreamNonBlocking, prio_hi) == hipSuccess) {
         (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&h->ev_col, hipEventDisableTiming);
         h->split = true;
       } else (void)hipStreamDestroy(h->s_side);
     }
@@ -158,7 +161,7 @@ extern "C" int mcr_destroy(mcr_env* h) {
   for (auto e : h->free_events) (void)hipEventDestroy(e);
   if (h->split) {
     (void)hipStreamDestroy(h->s_side); (void)hipStreamDestroy(h->s_defer);
-    (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_fork2); (void)hipEventDestroy(h->ev_join2);
+    (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_fork2); (void)hipEventDestroy(h->ev_join2); (void)hipEventDestroy(h->ev_col);
   }
   (void)hipFree(h->slab);
   (void)hipHostFree(h->consumed_host);
@@ -256,14 +259,14 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     P.clist = h->P.clist + par * (B + 1); P.clist_next = h->P.clist + oth * (B + 1);
     P.dlist = h->P.dlist + par * (B + 1); P.rlist = h->P.rlist + par * (B + 1);
     P.vcount = h->P.vcount + par * (B + 2); P.vorder = P.vcount + 2;
+    P.part = h->P.part + par * B; P.part_next = h->split ? h->P.part + oth * B : nullptr;
     P.next_counts[0] = h->P.dlist + oth * (B + 1); P.next_counts[1] = h->P.rlist + oth * (B + 1);
     P.next_counts[2] = h->P.vcount + oth * (B + 2); P.next_counts[3] = P.next_counts[2] + 1;
     h->step_parity ^= 1;
   }
-  LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), st, P, 0);
-  P.split = 0;
   if (!h->split) {
     // single stream: collide -> dynamics -> reset pass of the re-spawned envs (:408) -> raster -> bookkeeping, all envs
+    LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), st, P, 0);
     LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 0);
     if (P.auto_reset) {
       LAUNCH_LDS(3, k_collide, B, 64, col::lds_bytes(N), st, P, 1);
@@ -276,16 +279,24 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     return;
   }
   // Three chains that meet again at the end (k_list_chain.h: a list chain is one fused launch + its raster):
-  //   st      : collide(all) -+-> dynamics(main envs, 2 position sweeps) -+-> bookkeeping(main envs) -> raster(main envs) ------+
-  //   s_side  :               +-> chain(contact envs) -> their raster ----+-> reset pass(re-spawned envs) -> their raster ------+
-  //   s_defer :                                                           +-> chain(resume the deferred envs) -> their raster --+
+  //   st      : -+-> dynamics(main envs, 2 position sweeps) ---------+-> bookkeeping(main envs) -> raster(main envs) ------+
+  //   s_side  :  +-> collide(all) -> chain(contact envs) -> raster --+-> reset pass(re-spawned envs) -> their raster ------+
+  //   s_defer :                                                      +-> chain(resume the deferred envs) -> their raster --+
   // Contact envs: a wavefront holding a touching car<->car pair takes 2-4x as long as the others.  Deferred envs: the
   // few whose position loop is still iterating after 2 sweeps (a slow marginal crawl that would hold the whole main
   // launch for up to 60).  Re-spawned envs (auto-reset, ~B/1000 per step): their reset pass would hold the raster of
   // everybody else (they are not in the main raster's list, see k_dynamics).
   P.defer_after = MCR_DEFER_AFTER; P.respawn_list = P.auto_reset ? 1 : 0; P.list_envs_per_block = MCR_SIDE_ENVS_PER_WAVE;
+  // The contact pass runs on the side stream BESIDE the main dynamics (cc_mode, mcr_kernels.h): nothing the solver needs
+  // comes from it (Car.step reads the wheels' tile bits of the PREVIOUS pass; which envs are the contact chain's follows
+  // from the entry poses), only the step's bookkeeping at the end of the dynamics kernel does, and that waits for
+  // k_collide's per-env "done" word.  24 us + a kernel boundary off the critical path.
+  P.cc_mode = 1; P.epoch = 1 + (h->step_parity & 1);
   (void)hipEventRecord(h->ev_fork, st);
   (void)hipStreamWaitEvent(h->s_side, h->ev_fork, 0);
+  LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), h->s_side, P, 0);
+  (void)hipEventRecord(h->ev_col, h->s_side);
+  P.split = 0;
   // bookkeeping of a chain's cars: fused into the chain for N <= 2 (2 envs x N cars take their turns on one wavefront),
   // a list launch of its own beyond that
   const int fuse_flags = (view_flags && N <= 2) ? 1 : 0;
@@ -298,6 +309,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 0);
   (void)hipEventRecord(h->ev_fork2, st);
   (void)hipStreamWaitEvent(h->s_defer, h->ev_fork2, 0);
+  (void)hipStreamWaitEvent(h->s_defer, h->ev_col, 0);
   (void)hipStreamWaitEvent(h->s_side, h->ev_fork2, 0);
   P.role = 3;
   LAUNCH_LDS(7, k_list_chain, lg_dyn, 64, col::lds_bytes(N), h->s_defer, P, fuse_flags);
@@ -319,6 +331,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   // before the raster, and those ~16 us are what the list chains — forked off at the same moment — need to get their
   // wavefronts placed: a chain that starts beside a raster that already fills every CU runs 2-3x slower (measured).
   if (view_flags) hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, st, P);
+  (void)hipStreamWaitEvent(st, h->ev_col, 0);                      // the raster reads the tiles' recolour flags (long done)
   P.use_vorder = 1;
   if (draw) launch_view(h, 2, B, st, P, 0);
   P.use_vorder = 0;
@@ -333,7 +346,7 @@ extern "C" int mcr_reset(mcr_env* h, const uint8_t* d_env_mask, uint8_t* d_obs, 
   P.reset_mask = d_env_mask; P.obs = h->cfg.obs_enabled ? d_obs : nullptr; P.actions = nullptr;
   launch_reset(h, P, st);
   HIPCHK(hipGetLastError());
-  h->any_reset = true;
+  h->any_reset = true; h->verdict_fresh = false;
   return MCR_OK;
 }
 
@@ -347,6 +360,11 @@ extern "C" int mcr_step(mcr_env* h, const float* d_actions, uint8_t* d_obs, doub
   // with auto_reset, finished envs are re-spawned on the device and take the action-less first step of their
   // new episode inside this call; the view kernel always runs (it also owns the backward/on-grass flags)
   const int vf = d_actions ? 1 : 0;
+  if (h->split && !h->verdict_fresh) {   // after reset() / reset_envs() / a state restore / a step without actions: which envs hold a touching car<->car pair?
+    McrParams Pt = P; Pt.role = 0; Pt.part = h->P.part + (size_t)h->step_parity * P.B;
+    hipLaunchKernelGGL(k_touch, dim3(P.B), dim3(64), 0, st, Pt);
+  }
+  h->verdict_fresh = vf != 0;             // this step's bookkeeping evaluates the next step's
   if (h->use_graph > 0 && !h->timing) {
     // The step is a fixed sequence of ~13 launches on up to three streams whose arguments only change with the
     // contact-list parity: it can be replayed as a hipGraph (measured r02: 0.4 % faster — the gaps between the step's
@@ -593,7 +611,7 @@ extern "C" int mcr_set_state_blob(mcr_env* h, int env, const void* blob) {
   HIPCHK(hipMemcpy(P.carpoly + (size_t)env * N * MCR_CARPOLY_FLOATS, b + L.carpoly, sizeof(float) * MCR_CARPOLY_FLOATS * N, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(P.slots + ((size_t)env * 2 + cur.slot) * MCR_SLOT_BYTES, b + L.slot, MCR_SLOT_BYTES, hipMemcpyHostToDevice));
   if (P.particles) HIPCHK(hipMemcpy(P.particles + (size_t)env * N * MCR_PART_WORDS, b + L.particles, sizeof(uint32_t) * MCR_PART_WORDS * N, hipMemcpyHostToDevice));
-  h->any_reset = true;
+  h->any_reset = true; h->verdict_fresh = false;
   return MCR_OK;
 }
 
@@ -635,6 +653,12 @@ extern "C" int mcr_debug_read_counters(mcr_env* h, uint64_t* out4) {
   if (!h || !out4) return MCR_ERR_ARG;
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(out4, h->P.counters, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost));
+  return MCR_OK;
+}
+extern "C" int mcr_debug_read_verdict_mismatches(mcr_env* h, uint64_t* out) {
+  if (!h || !out) return MCR_ERR_ARG;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out, h->P.counters + 4, sizeof(uint64_t), hipMemcpyDeviceToHost));
   return MCR_OK;
 }
 extern "C" int mcr_debug_read_contact_counts(mcr_env* h, int32_t* out) {

@@ -216,6 +216,13 @@ void mcr_build_shapes(McrShapes* S) {
     S->wheel_invMass = 1.0f / Mw; S->wheel_invI = 1.0f / Iw;
   }
   for (int k = 0; k < 4; ++k) { S->anchor_x[k] = (float)(kWheelPos[k][0] * MCR_SIZE); S->anchor_y[k] = (float)(kWheelPos[k][1] * MCR_SIZE); }
+  // bounding radii for the coarse car<->car test of k_touch.h: hull vertices around the hull's centre of mass, wheel
+  // vertices around the wheel's (its origin)
+  float hr = 0.0f, wr = 0.0f;
+  for (int k = 0; k < 4; ++k)
+    for (int i = 0; i < S->hull[k].n; ++i) hr = fmaxf(hr, hypotf(S->hull[k].vx[i] - S->hull_lcx, S->hull[k].vy[i] - S->hull_lcy));
+  for (int i = 0; i < S->wheel.n; ++i) wr = fmaxf(wr, hypotf(S->wheel.vx[i], S->wheel.vy[i]));
+  S->pad[0] = hr; S->pad[1] = wr;
 }
 
 extern "C" void mcr_mass_props(float* out) {

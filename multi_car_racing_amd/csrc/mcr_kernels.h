@@ -20,7 +20,9 @@ struct McrParams {
   int32_t* consumed_host;       // [B] mapped host memory: episode counter of the last install
   // contact side stream (mcr_config.num_streams == 2): envs holding a touching car<->car pair run their (much
   // longer) dynamics chain, reset pass and raster on a second stream, concurrently with everyone else's.
-  uint8_t* part;                // [B] 1: env belongs to the side stream this step (written by k_collide pass 0)
+  uint8_t* part;                // [B] 1: a car<->car fixture pair of the env touches at this step's entry poses: the env is the contact chain's.
+                                // The verdict (k_touch.h) is evaluated one step ahead by the bookkeeping kernels: two buffers, by step parity
+  uint8_t* part_next;           // ... the next step's, which this step's bookkeeping writes
   int32_t* clist;               // [1+B] count, then the env ids of the side-stream envs (any order); this step's buffer
   int32_t* clist_next;          // the other buffer (steps alternate): its count is zeroed by this step's main k_dynamics
   int32_t* next_counts[4];      // the counts of the OTHER parity's deferred / re-spawn / raster-order lists (the lists of a step live in the
@@ -28,6 +30,11 @@ struct McrParams {
   int32_t split;                // k_collide pass 0 fills part/clist
   int32_t* dlist;               // [1+B] count + env ids deferred by the main k_dynamics (zeroed by k_collide pass 0)
   int32_t* rlist;               // [1+B] count + env ids the main k_dynamics re-spawned in this step (zeroed by k_collide pass 0); filled when respawn_list
+  int32_t* collide_epoch;       // [B] k_collide pass 0 stores `epoch` here when it is through with the env (release); see cc_mode
+  int32_t epoch;                // 1 + step parity
+  int32_t cc_mode;              // 1: the main k_dynamics runs CONCURRENTLY with k_collide pass 0 (three-chain step): it finds the envs whose
+                                // car boxes overlap by itself (they are the contact chain's), and waits for collide_epoch[env] before it reads
+                                // what the collide pass produces for the step's bookkeeping (reward, tile count, wheel/tile bits)
   uint8_t* dpart;               // [B] 1: the main k_dynamics deferred this env in this step (written for every env it handles)
   uint32_t* particles;          // [B*N][MCR_PART_WORDS] skid particles of gym Car.step / _create_particle (drawn by render('rgb_array') only); null: not tracked
   int32_t respawn_list;         // the host runs the main envs' reset pass as a list launch (role 4)
@@ -80,8 +87,9 @@ __device__ __forceinline__ int mcr_env_of_slot(const McrParams& p, int s, bool m
   if (p.role == 4) return s < p.rlist[0] ? p.rlist[1 + s] : end;
   const int env = p.env0 + s;
   if (env >= end) return end;
-  // role 1 = the main launches: not the contact envs (k_collide's mark) and — for everybody but the main dynamics, which
-  // sets that mark itself — not the envs the main dynamics deferred
+  // role 1 = the main launches: not the contact envs (p.part: the touch verdict of this step's entry poses, written by last
+  // step's bookkeeping) and — for everybody but the main dynamics, which sets that mark itself — not the envs the main
+  // dynamics deferred
   return (p.role == 1 && (p.part[env] || (!main_dynamics && p.dpart[env]))) ? end : env;
 }
 // Work slot of a k_dynamics lane.  Roles 0/1: 64/G consecutive envs per wavefront.  Role 2 (side stream, every env

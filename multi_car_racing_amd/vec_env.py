@@ -286,6 +286,13 @@ class VecMultiCarRacing:
         _lib.check(self.L.mcr_debug_read_counters(self.h, _lib.ptr(out)), "mcr_debug_read_counters")
         return out
 
+
+    def verdict_mismatches(self):
+        """envs in which the contact pass disagreed with the touch verdict the main launches went by (must be 0; synchronises)"""
+        out = np.zeros(1, np.uint64)
+        _lib.check(self.L.mcr_debug_read_verdict_mismatches(self.h, _lib.ptr(out)), "mcr_debug_read_verdict_mismatches")
+        return int(out[0])
+
     def rollout_stats(self, reset=False):
         """(episodes finished, sum of their returns over all agents) accumulated on the device; synchronises."""
         out = np.zeros(2)

@@ -336,6 +336,7 @@ def test_side_stream_is_bit_identical_to_single_stream(torch_cuda, B, N):
     ctr = np.zeros(4, np.uint64)
     _lib.check(a2.L.mcr_debug_read_counters(a2.h, _lib.ptr(ctr)))
     assert ctr[0] > 0 and ctr[0] == ctr[1] and ctr[2] > 0, f"deferred {ctr[0]} resumed {ctr[1]} contact envs {ctr[2]}"
+    assert a2.verdict_mismatches() == 0, "the touch verdict of the main launches disagreed with the contact pass"
     a1.close(); a2.close()
 
 
