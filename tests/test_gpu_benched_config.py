@@ -93,6 +93,7 @@ def _contact_envs(torch, B, N, seed, steps, max_steps, car1_floors):
         env.step(_actions(torch, g, B, N, car1_floors))
         if k % 3 == 2:
             _lib.check(env.L.mcr_debug_read_contact_counts(env.h, _lib.ptr(cnt))); seen |= cnt > 0
+    assert env.verdict_mismatches() == 0, "the touch verdict of the main launches disagreed with the contact pass"
     env.close()
     return np.nonzero(seen)[0]
 
@@ -153,6 +154,7 @@ def _run_sampled(torch, O, B, N, seed, steps, n_sample, max_steps, masked_reset_
                     _cmp_pixels(got[j], f.first_obs, f.first_amb, f"masked reset at step {k} env {f.g}")
             _cmp_state(env, fol, idx, f"after masked reset at step {k}")
     frozen = int(env.debug_counters()[3])
+    assert env.verdict_mismatches() == 0, "the touch verdict of the main launches disagreed with the contact pass"
     env.close()
     return n_resets, n_contacts, frozen
 
@@ -206,7 +208,8 @@ def test_n8_b4096_properties_and_sampled_oracles(torch_cuda, oracle):
     big.close(); small.close()
 
 
-def test_freeze_and_thaw_when_host_withholds_staging(torch_cuda, oracle):
+@pytest.mark.parametrize("streams", [1, 2])
+def test_freeze_and_thaw_when_host_withholds_staging(torch_cuda, oracle, streams):
     """an env that finishes while no episode is staged freezes (zero reward, done 0) and must THAW
     as soon as the host stages one: its next step returns the first observation of the next episode of its own RNG
     streams and it keeps stepping bit-exact afterwards."""
@@ -214,7 +217,7 @@ def test_freeze_and_thaw_when_host_withholds_staging(torch_cuda, oracle):
     from multi_car_racing_amd.vec_env import VecMultiCarRacing
     B, N, seed, L = 6, 2, 90, 12
     env = VecMultiCarRacing(B, N, seed=seed, use_random_direction=True, auto_reset=True, max_episode_steps=L,
-                            car_contacts=True, async_refill=False, streams=1)
+                            car_contacts=True, async_refill=False, streams=streams)
     env.reset()                                          # consumes episode 1 and stages episode 2
     env.hold_refills = True                              # from now on nothing new gets staged
     fol = [_Follower(oracle, N, seed, g, L) for g in range(B)]
@@ -258,4 +261,5 @@ def test_freeze_and_thaw_when_host_withholds_staging(torch_cuda, oracle):
         _, _, orw, od = oracle.step_batch([f.o for f in fol], a, None, threads=2)
         for j, f in enumerate(fol):
             d, _ = f.after_step(bool(od[j])); assert np.array_equal(orw[j], rw[j]) and d == dn[j], (k, j)
+    assert env.verdict_mismatches() == 0
     env.close()
