@@ -24,9 +24,10 @@ __device__ __forceinline__ void flags_block(const McrParams& p, const int blk) {
   const McrEnvState es = p.env[env];
   // the wavefront of an env's first car also evaluates the env's touch verdict for the NEXT step (k_touch.h): the poses
   // this step ended with are the ones the next contact pass sees
+  // (evaluated before anything of the env record is looked at: its loads travel together with that one)
   if (p.part_next && blk % N == 0) {
-    const bool v = es.active ? mcr_touch_verdict(p, env) : false;
-    if (lane == 0) p.part_next[env] = v ? 1 : 0;
+    const bool v = mcr_touch_verdict(p, env);
+    if (lane == 0) p.part_next[env] = (es.active && v) ? 1 : 0;
   }
   if (!es.active || es.just_reset) return;                   // reset() -> step(None) skips the block (:435); a re-spawned car keeps its zeroed flags
   const uint8_t* __restrict__ slot = p.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES;
