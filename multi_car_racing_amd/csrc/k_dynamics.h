@@ -1019,6 +1019,8 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
   // ---- per-car view parameters for the rasteriser: one lane per agent view here instead of one redundant
   // evaluation per raster thread there.  Camera (:540-556): f64 exactly as CPython evaluates it, then the f32
   // values gym's Transform hands to glTranslatef/glRotatef/glScalef; HUD rectangles (:634-674).
+  float bxl = MCR_MAXFLT, byl = MCR_MAXFLT, bxh = -MCR_MAXFLT, byh = -MCR_MAXFLT;   // world box of the car's draw polygons (= its fixtures)
+  bool have_box = false;
   if (p.obs != nullptr && !respawn) {
     float* vp = p.viewp + (size_t)ci * MCR_VIEWP_FLOATS;
     const Xf hxf = xf_of(v2(b[0].cx, b[0].cy), b[0].a, v2(lcx, lcy));
@@ -1094,12 +1096,13 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
     // 16-byte stores — a polygon is 4 of them — and each distinct vertex is transformed once (padding repeats the last).
     float4* cp4 = (float4*)(p.carpoly + (size_t)ci * MCR_CARPOLY_FLOATS);
     int counts[12];
+    have_box = true;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const Xf wxf = xf_of(v2(b[k + 1].cx, b[k + 1].cy), b[k + 1].a, v2(0.0f, 0.0f));
       V2 w[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) w[i] = xmul(wxf, v2(S.wheel.vx[i], S.wheel.vy[i]));
+      for (int i = 0; i < 4; ++i) { w[i] = xmul(wxf, v2(S.wheel.vx[i], S.wheel.vy[i])); bxl = mcr_min(bxl, w[i].x); bxh = mcr_max(bxh, w[i].x); byl = mcr_min(byl, w[i].y); byh = mcr_max(byh, w[i].y); }
       float4* box = cp4 + (2 * k) * 4;
       box[0] = make_float4(w[0].x, w[0].y, w[1].x, w[1].y); box[1] = make_float4(w[2].x, w[2].y, w[3].x, w[3].y);
       box[2] = make_float4(w[3].x, w[3].y, w[3].x, w[3].y); box[3] = box[2];
@@ -1128,6 +1131,8 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
       V2 w[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) { if (i < n) w[i] = xmul(hxf, v2(S.hull[k].vx[i], S.hull[k].vy[i])); else w[i] = w[i - 1 < 0 ? 0 : i - 1]; }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { bxl = mcr_min(bxl, w[i].x); bxh = mcr_max(bxh, w[i].x); byl = mcr_min(byl, w[i].y); byh = mcr_max(byh, w[i].y); }
       float4* hp = cp4 + (8 + k) * 4;
 #pragma unroll
       for (int i = 0; i < 4; ++i) hp[i] = make_float4(w[2 * i].x, w[2 * i].y, w[2 * i + 1].x, w[2 * i + 1].y);
@@ -1136,6 +1141,26 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
     float4* cn = cp4 + MCR_CARPOLY_NOFF / 4;
 #pragma unroll
     for (int i = 0; i < 3; ++i) cn[i] = make_float4(__int_as_float(counts[4 * i]), __int_as_float(counts[4 * i + 1]), __int_as_float(counts[4 * i + 2]), __int_as_float(counts[4 * i + 3]));
+  }
+  // ---- the next step's touch verdict (k_touch.h), cheap half: can ANY fixture pair of two cars of this env touch?  (2: maybe —
+  // the bookkeeping kernel runs the exact test; 0: no — that is the verdict.)  A conservative filter: the boxes of the
+  // draw polygons (the fixtures' own vertices) with 0.2 of slack, or — no observations, or a fresh spawn — the hull discs of
+  // mcr_touch_verdict's first exit.
+  if (mode == 0 && p.role == 1 && p.part_next && p.car_contacts && p.N > 1) {
+    const int lead = (int)threadIdx.x - agent;
+    const float r0 = 2.0f * (fmaxf(S.pad[0], 2.5f + S.pad[1]) + 0.1f);
+    bool near = false;
+    for (int a = 0; a < p.N - 1; ++a)
+      for (int c = a + 1; c < p.N; ++c) {
+        const float ax = __shfl(b[0].cx, lead + a), ay = __shfl(b[0].cy, lead + a), ox = __shfl(b[0].cx, lead + c), oy = __shfl(b[0].cy, lead + c);
+        bool nr = (ax - ox) * (ax - ox) + (ay - oy) * (ay - oy) <= r0 * r0;
+        const float a0 = __shfl(bxl, lead + a), a1 = __shfl(byl, lead + a), a2 = __shfl(bxh, lead + a), a3 = __shfl(byh, lead + a);
+        const float c0 = __shfl(bxl, lead + c), c1 = __shfl(byl, lead + c), c2 = __shfl(bxh, lead + c), c3 = __shfl(byh, lead + c);
+        const bool boxes = __shfl((int)have_box, lead + a) && __shfl((int)have_box, lead + c);
+        if (boxes) nr = nr && !(a0 > c2 + 0.2f || a2 + 0.2f < c0 || a1 > c3 + 0.2f || a3 + 0.2f < c1);
+        near = near || nr;
+      }
+    if (agent == 0) p.part_next[env] = near ? 2 : 0;
   }
   }   // run
   DYN_STAMP(4);

@@ -22,14 +22,20 @@ __device__ __forceinline__ void flags_block(const McrParams& p, const int blk) {
   if (env >= p.env0 + p.nenv) return;
   const int ci = env * N + blk % N;
   const McrEnvState es = p.env[env];
-  // the wavefront of an env's first car also evaluates the env's touch verdict for the NEXT step (k_touch.h): the poses
-  // this step ended with are the ones the next contact pass sees
-  // (evaluated before anything of the env record is looked at: its loads travel together with that one)
-  if (p.part_next && blk % N == 0) {
-    const bool v = mcr_touch_verdict(p, env);
-    if (lane == 0) p.part_next[env] = (es.active && v) ? 1 : 0;
-  }
-  if (!es.active || es.just_reset) return;                   // reset() -> step(None) skips the block (:435); a re-spawned car keeps its zeroed flags
+  // The wavefront of an env's first car also settles the env's touch verdict for the NEXT step (k_touch.h): the poses this
+  // step ended with are the ones the next contact pass sees.  Main launch: the main dynamics has written 0 for every env
+  // whose hulls are far apart (nearly all) and 2 where the exact test is needed; list launches: always the exact test.
+  // The mark is requested here and looked at when the scan below is done (its latency is off the wavefront's chain).
+  const bool vwave = p.part_next != nullptr && blk % N == 0;
+  uint32_t vmark = 0;
+  if (vwave) vmark = p.role == 1 ? (uint32_t)p.part_next[env] : 2u;
+  auto settle_verdict = [&]() {
+    if (vwave && vmark == 2u) {
+      const bool v = mcr_touch_verdict(p, env);
+      if (lane == 0) p.part_next[env] = (es.active && v) ? 1 : 0;
+    }
+  };
+  if (!es.active || es.just_reset) { settle_verdict(); return; }   // reset() -> step(None) skips the block (:435); a re-spawned car keeps its zeroed flags
   const uint8_t* __restrict__ slot = p.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES;
   const McrSlotHeader* H = (const McrSlotHeader*)slot;
   const int T = H->T, P = H->P;
@@ -114,6 +120,7 @@ __device__ __forceinline__ void flags_block(const McrParams& p, const int blk) {
     const double od = __shfl_xor(bd, o); const int oi = __shfl_xor(bi, o);
     if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
   }
+  settle_verdict();
   if (lane != 0) return;
   if (bi == 0x7fffffff) {                                      // cannot happen with a valid track; exact full scan keeps the result defined
     bd = 1e300; bi = 0;
@@ -137,4 +144,5 @@ __device__ __forceinline__ void flags_block(const McrParams& p, const int blk) {
 }
 
 // one wavefront per car (the list launches of roles >= 2 call flags_block from k_list_chain.h)
-__global__ __launch_bounds__(64) void k_flags(McrParams p) { flags_block(p, (int)blockIdx.x); }
+// 8192 wavefronts = one round on 1024 SIMDs at 8 wavefronts each: the kernel must stay within 64 VGPRs
+__global__ __launch_bounds__(64, 8) void k_flags(McrParams p) { flags_block(p, (int)blockIdx.x); }
