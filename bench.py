@@ -254,7 +254,8 @@ def main():
                        "episodes_reset_in_timed_region": m["episodes"], "mean_episode_return_per_env": (m["return_sum"] / m["episodes"]) if m["episodes"] else None,
                        "tracks_generated_on_host_in_timed_region_rank0": generated,
                        "env_steps_frozen_waiting_for_host_rank0": int(env.env.debug_counters()[3] - ctr0[3]),
-                       "touch_verdict_mismatches_rank0": env.env.verdict_mismatches()},
+                       "touch_verdict_mismatches_rank0": env.env.verdict_mismatches(),
+                       "contact_pass_beside_dynamics": bool(env.env.L.mcr_concurrent_collide(env.env.h))},
             "roofline": roofline,
         }
         if K < 200:

@@ -184,6 +184,9 @@ int mcr_debug_read_counters(mcr_env* h, uint64_t* out4);
 /* the three-chain step decides one step ahead which envs hold a touching car<->car pair (the main dynamics launch runs
  * beside the contact pass); the contact pass counts the envs where it disagrees: must stay 0 */
 int mcr_debug_read_verdict_mismatches(mcr_env* h, uint64_t* out1);
+/* 1: the three-chain step runs the contact pass beside the main dynamics (mcr_create found that kernels of different streams
+ * overlap in this process); 0: it runs first (single stream, profilers that serialise kernels, MCR_SEQUENTIAL_COLLIDE=1) */
+int mcr_concurrent_collide(const mcr_env* h);
 /* number of touching car<->car fixture pairs (stored manifolds) per env after the last collide pass */
 int mcr_debug_read_contact_counts(mcr_env* h, int32_t* out /*[num_envs]*/);
 #define MCR_TIMING_SLOTS 8

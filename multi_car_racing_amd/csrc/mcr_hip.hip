@@ -54,17 +54,41 @@ struct mcr_env {
   struct StepGraph { bool valid; McrParams P; hipStream_t st; int view_flags; hipGraph_t graph; hipGraphExec_t exec; };
   StepGraph sg[2];
   int use_graph;              // 0 off, 1 on, -1 capture failed once: stay off
+  bool concurrent_collide;    // the contact pass may run beside the main dynamics (kernels of different streams do overlap here: probed at create)
   bool verdict_fresh;         // the touch verdicts (k_touch.h) of the next step's entry poses are in place (last step's bookkeeping wrote them)
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Do kernels of two streams really run side by side in this process?  Under a counter-collecting profiler, a debugger or
+// AMD_SERIALIZE_KERNEL they do not — and the cc_mode step (the main dynamics waits inside the kernel for words the
+// contact pass, launched on another stream, writes) must not be used then.  Probe: kernel A spins (bounded, ~2 ms) until
+// kernel B, launched AFTER it on another stream, has set a flag.
+__global__ void k_probe_wait(int* flag, int* result) {
+  int seen = 0;
+  for (int i = 0; i < 20000 && !seen; ++i) { seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __builtin_amdgcn_s_sleep(32); }
+  *result = seen;
+}
+__global__ void k_probe_set(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static bool kernels_overlap(hipStream_t sa, hipStream_t sb) {
+  int* d = nullptr; int r = 0;
+  if (hipMalloc(&d, 2 * sizeof(int)) != hipSuccess) return false;
+  bool ok = hipMemset(d, 0, 2 * sizeof(int)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+  if (ok) {
+    hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, sa, d, d + 1);
+    hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, sb, d);
+    ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(&r, d + 1, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && r == 1;
+  }
+  (void)hipFree(d);
+  return ok;
+}
 
 extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   if (!cfg || !out) { g_err = "null argument"; return MCR_ERR_ARG; }
   if (cfg->num_envs < 1 || cfg->num_agents < 1 || cfg->num_agents > MCR_MAX_AGENTS) { g_err = "num_envs/num_agents out of range"; return MCR_ERR_ARG; }
   HIPCHK(hipSetDevice(cfg->device));
   mcr_env* h = new mcr_env();
-  h->cfg = *cfg; h->timing = 0; h->any_reset = false; h->use_graph = 0; h->verdict_fresh = false; h->sg[0].valid = h->sg[1].valid = false;
+  h->cfg = *cfg; h->timing = 0; h->any_reset = false; h->use_graph = 0; h->verdict_fresh = false; h->concurrent_collide = false; h->sg[0].valid = h->sg[1].valid = false;
   for (int i = 0; i < MCR_TIMING_SLOTS; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
   const int B = cfg->num_envs, N = cfg->num_agents;
   int G = 1; while (G < N) G <<= 1;
@@ -142,6 +166,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
         (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&h->ev_col, hipEventDisableTiming);
+        h->concurrent_collide = !getenv("MCR_SEQUENTIAL_COLLIDE") && kernels_overlap(h->s_defer, h->s_side);
         h->split = true;
       } else (void)hipStreamDestroy(h->s_side);
     }
@@ -291,11 +316,15 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   // comes from it (Car.step reads the wheels' tile bits of the PREVIOUS pass; which envs are the contact chain's follows
   // from the entry poses), only the step's bookkeeping at the end of the dynamics kernel does, and that waits for
   // k_collide's per-env "done" word.  24 us + a kernel boundary off the critical path.
-  P.cc_mode = 1; P.epoch = 1 + (h->step_parity & 1);
+  // Where kernels of different streams do not overlap (mcr_create probes it: counter-collecting profilers, debuggers) the
+  // contact pass simply runs first, on the caller's stream.
+  const bool cc = h->concurrent_collide;
+  P.cc_mode = cc ? 1 : 0; P.epoch = 1 + (h->step_parity & 1);
+  if (!cc) LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), st, P, 0);
   (void)hipEventRecord(h->ev_fork, st);
   (void)hipStreamWaitEvent(h->s_side, h->ev_fork, 0);
-  LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), h->s_side, P, 0);
-  (void)hipEventRecord(h->ev_col, h->s_side);
+  if (cc) LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), h->s_side, P, 0);
+  (void)hipEventRecord(h->ev_col, cc ? h->s_side : st);
   P.split = 0;
   // bookkeeping of a chain's cars: fused into the chain for N <= 2 (2 envs x N cars take their turns on one wavefront),
   // a list launch of its own beyond that
@@ -655,6 +684,7 @@ extern "C" int mcr_debug_read_counters(mcr_env* h, uint64_t* out4) {
   HIPCHK(hipMemcpy(out4, h->P.counters, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost));
   return MCR_OK;
 }
+extern "C" int mcr_concurrent_collide(const mcr_env* h) { return (h && h->split && h->concurrent_collide) ? 1 : 0; }
 extern "C" int mcr_debug_read_verdict_mismatches(mcr_env* h, uint64_t* out) {
   if (!h || !out) return MCR_ERR_ARG;
   HIPCHK(hipDeviceSynchronize());
