@@ -1,9 +1,9 @@
 """Summarise gpurun_out/prof_<round>/ into profiles/<round>_*.md|json (tracked).
 
 A step of the default configuration issues several launches of the same kernel (main chain, contact side stream,
-resume stream), so launches are labelled by queue and position in the step: on the caller's queue collide, dynamics,
-bookkeeping, view; on the side queue chain(contact envs), view, reset pass(re-spawned envs), view; on the third queue
-chain(resume), view."""
+resume stream), so launches are labelled by queue and position in the step: on the caller's queue dynamics, bookkeeping,
+view; on the side queue collide, chain(contact envs), view, reset pass(re-spawned envs), view; on the third queue
+chain(resume), view.  (Counter passes: the contact pass runs first on the caller's queue, see label().)"""
 import json, os, sys
 import pandas as pd
 
@@ -33,28 +33,42 @@ DEFER_ORDER = {"k_list_chain": ["chain (resume of deferred envs, third stream)"]
 STEP_KERNELS = ("k_collide", "k_dynamics", "k_view", "k_flags", "k_list_chain", "k_reset_list")
 
 def label(df, order_col):
-    """adds column Label for the launches of the last STEPS steps.  A step starts with its k_collide launch on the
-    caller's queue; steps are counted back from the end of the run (reset() and the pre-roll's masked resets add launches
-    of their own further up)."""
+    """adds column Label for the launches of the last STEPS steps.  The caller's queue is the one that carries k_flags.  A
+    step starts with the caller's-queue k_dynamics launch that precedes a k_flags launch — or with the k_collide launch right
+    before it where the contact pass runs first (single stream; counter passes: mcr_create finds kernels serialised and
+    does not put the contact pass beside the dynamics) — and every launch of the other queues belongs to the step during
+    which it appears (a step joins its streams before it returns)."""
     df = df.sort_values(order_col).reset_index(drop=True)
     df["K"] = df["Kernel_Name"].map(kname)
     df["Label"] = None
-    col = df.index[df.K == "k_collide"].tolist()
-    if not col:
+    fl = df[df.K == "k_flags"]
+    if fl.empty:
         return df
-    main_q = df.loc[col, "Queue_Id"].value_counts().index[0]
+    main_q = fl.Queue_Id.value_counts().index[0]
     rq = df[df.K == "k_reset_list"].Queue_Id.value_counts()
     side_q = rq.index[0] if len(rq) else None                 # the side stream is the one that carries the reset pass
-    col = [i for i in col if df.at[i, "Queue_Id"] == main_q]
-    if len(col) < STEPS:
+    mq = df.index[df.Queue_Id == main_q].tolist()
+    pos = {i: n for n, i in enumerate(mq)}
+    starts = []
+    for i in fl.index[fl.Queue_Id == main_q]:
+        n = pos[i]
+        if n == 0 or df.at[mq[n - 1], "K"] != "k_dynamics":
+            continue
+        s0 = mq[n - 1]
+        if n >= 2 and df.at[mq[n - 2], "K"] == "k_collide":
+            s0 = mq[n - 2]
+        starts.append(s0)
+    if len(starts) < STEPS:
         return df
-    starts = col[-STEPS:] + [len(df)]
+    starts = starts[-STEPS:] + [len(df)]
     for a, e in zip(starts[:-1], starts[1:]):
         seen = {}
         for i in range(a, e):
             k = df.at[i, "K"]
             if k not in STEP_KERNELS: continue
             q = df.at[i, "Queue_Id"]
+            if k == "k_collide":
+                df.at[i, "Label"] = "collide (all envs)"; continue
             key = (k, q); n = seen.get(key, 0); seen[key] = n + 1
             names = (MAIN_ORDER if q == main_q else (SIDE_ORDER if q == side_q else DEFER_ORDER)).get(k, [])
             df.at[i, "Label"] = names[n] if n < len(names) else f"{k} #{n}"
