@@ -354,12 +354,13 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
     if (lane == 0) { store[0] = (uint32_t)nn; store[1] = base > MCR_CC_MAX ? 1u : 0u; }
     nn_final = nn;
   } else if (lane == 0 && pass == 1) store[0] = 0;
-  // side-stream partition: envs whose dynamics chain is going to be long (a touching car<->car pair).  The verdict the
-  // main launches go by (p.part: mcr_touch_verdict, evaluated by last step's bookkeeping on the same poses) must agree:
-  // counters[4] counts disagreements (tests and bench assert 0).
+  // side-stream partition: envs whose dynamics chain is going to be long (a touching car<->car pair).  cc_mode: the verdict
+  // the main launches go by (p.part: mcr_touch_verdict, evaluated by last step's bookkeeping on the same poses) must
+  // agree — counters[4] counts disagreements (tests and bench assert 0).
   if (pass == 0 && p.split && lane == 0) {
     if (nn_final > 0) { p.clist[1 + atomicAdd(&p.clist[0], 1)] = env; atomicAdd(&p.counters[2], 1ull); }
-    if ((nn_final > 0) != (p.part[env] != 0)) atomicAdd(&p.counters[4], 1ull);
+    if (!p.cc_mode) p.part[env] = nn_final > 0 ? 1 : 0;         // the contact pass runs first: it is the one that marks the contact chain's envs
+    else if ((nn_final > 0) != (p.part[env] != 0)) atomicAdd(&p.counters[4], 1ull);
   }
   if (pass == 0 && p.cc_mode) {            // the main dynamics, running beside this launch, may read this env's results now
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // the stores above have completed (no cache write-back: they were write-through)

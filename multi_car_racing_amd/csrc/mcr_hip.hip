@@ -166,7 +166,9 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
         (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&h->ev_col, hipEventDisableTiming);
-        h->concurrent_collide = !getenv("MCR_SEQUENTIAL_COLLIDE") && kernels_overlap(h->s_defer, h->s_side);
+        // (beyond 4 cars per env the one-step-ahead touch verdict — a second pass over up to 28 car pairs — costs more than
+        // the contact pass gains by running beside the dynamics: measured at N = 8)
+        h->concurrent_collide = N <= 4 && !getenv("MCR_SEQUENTIAL_COLLIDE") && kernels_overlap(h->s_defer, h->s_side);
         h->split = true;
       } else (void)hipStreamDestroy(h->s_side);
     }
@@ -284,7 +286,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     P.clist = h->P.clist + par * (B + 1); P.clist_next = h->P.clist + oth * (B + 1);
     P.dlist = h->P.dlist + par * (B + 1); P.rlist = h->P.rlist + par * (B + 1);
     P.vcount = h->P.vcount + par * (B + 2); P.vorder = P.vcount + 2;
-    P.part = h->P.part + par * B; P.part_next = h->split ? h->P.part + oth * B : nullptr;
+    P.part = h->P.part + par * B; P.part_next = (h->split && h->concurrent_collide) ? h->P.part + oth * B : nullptr;
     P.next_counts[0] = h->P.dlist + oth * (B + 1); P.next_counts[1] = h->P.rlist + oth * (B + 1);
     P.next_counts[2] = h->P.vcount + oth * (B + 2); P.next_counts[3] = P.next_counts[2] + 1;
     h->step_parity ^= 1;
@@ -389,7 +391,7 @@ extern "C" int mcr_step(mcr_env* h, const float* d_actions, uint8_t* d_obs, doub
   // with auto_reset, finished envs are re-spawned on the device and take the action-less first step of their
   // new episode inside this call; the view kernel always runs (it also owns the backward/on-grass flags)
   const int vf = d_actions ? 1 : 0;
-  if (h->split && !h->verdict_fresh) {   // after reset() / reset_envs() / a state restore / a step without actions: which envs hold a touching car<->car pair?
+  if (h->split && h->concurrent_collide && !h->verdict_fresh) {   // after reset() / reset_envs() / a state restore / a step without actions: which envs hold a touching car<->car pair?
     McrParams Pt = P; Pt.role = 0; Pt.part = h->P.part + (size_t)h->step_parity * P.B;
     hipLaunchKernelGGL(k_touch, dim3(P.B), dim3(64), 0, st, Pt);
   }
