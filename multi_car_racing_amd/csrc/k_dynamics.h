@@ -882,8 +882,12 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
   double step_reward = 0.0, reward = 0.0, prev_reward = 0.0, epret = 0.0;
   uint32_t tvc = 0, flags = 0;
   if (p.cc_mode && mode == 0 && p.role == 1 && run)               // k_collide pass 0 runs beside this launch: wait until it is through with this env
-    for (int spin = 0; spin < (1 << 24) && __hip_atomic_load(&p.collide_epoch[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch; ++spin)
+  {
+    int spin = 0;
+    for (; spin < (1 << 24) && __hip_atomic_load(&p.collide_epoch[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch; ++spin)
       __builtin_amdgcn_s_sleep(8);                                  // (bounded: ~3 s; k_collide was enqueued before this launch and takes ~25 us)
+    if (spin == (1 << 24)) atomicAdd(&p.counters[4], 1ull);         // gave up: the results of this env are wrong from here on, and the counter says so
+  }
   const bool cc_wait = p.cc_mode && mode == 0 && p.role == 1;
   uint32_t onroad_new = 0;
   if (run && cc_wait) {                                           // k_collide's three words of this car: device-scope loads (see k_collide)
