@@ -215,6 +215,16 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
     return r;
   };
 
+  // slot layout of a view's specials (see the candidate phase): spread over the wavefronts when the view fits one round
+  auto spread_layout = [&](int pv, int f, int g) -> bool { return N <= 4 && pv <= 128 - 14 * N && g <= 56 && f - 14 * N <= 64; };
+  auto special_of = [&](int c, bool spread, int sb, int f, int g) -> int {   // candidate c -> index among the view's specials, or -1
+    if (!spread) return (c >= sb && c - sb < f + g) ? c - sb : -1;
+    const int nh = f - 14 * N;                                              // gauges, flag [, playfield]
+    if (c >= sb && c < 128) return c - sb;
+    if (c >= 192 - nh && c < 192) return 14 * N + c - (192 - nh);
+    if (c >= 248 - g && c < 248) return f + c - (248 - g);
+    return -1;
+  };
   int vs = 0;                                                               // views this workgroup has drawn
 #pragma nounroll
   for (;;) {
@@ -263,7 +273,11 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
     const int F = 14 * N + 8 + (inside_field ? 0 : 1);
     const int nspec = (F + G + 1) & ~1;                                     // even: the 8-gon's slot pair never straddles two rounds
     const int nround = (Pv + nspec + RC - 1) / RC;
-    const int SB = nround * RC - nspec;
+    // A view that fits one round with room to spare (the rule once the camera has zoomed in) SPREADS its specials over
+    // the wavefronts instead: cars end at slot 128 (wavefront 1), gauges / flag / playfield at 192 (wavefront 2), grass at
+    // 248 (wavefront 3) — every wavefront then runs one kind of candidate, not all of them one after the other.
+    const bool spread = spread_layout(Pv, F, G);
+    const int SB = spread ? 128 - 14 * N : nround * RC - nspec;             // first slot of the cars (= of the specials when they are contiguous)
     if (vs == 0 && tid < RC) nxt = fetch_raw(tid, Pv, SB, buf, slot, P, env);   // later views: requested while the previous one was drawn
 #pragma nounroll
     for (int rd = 0; rd < nround; ++rd) {
@@ -302,9 +316,8 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
             my_meta = setup_poly(px, py, false, mk_key(RANK_SLOT0 + tid, pal), i0, i1, j0, j1, rdat, tid);
           }
         }
-      } else if (mine && c >= SB && c - SB < F + G) {
+      } else if (const int sidx = special_of(c, spread, SB, F, G); mine && sidx >= 0) {
         // ---- specials
-        const int sidx = c - SB;
         float px[8], py[8]; uint32_t key = 0; int cminY = 12, nn = 0;    // nn: 4 / 8 vertices in world space, -4: 4 vertices in pixel space
         float wx[8], wy[8];
         if (sidx < 14 * N) {                                                // Car.draw polygon
@@ -385,8 +398,9 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
           const float* __restrict__ vn = vrec[buf ^ 1];
           const int pvn = UNI(nvb[buf ^ 1]) * MCR_QBLK;
           const int gn = UNI(__float_as_int(vn[VP_GRASS + 1])) * UNI(__float_as_int(vn[VP_GRASS + 3]));
-          const int nsn = (14 * N + 8 + (UNI(__float_as_int(vn[VP_GRASS + 4])) ? 0 : 1) + gn + 1) & ~1;
-          const int sbn = (pvn + nsn + RC - 1) / RC * RC - nsn;
+          const int fn = 14 * N + 8 + (UNI(__float_as_int(vn[VP_GRASS + 4])) ? 0 : 1);
+          const int nsn = (fn + gn + 1) & ~1;
+          const int sbn = spread_layout(pvn, fn, gn) ? 128 - 14 * N : (pvn + nsn + RC - 1) / RC * RC - nsn;
           nxt = fetch_raw(tid, pvn, sbn, buf ^ 1, slot_v, last ? UNI(P_nv) : P, env_v);
         }
       }
