@@ -189,6 +189,11 @@ int mcr_debug_read_verdict_mismatches(mcr_env* h, uint64_t* out1);
 int mcr_concurrent_collide(const mcr_env* h);
 /* number of touching car<->car fixture pairs (stored manifolds) per env after the last collide pass */
 int mcr_debug_read_contact_counts(mcr_env* h, int32_t* out /*[num_envs]*/);
+/* The sensor predicate of the contact pass (Box2D's b2TestOverlap: GJK b2Distance behind mcr.py:428 -> b2Contact::Update) on
+ * caller-supplied cases, for differential tests: case i = a tile given by its 4 points quads[i][8] (host, f32; the hull is
+ * built as the episode generator builds it) against car fixture `fixture` (0..3 hull polygons, 4 the wheel box) of a body
+ * whose origin and angle are poses[i][3]; out[i] = touching (host).  Synchronous. */
+int mcr_debug_overlap(mcr_env* h, int n, const float* quads, const float* poses, int fixture, uint8_t* out);
 #define MCR_TIMING_SLOTS 8
 int mcr_timing_read(mcr_env* h, double* ms_out /*[MCR_TIMING_SLOTS]*/, int64_t* launches_out /*[MCR_TIMING_SLOTS]*/);
 

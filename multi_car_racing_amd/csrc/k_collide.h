@@ -9,11 +9,12 @@
 //    that the f64 reward accumulation is order-exact (:113-120);
 //  * the per-wheel "touches any tile" mask (friction_limit, Car.step) is a wave-wide OR.
 //
-// Overlap predicate == result of b2TestOverlap (b2Distance with radii, touching iff
-// distance < 10*FLT_EPSILON): SAT for penetration / early-out, exact vertex-edge distance otherwise.
+// Overlap predicate == b2TestOverlap itself (GJK b2Distance with radii, touching iff distance < 10*FLT_EPSILON: k_gjk.h),
+// behind a SAT far-field filter that never changes its result (col::overlap).
 #pragma once
 #include "mcr_kernels.h"
 #include "k_carcontacts.h"
+#include "k_gjk.h"
 
 namespace col {
 
@@ -48,35 +49,20 @@ __device__ __forceinline__ float sat_tile_fixture(const TilePoly& T, const float
   TILE_FOR(i) { if (i < T.n) best = mcr_max(best, mn[i]); }
   return best;
 }
-__device__ __forceinline__ float pt_seg_d2(float px, float py, float ax, float ay, float bx, float by) {
-  float abx = bx - ax, aby = by - ay, apx = px - ax, apy = py - ay;
-  float t = apx * abx + apy * aby;
-  float den = abx * abx + aby * aby;
-  if (t <= 0.0f) return apx * apx + apy * apy;
-  if (t >= den) { float bpx = px - bx, bpy = py - by; return bpx * bpx + bpy * bpy; }
-  float cr = abx * apy - aby * apx;
-  return (cr * cr) / den;
-}
-__device__ __forceinline__ bool overlap(const float* avx, const float* avy, const float* anx, const float* any_, int an, const TilePoly& T) {
+// b2TestOverlap(tile, car fixture) — Box2D's GJK (k_gjk.h) behind a far-field filter.  The maximum SAT separation s over the
+// edge normals of both polygons (f32, error ~1e-5 at 250-unit coordinates) is a lower bound of the core distance:
+//   s > 0.02 + 1e-3  -> the cores are farther apart than the two radii by ~50x the f32 noise: GJK says "apart";
+//   s <= 0           -> no edge normal separates the cores: they intersect or are within the noise of it (corners of >= 50
+//                       degrees: distance <= 1.6 s): GJK returns a distance far below 0.02 and says "touching";
+//   in between       -> GJK decides.  (oracle sweep, tests/test_oracle_pinning.py: an exact-distance predicate and GJK
+//                       never differ beyond 5e-5 of the threshold, so the filter's 1e-3 changes no result.)
+__device__ __forceinline__ bool overlap(const float* avx, const float* avy, const float* anx, const float* any_, int an, const TilePoly& T,
+                                        const float4 va, const float4 vb, const McrPoly* __restrict__ PB, const float4 xfB) {
   const float R = 2.0f * B2_POLYGON_RADIUS;
-  const float TH = R + 10.0f * B2_EPSILON;
-  float s = mcr_max(sat_fixture_tile(avx, avy, anx, any_, an, T), sat_tile_fixture(T, avx, avy, an));
-  if (s > TH) return false;
+  const float s = mcr_max(sat_fixture_tile(avx, avy, anx, any_, an, T), sat_tile_fixture(T, avx, avy, an));
+  if (s > R + 1e-3f) return false;
   if (s <= 0.0f) return true;
-  // exact distance between the disjoint convex polygons: min over vertex-edge pairs, both ways
-  float ex[4], ey[4];                                  // end point of tile edge j: vertex (j+1) % n
-  ex[0] = T.vx[1]; ey[0] = T.vy[1]; ex[1] = T.vx[2]; ey[1] = T.vy[2];
-  ex[2] = T.n == 3 ? T.vx[0] : T.vx[3]; ey[2] = T.n == 3 ? T.vy[0] : T.vy[3]; ex[3] = T.vx[0]; ey[3] = T.vy[0];
-  float d2 = MCR_MAXFLT;
-  for (int i = 0; i < an; ++i) {
-    const float px = avx[i], py = avy[i];
-    TILE_FOR(j) { if (j < T.n) d2 = mcr_min(d2, pt_seg_d2(px, py, T.vx[j], T.vy[j], ex[j], ey[j])); }
-  }
-  TILE_FOR(i) {
-    if (i < T.n)
-      for (int j = 0; j < an; ++j) { const int k = (j + 1 == an) ? 0 : j + 1; d2 = mcr_min(d2, pt_seg_d2(T.vx[i], T.vy[i], avx[j], avy[j], avx[k], avy[k])); }
-  }
-  return d2 < TH * TH;
+  return gjk::touching(va, vb, T.n, PB, xfB);
 }
 
 }  // namespace col
@@ -171,7 +157,8 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
           TP.n = (int)(TCNT[t] & 0xffu);
           TP.vx[0] = va.x; TP.vy[0] = va.y; TP.vx[1] = va.z; TP.vy[1] = va.w; TP.vx[2] = vb.x; TP.vy[2] = vb.y; TP.vx[3] = vb.z; TP.vy[3] = vb.w;
           TP.nx[0] = na.x; TP.ny[0] = na.y; TP.nx[1] = na.z; TP.ny[1] = na.w; TP.nx[2] = nb.x; TP.ny[2] = nb.y; TP.nx[3] = nb.z; TP.ny[3] = nb.w;
-          if (overlap(fvx[f], fvy[f], fnx[f], fny[f], fcnt[f], TP))
+          const McrShapes& S = *p.shapes;
+          if (overlap(fvx[f], fvy[f], fnx[f], fny[f], fcnt[f], TP, va, vb, fi < 4 ? &S.hull[fi] : &S.wheel, fxf[f]))
           { if (fi >= 4) atomicOr(&tres[t], 1u << (c * 4 + (fi - 4))); atomicOr(&tany[t >> 5], 1u << (t & 31)); }
         }
       }

@@ -706,6 +706,54 @@ extern "C" int mcr_debug_read_dynamics_stamps(mcr_env* h, uint64_t* out, int n_u
   HIPCHK(hipMemcpy(out, h->P.dbg_stamps, sizeof(uint64_t) * (size_t)n_u64, hipMemcpyDeviceToHost));
   return MCR_OK;
 }
+// the sensor predicate of k_collide (col::overlap: SAT far-field filter + Box2D's GJK) on caller-supplied cases
+__global__ void k_debug_overlap(const McrShapes* shapes, int fixture, int n, const float4* __restrict__ va, const float4* __restrict__ vb,
+                                const float4* __restrict__ na, const float4* __restrict__ nb, const int* __restrict__ cnt,
+                                const float* __restrict__ poses, uint8_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const McrShapes& S = *shapes;
+  const McrPoly& P = fixture < 4 ? S.hull[fixture] : S.wheel;
+  const V2 lc = fixture < 4 ? v2(S.hull_lcx, S.hull_lcy) : v2(0.0f, 0.0f);
+  // the body origin is given (b2BodyDef.position); sweep.c = xf * localCenter, then the transform k_collide derives from (c, a)
+  Xf x0; x0.q = rot_of(poses[i * 3 + 2]); x0.p = v2(poses[i * 3], poses[i * 3 + 1]);
+  const Xf xf = xf_of(xmul(x0, lc), poses[i * 3 + 2], lc);
+  float wx[8], wy[8], nx[8], ny[8];
+  for (int k = 0; k < 8; ++k) { wx[k] = wy[k] = nx[k] = ny[k] = 0.0f; }
+  for (int k = 0; k < P.n; ++k) { const V2 w = xmul(xf, v2(P.vx[k], P.vy[k])); const V2 nn = rmul(xf.q, v2(P.nx[k], P.ny[k])); wx[k] = w.x; wy[k] = w.y; nx[k] = nn.x; ny[k] = nn.y; }
+  col::TilePoly TP; const float4 a = va[i], b = vb[i], c = na[i], d = nb[i];
+  TP.n = cnt[i];
+  TP.vx[0] = a.x; TP.vy[0] = a.y; TP.vx[1] = a.z; TP.vy[1] = a.w; TP.vx[2] = b.x; TP.vy[2] = b.y; TP.vx[3] = b.z; TP.vy[3] = b.w;
+  TP.nx[0] = c.x; TP.ny[0] = c.y; TP.nx[1] = c.z; TP.ny[1] = c.w; TP.nx[2] = d.x; TP.ny[2] = d.y; TP.nx[3] = d.z; TP.ny[3] = d.w;
+  out[i] = col::overlap(wx, wy, nx, ny, P.n, TP, a, b, &P, make_float4(xf.p.x, xf.p.y, xf.q.s, xf.q.c)) ? 1 : 0;
+}
+void mcr_tile_hull(const float* fx, const float* fy, float* aabb4, float* va4, float* vb4, float* na4, float* nb4, int* count);   // mcr_host.cpp
+extern "C" int mcr_debug_overlap(mcr_env* h, int n, const float* quads, const float* poses, int fixture, uint8_t* out) {
+  if (!h || !quads || !poses || !out || n < 0 || fixture < 0 || fixture > 4) { g_err = "bad argument"; return MCR_ERR_ARG; }
+  if (n == 0) return MCR_OK;
+  std::vector<float> hull((size_t)n * 16); std::vector<int> cnt(n);
+  float* VA = hull.data(); float* VB = VA + (size_t)n * 4; float* NA = VB + (size_t)n * 4; float* NB = NA + (size_t)n * 4;
+  for (int i = 0; i < n; ++i) {
+    float fx[4], fy[4], box[4];
+    for (int k = 0; k < 4; ++k) { fx[k] = quads[(size_t)i * 8 + 2 * k]; fy[k] = quads[(size_t)i * 8 + 2 * k + 1]; }
+    mcr_tile_hull(fx, fy, box, VA + (size_t)i * 4, VB + (size_t)i * 4, NA + (size_t)i * 4, NB + (size_t)i * 4, &cnt[i]);
+  }
+  uint8_t* d = nullptr;
+  const size_t b_hull = sizeof(float) * 16 * (size_t)n, b_cnt = sizeof(int) * (size_t)n, b_pose = sizeof(float) * 3 * (size_t)n;
+  HIPCHK(hipMalloc(&d, b_hull + b_cnt + b_pose + (size_t)n));
+  float* d_hull = (float*)d; int* d_cnt = (int*)(d + b_hull); float* d_pose = (float*)(d + b_hull + b_cnt); uint8_t* d_out = d + b_hull + b_cnt + b_pose;
+  hipError_t e = hipMemcpy(d_hull, hull.data(), b_hull, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_cnt, cnt.data(), b_cnt, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_pose, poses, b_pose, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_debug_overlap, dim3((n + 255) / 256), dim3(256), 0, 0, h->P.shapes, fixture, n, (const float4*)d_hull, (const float4*)(d_hull + (size_t)n * 4),
+                       (const float4*)(d_hull + (size_t)n * 8), (const float4*)(d_hull + (size_t)n * 12), d_cnt, d_pose, d_out);
+    e = hipMemcpy(out, d_out, (size_t)n, hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(d);
+  if (e != hipSuccess) { g_err = std::string("mcr_debug_overlap: ") + hipGetErrorString(e); return MCR_ERR_HIP; }
+  return MCR_OK;
+}
 extern "C" int mcr_debug_set(mcr_env* h, int value) { if (!h) return MCR_ERR_ARG; h->P.debug = value; return MCR_OK; }
 extern "C" int mcr_timing_enable(mcr_env* h, int enable) { if (!h) return MCR_ERR_ARG; h->timing = enable; return MCR_OK; }
 extern "C" int mcr_timing_read(mcr_env* h, double* ms_out, int64_t* launches_out) {

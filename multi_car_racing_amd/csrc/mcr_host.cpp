@@ -317,6 +317,23 @@ bool track_attempt(uint32_t* mt, std::vector<TrackPt>& lap) {
 inline int wrap(int i, int n) { i %= n; return i < 0 ? i + n : i; }
 }  // namespace
 
+// The sensor fixture of one tile as the device slot stores it: b2PolygonShape::Set of its 4 points -> tight AABB, hull
+// vertices v0 v1 | v2 v3 (CCW), normals n0 n1 | n2 n3, vertex count (3 or 4; a triangle repeats vertex 0 / normal 2).
+// (also used by mcr_debug_overlap, mcr_hip.hip)
+void mcr_tile_hull(const float* fx, const float* fy, float* aabb4, float* va4, float* vb4, float* na4, float* nb4, int* count) {
+  HostPoly hp;
+  if (!hull_from_points(fx, fy, 4, hp)) { hp.n = 3; for (int k = 0; k < 3; ++k) { hp.x[k] = fx[k]; hp.y[k] = fy[k]; hp.nx[k] = hp.ny[k] = 0; } }
+  float lox = MCR_MAXFLT, loy = MCR_MAXFLT, hix = -MCR_MAXFLT, hiy = -MCR_MAXFLT;
+  for (int k = 0; k < hp.n; ++k) { lox = fminf(lox, hp.x[k]); loy = fminf(loy, hp.y[k]); hix = fmaxf(hix, hp.x[k]); hiy = fmaxf(hiy, hp.y[k]); }
+  aabb4[0] = lox; aabb4[1] = loy; aabb4[2] = hix; aabb4[3] = hiy;
+  if (hp.n == 3) { hp.x[3] = hp.x[0]; hp.y[3] = hp.y[0]; hp.nx[3] = hp.nx[2]; hp.ny[3] = hp.ny[2]; }
+  va4[0] = hp.x[0]; va4[1] = hp.y[0]; va4[2] = hp.x[1]; va4[3] = hp.y[1];
+  vb4[0] = hp.x[2]; vb4[1] = hp.y[2]; vb4[2] = hp.x[3]; vb4[3] = hp.y[3];
+  na4[0] = hp.nx[0]; na4[1] = hp.ny[0]; na4[2] = hp.nx[1]; na4[3] = hp.ny[1];
+  nb4[0] = hp.nx[2]; nb4[1] = hp.ny[2]; nb4[2] = hp.nx[3]; nb4[3] = hp.ny[3];
+  *count = hp.n;
+}
+
 extern "C" size_t mcr_episode_bytes(void) { return MCR_SLOT_BYTES; }
 
 extern "C" int mcr_episode_generate(uint32_t* mt_track, int num_agents, int cw, const int32_t* car_order,
@@ -372,15 +389,7 @@ extern "C" int mcr_episode_generate(uint32_t* mt_track, int num_agents, int cw, 
     ++q;
     // sensor fixture of the tile body (:317-325): b2PolygonShape::Set of the same 4 points
     HostPoly hp;
-    if (!hull_from_points(fx, fy, 4, hp)) { hp.n = 3; for (int k = 0; k < 3; ++k) { hp.x[k] = fx[k]; hp.y[k] = fy[k]; hp.nx[k] = hp.ny[k] = 0; } }
-    float lox = MCR_MAXFLT, loy = MCR_MAXFLT, hix = -MCR_MAXFLT, hiy = -MCR_MAXFLT;
-    for (int k = 0; k < hp.n; ++k) { lox = fminf(lox, hp.x[k]); loy = fminf(loy, hp.y[k]); hix = fmaxf(hix, hp.x[k]); hiy = fmaxf(hiy, hp.y[k]); }
-    TA[i * 4 + 0] = lox; TA[i * 4 + 1] = loy; TA[i * 4 + 2] = hix; TA[i * 4 + 3] = hiy;
-    if (hp.n == 3) { hp.x[3] = hp.x[0]; hp.y[3] = hp.y[0]; hp.nx[3] = hp.nx[2]; hp.ny[3] = hp.ny[2]; }
-    VA[i * 4 + 0] = hp.x[0]; VA[i * 4 + 1] = hp.y[0]; VA[i * 4 + 2] = hp.x[1]; VA[i * 4 + 3] = hp.y[1];
-    VB[i * 4 + 0] = hp.x[2]; VB[i * 4 + 1] = hp.y[2]; VB[i * 4 + 2] = hp.x[3]; VB[i * 4 + 3] = hp.y[3];
-    NA[i * 4 + 0] = hp.nx[0]; NA[i * 4 + 1] = hp.ny[0]; NA[i * 4 + 2] = hp.nx[1]; NA[i * 4 + 3] = hp.ny[1];
-    NB[i * 4 + 0] = hp.nx[2]; NB[i * 4 + 1] = hp.ny[2]; NB[i * 4 + 2] = hp.nx[3]; NB[i * 4 + 3] = hp.ny[3];
+    mcr_tile_hull(fx, fy, TA + i * 4, VA + i * 4, VB + i * 4, NA + i * 4, NB + i * 4, &hp.n);
     TC[i] = (uint32_t)hp.n | (kerb[i] ? 0x100u : 0u);
     if (kerb[i]) {
       double side = sgn(b.beta - a.beta);

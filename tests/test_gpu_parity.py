@@ -522,6 +522,28 @@ def test_random_rollout_with_contacts_enabled(torch_cuda, oracle, streams):
     env.close()
 
 
+def test_device_sensor_predicate_is_box2d_gjk(torch_cuda, oracle, lib):
+    """The contact pass decides "wheel touches tile" with Box2D's own b2TestOverlap (GJK b2Distance, k_gjk.h) behind a SAT
+    far-field filter: >= 1e6 wheel/tile poses whose exact core separation is 0.02 +- 1e-5 (inside the f32 noise of the
+    threshold), plus wider bands and clear cases, through the DEVICE predicate (mcr_debug_overlap) and the oracle's GJK
+    restatement: zero differences."""
+    env = _make(1, 1, 0)
+    L = lib.load()
+    total = 0
+    for n, seed, band in ((1_250_000, 1, 1e-5), (300_000, 2, 1e-3), (150_000, 3, 0.015), (100_000, 4, 0.5)):
+        quads, poses, g = oracle.overlap_cases(n, seed=seed, band=band)
+        k = len(g)
+        assert k > 0.8 * n
+        out = np.zeros(k, np.uint8)
+        lib.check(L.mcr_debug_overlap(env.h, k, lib.ptr(np.ascontiguousarray(quads.reshape(k, 8))), lib.ptr(np.ascontiguousarray(poses)), 4, lib.ptr(out)), "mcr_debug_overlap")
+        diff = int((out.astype(bool) != g).sum())
+        assert diff == 0, f"band {band}: device predicate differs from Box2D's GJK in {diff} of {k} cases"
+        assert 0.2 * k < g.sum() < 0.8 * k            # the cases do straddle the threshold
+        total += k if band <= 1e-5 else 0
+    assert total >= 1_000_000
+    env.close()
+
+
 def test_synth_actions_device_equals_host_twin(torch_cuda, lib):
     torch = torch_cuda
     env = _make(37, 3, 0, env_offset=500)

@@ -83,9 +83,9 @@ def test_contact_and_step_bookkeeping_traces(oracle):
             r, done = env.bookkeeping(True)
             es = env.env_state()
             assert done == tr["done"], (ep["N"], k)
-            # f64 reward sums: same addends, the reference adds them in its contact-callback order
-            np.testing.assert_allclose(r, tr["step_reward"], rtol=0, atol=1e-9)
-            np.testing.assert_allclose(es["reward"], tr["reward"], rtol=0, atol=1e-9)
+            # f64 reward sums, bit for bit: the script's order IS the reference's contact-callback order
+            assert r.tolist() == tr["step_reward"], (ep["N"], k)
+            assert es["reward"].tolist() == tr["reward"], (ep["N"], k)
             assert es["tile_visited_count"].tolist() == tr["tile_visited_count"]
             assert es["driving_backward"].astype(bool).tolist() == tr["driving_backward"], (ep["N"], k)
             assert es["driving_on_grass"].astype(bool).tolist() == tr["driving_on_grass"], (ep["N"], k)

@@ -1,7 +1,9 @@
 """CPU: what can be pinned about the oracle's third-party restatements without Box2D / gym / pyglet.
 
-* b2TestOverlap: Box2D's actual algorithm (GJK b2Distance, restated in the oracle) against the SAT + vertex-edge predicate
-  the oracle and the kernels use, >= 1e7 random wheel/tile poses at the 0.02 threshold -> measured disagreement rates;
+* b2TestOverlap: Box2D's actual algorithm (GJK b2Distance, restated in the oracle — and, since round 3, what the step of
+  both the oracle and the kernels uses) against an independent exact-distance predicate (SAT + vertex-edge), >= 1e7 random
+  wheel/tile poses at the 0.02 threshold -> the width of the zone in which the two can differ, which sizes the SAT
+  far-field filter in front of the device GJK (k_collide.h: 1e-3, i.e. 20x that width);
 * closed-form solver KATs: momentum conservation of the joint/contact solver, a revolute joint driven into its limit,
   a point-symmetric head-on collision;
 * the raster: an independent scanline rasteriser (f64 edge intersections, no half-plane tests) re-draws the oracle's
@@ -15,11 +17,11 @@ from tests.util import oracle_episode
 # ----------------------------------------------------------------------------- b2TestOverlap: GJK vs SAT
 def test_gjk_vs_sat_overlap_at_the_threshold(oracle):
     """1e7 poses with the exact (f64) core separation drawn from 0.02 +- 1e-5, i.e. inside the f32 noise of 250-unit world
-    coordinates (1 ulp = 1.5e-5).  Measured on this build: the two predicates decide differently in 19.4 % of those poses
-    (28 % inside +-1e-6); the disagreement decays to nothing by |delta| = 5e-5 (0 of 4e6 at band 1e-3), which makes the
-    effective half-width of the zone in which they can differ 2.4e-6 units.  A wheel approaching a tile closes >= 0.1
-    units per step, so about 5e-5 of the contact begin/end events fall into that zone — there the event moves by ONE step
-    (never lost: the next step is far past the threshold).  GJK itself never needed more than 5 of its 20 iterations."""
+    coordinates (1 ulp = 1.5e-5).  GJK (what Box2D and the step use) and an exact-distance predicate in f32 decide
+    differently in ~19 % of those poses — both are at the mercy of the same rounding noise there — and never beyond
+    |delta| = 5e-5 (0 of 4e6 at band 1e-3): the zone in which ANY sound f32 predicate can differ from GJK has an effective
+    half-width of 2.4e-6 units.  That is what makes the kernel's SAT far-field filter (apart beyond 0.02 + 1e-3, touching
+    when the cores intersect, GJK in between) exact.  GJK itself never needed more than 5 of its 20 iterations."""
     r = oracle.overlap_sweep(10_000_000, seed=1, band=1e-5, far=5e-5)
     assert r["samples"] == 10_000_000
     rate = r["disagree"] / r["samples"]
