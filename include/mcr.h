@@ -189,6 +189,12 @@ int mcr_debug_read_verdict_mismatches(mcr_env* h, uint64_t* out1);
 int mcr_concurrent_collide(const mcr_env* h);
 /* number of touching car<->car fixture pairs (stored manifolds) per env after the last collide pass */
 int mcr_debug_read_contact_counts(mcr_env* h, int32_t* out /*[num_envs]*/);
+/* Conditions that make results wrong are reported by the kernels in mapped host memory and turned into MCR_ERR_STATE by the
+ * next mcr_step (no synchronisation: a condition raised by a step still in flight surfaces one call later).  Words:
+ * [0] the main dynamics gave up waiting for the contact pass (three-chain step; the handle then runs the contact pass in front),
+ * [1] contact pass vs one-step-ahead touch verdict mismatches, [2] car<->car manifold store / LDS pool overflows (excess
+ * dropped), [3] tile begin-event queue overflows.  mcr_status copies the cumulative counts (n_words <= 8). */
+int mcr_status(mcr_env* h, uint32_t* out, int n_words);
 /* The sensor predicate of the contact pass (Box2D's b2TestOverlap: GJK b2Distance behind mcr.py:428 -> b2Contact::Update) on
  * caller-supplied cases, for differential tests: case i = a tile given by its 4 points quads[i][8] (host, f32; the hull is
  * built as the episode generator builds it) against car fixture `fixture` (0..3 hull polygons, 4 the wheel box) of a body

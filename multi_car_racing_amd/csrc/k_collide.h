@@ -5,8 +5,9 @@
 //    car) into LDS, 8-lane groups reduce each car's AABB;
 //  * the wave then streams the track's tile AABBs from HBM (one float4 per lane per 64 tiles, fully
 //    coalesced); only tiles whose AABB meets a car's box load their hull and run the overlap test;
-//  * begin events are replayed in a defined order (tile ascending, car ascending) with wave ballots so
-//    that the f64 reward accumulation is order-exact (:113-120);
+//  * begin events are replayed in the order Box2D's Collide fires them — contacts of a later FindNewContacts first, then
+//    tile descending, then car / wheel descending (the broadphase model below) — so that "who visited the
+//    tile first" and the f64 reward accumulation are the reference's (:113-120);
 //  * the per-wheel "touches any tile" mask (friction_limit, Car.step) is a wave-wide OR.
 //
 // Overlap predicate == b2TestOverlap itself (GJK b2Distance with radii, touching iff distance < 10*FLT_EPSILON: k_gjk.h),
@@ -23,6 +24,7 @@ namespace col {
 struct TilePoly { int n; float vx[4], vy[4], nx[4], ny[4]; };
 
 #define CAND_CAP 128                 // (tile, car) candidate pairs buffered before the overlap pass runs
+#define EVQ_CAP 128                  // begin events replayed per env and pass (4N wheels x the few tiles a wheel can reach in a step)
 // dynamic LDS of k_collide: 8N fixtures x (2 float4 + 4 x 8 floats + count)
 __host__ __device__ inline size_t lds_bytes(int N) { return (size_t)8 * N * (2 * 16 + 4 * 8 * 4 + 4); }
 #define TILE_FOR(i) _Pragma("unroll") for (int i = 0; i < 4; ++i)
@@ -73,7 +75,12 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   const int env = mcr_env_of_slot(p, blk), lane = threadIdx.x;
   if (env >= p.env0 + p.nenv) return;
   const McrEnvState es = p.env[env];
-  if (!es.active) return;
+  if (!es.active) {
+    // contact pass in front (single stream, N > 4, serialised kernels): this pass owns the contact chain's marks — an env
+    // that froze while its cars were touching must not keep a stale one (it would be skipped by every main launch)
+    if (pass == 0 && p.split && !p.cc_mode && lane == 0) p.part[env] = 0;
+    return;
+  }
   if (pass == 1 && !es.resetting) return;
   const int N = p.N, BN = p.BN;
   const uint8_t* slot = p.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES;
@@ -94,6 +101,22 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   __shared__ uint32_t newrec[MCR_CC_MAX][16];
   __shared__ uint32_t tres[MCR_TILE_CAP], tany[MCR_TILE_CAP / 32];
   __shared__ uint32_t cand[CAND_CAP];
+  // ---- broadphase model of the wheels (Box2D: b2Fixture::Synchronize / b2DynamicTree::MoveProxy at the END of the last
+  // step, b2BroadPhase::UpdatePairs -> b2ContactManager::AddPair right after it; evaluated lazily here, on the next pass).
+  // A tile<->wheel contact exists exactly while the two proxies' FAT AABBs overlap, and Collide serves the contacts
+  // newest batch first (AddPair inserts at the list head, Collide walks from the head), inside a batch in descending
+  // (tile proxy id, wheel proxy id) order (UpdatePairs sorts the pairs ascending before AddPair sees them): what has to be
+  // remembered per (tile, wheel) is the pass whose FindNewContacts made the contact (bp_stamp), and that follows from the
+  // wheel's fat AABB before and after each move.  First-episode proxy ids: ascending in creation order — tiles in track
+  // order, then car by car the hull polygons and the wheels.
+  __shared__ float4 wfat_new[MCR_MAX_AGENTS * 4], wfat_old[MCR_MAX_AGENTS * 4];
+  __shared__ float cfat[MCR_MAX_AGENTS][4];                        // per car: union of its wheels' fat AABBs
+  __shared__ unsigned long long evq[EVQ_CAP];                       // begin events of this pass: stamp << 14 | tile << 5 | car * 4 + wheel
+  __shared__ uint16_t tfl16[MCR_TILE_CAP];                          // flags word of the tiles that take a begin event
+  __shared__ int evn;
+  const uint32_t label = pass == 1 ? 0u : es.bp_step;
+  const bool fresh = pass == 1 || p.bp_fresh != 0;
+  unsigned long long moved_mask;                                    // bit car * 4 + wheel (in the low 32 bits)
   {
     const int c = lane >> 3, fi = lane & 7;
     float lox = MCR_MAXFLT, loy = MCR_MAXFLT, hix = -MCR_MAXFLT, hiy = -MCR_MAXFLT;
@@ -116,6 +139,46 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
       }
       fbox[lane] = make_float4(lox - 0.05f, loy - 0.05f, hix + 0.05f, hiy + 0.05f);
     }
+    bool moved = false;
+    float flx = MCR_MAXFLT, fly = MCR_MAXFLT, fhx = -MCR_MAXFLT, fhy = -MCR_MAXFLT;       // this wheel's fat AABB after the update
+    if (c < N && fi >= 4) {
+      const int wi = (env * N + c) * 4 + (fi - 4), WS = 4 * BN;
+      const float4 xfq = fxf[lane];
+      const float ax0 = lox - B2_POLYGON_RADIUS, ay0 = loy - B2_POLYGON_RADIUS, ax1 = hix + B2_POLYGON_RADIUS, ay1 = hiy + B2_POLYGON_RADIUS;   // b2PolygonShape::ComputeAABB
+      float4 of = make_float4(MCR_MAXFLT, MCR_MAXFLT, -MCR_MAXFLT, -MCR_MAXFLT);           // "no old proxy": overlaps nothing
+      float ux0 = ax0, uy0 = ay0, ux1 = ax1, uy1 = ay1, dx = 0.0f, dy = 0.0f;
+      if (!fresh) {
+        of = make_float4(p.bpf[(BP_FAT + 0) * WS + wi], p.bpf[(BP_FAT + 1) * WS + wi], p.bpf[(BP_FAT + 2) * WS + wi], p.bpf[(BP_FAT + 3) * WS + wi]);
+        // b2Fixture::Synchronize: union of the AABBs at the transforms the last step was entered and left with
+        ux0 = mcr_min(p.bpf[(BP_PREV + 0) * WS + wi], ax0); uy0 = mcr_min(p.bpf[(BP_PREV + 1) * WS + wi], ay0);
+        ux1 = mcr_max(p.bpf[(BP_PREV + 2) * WS + wi], ax1); uy1 = mcr_max(p.bpf[(BP_PREV + 3) * WS + wi], ay1);
+        dx = 2.0f * (xfq.x - p.bpf[(BP_PREVP + 0) * WS + wi]); dy = 2.0f * (xfq.y - p.bpf[(BP_PREVP + 1) * WS + wi]);   // b2_aabbMultiplier * displacement
+      }
+      float4 nf = of;
+      if (fresh || !(of.x <= ux0 && of.y <= uy0 && ux1 <= of.z && uy1 <= of.w)) {          // b2DynamicTree::MoveProxy (b2AABB::Contains)
+        nf = make_float4(ux0 - 0.1f, uy0 - 0.1f, ux1 + 0.1f, uy1 + 0.1f);                   // b2_aabbExtension
+        if (dx < 0.0f) nf.x += dx; else nf.z += dx;
+        if (dy < 0.0f) nf.y += dy; else nf.w += dy;
+        moved = true;
+        p.bpf[(BP_FAT + 0) * WS + wi] = nf.x; p.bpf[(BP_FAT + 1) * WS + wi] = nf.y; p.bpf[(BP_FAT + 2) * WS + wi] = nf.z; p.bpf[(BP_FAT + 3) * WS + wi] = nf.w;
+      }
+      p.bpf[(BP_PREV + 0) * WS + wi] = ax0; p.bpf[(BP_PREV + 1) * WS + wi] = ay0; p.bpf[(BP_PREV + 2) * WS + wi] = ax1; p.bpf[(BP_PREV + 3) * WS + wi] = ay1;
+      p.bpf[(BP_PREVP + 0) * WS + wi] = xfq.x; p.bpf[(BP_PREVP + 1) * WS + wi] = xfq.y;
+      wfat_new[c * 4 + (fi - 4)] = nf; wfat_old[c * 4 + (fi - 4)] = of;
+      flx = nf.x; fly = nf.y; fhx = nf.z; fhy = nf.w;
+    }
+    {
+      const unsigned long long mm = __ballot(moved);                                         // lane = car * 8 + 4 + wheel -> bit car * 4 + wheel
+      unsigned long long packed = 0ull;
+      for (int cc_ = 0; cc_ < N; ++cc_) packed |= ((mm >> (cc_ * 8 + 4)) & 0xfull) << (cc_ * 4);
+      moved_mask = packed;
+    }
+    for (int o = 1; o < 8; o <<= 1) {
+      flx = mcr_min(flx, __shfl_xor(flx, o)); fly = mcr_min(fly, __shfl_xor(fly, o));
+      fhx = mcr_max(fhx, __shfl_xor(fhx, o)); fhy = mcr_max(fhy, __shfl_xor(fhy, o));
+    }
+    if (fi == 0 && c < MCR_MAX_AGENTS) { cfat[c][0] = flx; cfat[c][1] = fly; cfat[c][2] = fhx; cfat[c][3] = fhy; }
+    if (lane == 0) evn = 0;
     for (int o = 1; o < 8; o <<= 1) {
       lox = mcr_min(lox, __shfl_xor(lox, o)); loy = mcr_min(loy, __shfl_xor(loy, o));
       hix = mcr_max(hix, __shfl_xor(hix, o)); hiy = mcr_max(hiy, __shfl_xor(hiy, o));
@@ -175,6 +238,10 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
     if (lane < MCR_TILE_CAP / MCR_TBLK) kb = ((const float4*)(slot + MCR_OFF_TBLK))[lane];
     bool near = false;
     for (int c = 0; c < N; ++c) near = near || !(kb.x > cbox[c][2] || kb.z < cbox[c][0] || kb.y > cbox[c][3] || kb.w < cbox[c][1]);
+    // ... and, where a wheel's proxy moved, the blocks whose tiles' fat AABBs (tight -+ 0.11) can meet the car's fat AABBs:
+    // that is where FindNewContacts makes contacts
+    if (moved_mask) for (int c = 0; c < N; ++c)
+      if ((moved_mask >> (4 * c)) & 0xfull) near = near || !(kb.x - 0.12f > cfat[c][2] || kb.z + 0.12f < cfat[c][0] || kb.y - 0.12f > cfat[c][3] || kb.w + 0.12f < cfat[c][1]);
     visit = (uint32_t)__ballot(near && kb.x <= kb.z) | (pass == 1 ? 0u : es.touch_blocks);
   }
   // the visited blocks' tiles, four blocks at a time: lane -> tile t (or -1)
@@ -191,6 +258,18 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
     const int t = next_tiles(vm);
     float4 bb = make_float4(MCR_MAXFLT, MCR_MAXFLT, -MCR_MAXFLT, -MCR_MAXFLT);
     if (t >= 0) bb = TAABB[t];
+    if (moved_mask) {
+      // FindNewContacts: a moved wheel proxy gets a contact with every tile whose fat AABB its NEW fat AABB overlaps and its
+      // old one did not (those already had one); all of them belong to this pass's batch
+      const float tx0 = (bb.x - B2_POLYGON_RADIUS) - 0.1f, ty0 = (bb.y - B2_POLYGON_RADIUS) - 0.1f, tx1 = (bb.z + B2_POLYGON_RADIUS) + 0.1f, ty1 = (bb.w + B2_POLYGON_RADIUS) + 0.1f;
+      for (unsigned long long mm = moved_mask; mm; mm &= mm - 1ull) {
+        const int f = __builtin_ctzll(mm);
+        const float4 nf = wfat_new[f], of = wfat_old[f];
+        const bool on = !(nf.x > tx1 || tx0 > nf.z || nf.y > ty1 || ty0 > nf.w);         // b2TestOverlap(aabb, aabb)
+        const bool oo = !(of.x > tx1 || tx0 > of.z || of.y > ty1 || ty0 > of.w);
+        if (t >= 0 && on && !oo) p.bp_stamp[((size_t)env * MCR_TILE_CAP + t) * (4 * N) + f] = label;
+      }
+    }
     for (int c = 0; c < N; ++c) {
       const bool hit = !(bb.x > cbox[c][2] || bb.z < cbox[c][0] || bb.y > cbox[c][3] || bb.w < cbox[c][1]);
       const unsigned long long m = __ballot(hit);
@@ -203,7 +282,7 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   }
   flush();
 
-  // ---- phase C: per-tile contact state, begin events, reward replay (lane = tile)
+  // ---- phase C: per-tile contact state (lane = tile); the begin events go to a queue ...
   uint32_t or_bits = 0, new_blocks = 0;
   for (uint32_t vm = visit; vm;) {
     const int t = next_tiles(vm);
@@ -215,30 +294,55 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
       newbits = tres[t];
       if (((tany[t >> 5] >> (t & 31)) & 1u) || old != newbits) fl |= 0x100u;          // any Begin/End recolours the tile (:102-104)
     }
-    const uint32_t begins = newbits & ~old;
-    unsigned long long m = __ballot(valid && begins != 0);
-    while (m) {
-      const int l = __ffsll((long long)m) - 1; m &= m - 1;
-      const uint32_t bg = (uint32_t)__shfl((int)begins, l);
-      uint32_t vis = (uint32_t)__shfl((int)(fl & 0xffu), l);
-#pragma unroll
-      for (int c = 0; c < MCR_MAX_AGENTS; ++c) {
-        if (c < N && ((bg >> (4 * c)) & 0xFu) && !(vis & (1u << c))) {
-          vis |= 1u << c;
-          tvc[c] += 1;
-          int past = __popc(vis) - 1;
-          double factor = 1 - ((double)past / (double)N);
-          reward[c] += factor * 1000.0 / (double)T;
-        }
-      }
-      if (lane == l) fl = (fl & ~0xffu) | vis;
+    uint32_t begins = newbits & ~old;
+    if (valid) {
+      touch[t] = newbits;
+      if (begins) tfl16[t] = (uint16_t)fl; else tflags[t] = (uint16_t)fl;               // a tile with begin events is written back after the replay
     }
-    if (valid) { touch[t] = newbits; tflags[t] = (uint16_t)fl; }
+    for (; begins; begins &= begins - 1u) {
+      const int f = __builtin_ctz(begins);                                              // car * 4 + wheel
+      const unsigned long long key = (1ull << 62) | ((unsigned long long)p.bp_stamp[((size_t)env * MCR_TILE_CAP + t) * (4 * N) + f] << 14) | ((unsigned long long)t << 5) | (unsigned long long)f;
+      const int slot = atomicAdd(&evn, 1);
+      if (slot < EVQ_CAP) evq[slot] = key;
+    }
     or_bits |= newbits;
     if (newbits) new_blocks |= 1u << (t / MCR_TBLK);
   }
+  __syncthreads();
+  // ... and are replayed in Box2D's order: highest (batch, tile, car * 4 + wheel) first.  Every lane keeps the same reward /
+  // count accumulators; the road_visited bits of the tiles involved live in LDS during the replay.
+  {
+    int n = evn;
+    if (n > EVQ_CAP) { if (lane == 0) atomicAdd(&p.status[ST_EVENT_OVERFLOW], 1u); n = EVQ_CAP; }
+    unsigned long long k0 = lane < n ? evq[lane] : 0ull, k1 = lane + 64 < n ? evq[lane + 64] : 0ull;
+    const unsigned long long m0 = k0, m1 = k1;
+    for (int i = 0; i < n; ++i) {
+      unsigned long long m = k0 > k1 ? k0 : k1;
+      for (int o = 1; o < 64; o <<= 1) { const unsigned long long other = (unsigned long long)__shfl_xor((long long)m, o); m = other > m ? other : m; }
+      if (k0 == m) k0 = 0ull; else if (k1 == m) k1 = 0ull;                              // keys are distinct ((tile, wheel) pairs) and never 0 (bit 62)
+      const int t = (int)((m >> 5) & 511ull), c = (int)((m >> 2) & 7ull);
+      uint32_t fl = tfl16[t];
+      if (!(fl & (1u << c))) {                                                          // FrictionDetector._contact (:113-120)
+        fl |= 1u << c;
+#pragma unroll
+        for (int cc_ = 0; cc_ < MCR_MAX_AGENTS; ++cc_) {
+          if (cc_ == c) {
+            tvc[cc_] += 1;
+            const int past = __popc(fl & 0xffu) - 1;
+            const double factor = 1 - ((double)past / (double)N);
+            reward[cc_] += factor * 1000.0 / (double)T;
+          }
+        }
+        __syncthreads();                                                                // every lane has read the word
+        if (lane == 0) tfl16[t] = (uint16_t)fl;
+      }
+      __syncthreads();
+    }
+    if (m0) { const int t = (int)((m0 >> 5) & 511ull); tflags[t] = tfl16[t]; }          // (lanes sharing a tile store the same word)
+    if (m1) { const int t = (int)((m1 >> 5) & 511ull); tflags[t] = tfl16[t]; }
+  }
   for (int o = 1; o < 64; o <<= 1) new_blocks |= (uint32_t)__shfl_xor((int)new_blocks, o);
-  if (lane == 0) p.env[env].touch_blocks = new_blocks;
+  if (lane == 0) { p.env[env].touch_blocks = new_blocks; p.env[env].bp_step = label + 1u; }
   for (int o = 1; o < 64; o <<= 1) or_bits |= (uint32_t)__shfl_xor((int)or_bits, o);
   if (lane < N) {
     const int ci = env * N + lane;
@@ -338,7 +442,7 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
     __syncthreads();
     const int nn = base < MCR_CC_MAX ? base : MCR_CC_MAX;
     for (int i = lane; i < nn * 16; i += 64) store[4 + (i >> 4) * MCR_CC_WORDS + (i & 15)] = newrec[i >> 4][i & 15];
-    if (lane == 0) { store[0] = (uint32_t)nn; store[1] = base > MCR_CC_MAX ? 1u : 0u; }
+    if (lane == 0) { store[0] = (uint32_t)nn; store[1] = base > MCR_CC_MAX ? 1u : 0u; if (base > MCR_CC_MAX) atomicAdd(&p.status[ST_CC_OVERFLOW], 1u); }
     nn_final = nn;
   } else if (lane == 0 && pass == 1) store[0] = 0;
   // side-stream partition: envs whose dynamics chain is going to be long (a touching car<->car pair).  cc_mode: the verdict
@@ -347,12 +451,22 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   if (pass == 0 && p.split && lane == 0) {
     if (nn_final > 0) { p.clist[1 + atomicAdd(&p.clist[0], 1)] = env; atomicAdd(&p.counters[2], 1ull); }
     if (!p.cc_mode) p.part[env] = nn_final > 0 ? 1 : 0;         // the contact pass runs first: it is the one that marks the contact chain's envs
-    else if ((nn_final > 0) != (p.part[env] != 0)) atomicAdd(&p.counters[4], 1ull);
+    else if ((nn_final > 0) != (p.part[env] != 0)) { atomicAdd(&p.counters[4], 1ull); atomicAdd(&p.status[ST_VERDICT], 1u); }
   }
-  if (pass == 0 && p.cc_mode) {            // the main dynamics, running beside this launch, may read this env's results now
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // the stores above have completed (no cache write-back: they were write-through)
-    __syncthreads();
-    if (lane == 0) __hip_atomic_store(&p.collide_epoch[env], p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (pass == 0 && p.cc_mode && !((p.debug & 4096) && env == p.env0)) {     // the main dynamics, running beside this launch, may read this env's results now
+    // (debug bit 12: env 0's word is withheld — what a starved contact pass looks like to the dynamics; tests)
+    // The three result words above left as write-through device-scope stores; "s_waitcnt vmcnt(0)" (all a workgroup-scope release
+    // fence costs) holds the epoch word back until they are acknowledged by the memory side, which for write-through stores is the
+    // device's coherence point.  An agent-scope RELEASE would in addition write this XCD's whole dirty L2 back (4096 times per
+    // launch: 24 -> 146 us, measured) to publish lines nobody reads across XCDs; debug bit 11 selects it for measurements.
+    if (p.debug & 2048) {
+      __syncthreads();
+      if (lane == 0) __hip_atomic_store(&p.collide_epoch[env], p.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads();
+      if (lane == 0) __hip_atomic_store(&p.collide_epoch[env], p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 

@@ -587,7 +587,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
     int incl = need;
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
     pool_base = incl - need;
-    if (agent == 0 && pool_base + ccn > DYN_VC_POOL) { ccn = DYN_VC_POOL - pool_base; if (ccn < 0) ccn = 0; store[1] = 2u; }
+    if (agent == 0 && pool_base + ccn > DYN_VC_POOL) { ccn = DYN_VC_POOL - pool_base; if (ccn < 0) ccn = 0; store[1] = 2u; atomicAdd(&p.status[ST_CC_OVERFLOW], 1u); }
     ccn = __shfl(ccn, leader_lane); pool_base = __shfl(pool_base, leader_lane);
     if (ccn > 0) {
 #pragma unroll
@@ -883,10 +883,15 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
   uint32_t tvc = 0, flags = 0;
   if (p.cc_mode && mode == 0 && p.role == 1 && run)               // k_collide pass 0 runs beside this launch: wait until it is through with this env
   {
+    // p.epoch is the handle's step counter: no earlier pass can have left the same value behind.  The wait is bounded (~3 s; the
+    // contact pass was enqueued before this launch, takes ~25 us and — mcr_hip.hip gates cc_mode on it — always finds room beside
+    // this launch's one wavefront per SIMD); a give-up is REPORTED (status word -> mcr_step fails, the handle falls back to the
+    // contact pass in front), never silent.  debug bit 12 shortens the bound (tests).
+    const int bound = (p.debug & 4096) ? (1 << 14) : (1 << 24);
     int spin = 0;
-    for (; spin < (1 << 24) && __hip_atomic_load(&p.collide_epoch[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch; ++spin)
-      __builtin_amdgcn_s_sleep(8);                                  // (bounded: ~3 s; k_collide was enqueued before this launch and takes ~25 us)
-    if (spin == (1 << 24)) atomicAdd(&p.counters[4], 1ull);         // gave up: the results of this env are wrong from here on, and the counter says so
+    if (p.debug & 2048) { for (; spin < bound && __hip_atomic_load(&p.collide_epoch[env], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != p.epoch; ++spin) __builtin_amdgcn_s_sleep(8); }
+    else { for (; spin < bound && __hip_atomic_load(&p.collide_epoch[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch; ++spin) __builtin_amdgcn_s_sleep(8); }
+    if (spin == bound) { atomicAdd(&p.counters[5], 1ull); atomicAdd(&p.status[ST_SPIN_GIVEUP], 1u); }
   }
   const bool cc_wait = p.cc_mode && mode == 0 && p.role == 1;
   uint32_t onroad_new = 0;
@@ -1164,7 +1169,9 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
         if (boxes) nr = nr && !(a0 > c2 + 0.2f || a2 + 0.2f < c0 || a1 > c3 + 0.2f || a3 + 0.2f < c1);
         near = near || nr;
       }
-    if (agent == 0) p.part_next[env] = near ? 2 : 0;
+    // (an env re-spawned in this step whose reset pass is a list launch of its own, role 4: that launch settles the verdict on
+    // the poses it ends with — the bookkeeping kernel of the main envs, which may run beside it, must leave the env alone)
+    if (agent == 0) p.part_next[env] = (near && !(respawn && p.respawn_list)) ? 2 : 0;
   }
   }   // run
   DYN_STAMP(4);

@@ -26,7 +26,8 @@ __global__ __launch_bounds__(64) void k_reset_list(McrParams p) {
   const int nb = mcr_virtual_blocks(p, p.list_envs_per_block);
   for (int blk = blockIdx.x; blk < nb; blk += gridDim.x) {
     list_reset_pass(p, blk);
-    // the next step's touch verdict of the re-spawned envs (their cars take no bookkeeping in this step: first observation)
+    // the next step's touch verdict of the re-spawned envs: this launch is its only writer (the main dynamics left a 0, so the
+    // main envs' bookkeeping kernel does not look at these envs; their cars take no bookkeeping in this step: first observation)
     if (p.part_next) {
       __threadfence();
       for (int k = 0; k < p.list_envs_per_block; ++k) {

@@ -111,6 +111,13 @@ enum {
   CU_ONROAD_NEW = 4,  // the same bits as this step's Collide found them (k_collide writes, the step's k_dynamics promotes them to CU_ONROAD)
   CU_COUNT = 5
 };
+// broadphase model of the wheels (k_collide.h): f32 fields  bpf[field][4 * BN]  (car * 4 + wheel)
+enum {
+  BP_FAT = 0,    // +0..3: fat AABB of the wheel's proxy (lo.x lo.y hi.x hi.y)
+  BP_PREV = 4,   // +0..3: the fixture's AABB at the transform the last contact pass saw (b2PolygonShape::ComputeAABB)
+  BP_PREVP = 8,  // +0..1: that transform's p
+  BP_COUNT = 10
+};
 // per-env state
 struct McrEnvState {
   double t;                // self.t
@@ -123,7 +130,7 @@ struct McrEnvState {
   int32_t just_reset;      // the obs being produced is a first observation (a7 bookkeeping is skipped, :435)
   int32_t frozen;          // auto-reset found no staged episode when this env finished: inactive until the host stages one (then it thaws)
   uint32_t touch_blocks;   // bit b: some tile of block b (MCR_TBLK tiles) had a wheel on it after the last contact pass (k_collide looks at those + the ones near a car)
-  int32_t pad0;
+  uint32_t bp_step;        // contact passes this episode has seen (the reset pass is 0): labels the batches of the broadphase model (k_collide.h), owned by k_collide
 };
 
 // fixtures of one car in body-local coordinates (host builds them with its b2PolygonShape::Set

@@ -56,9 +56,21 @@ struct mcr_env {
   int use_graph;              // 0 off, 1 on, -1 capture failed once: stay off
   bool concurrent_collide;    // the contact pass may run beside the main dynamics (kernels of different streams do overlap here: probed at create)
   bool verdict_fresh;         // the touch verdicts (k_touch.h) of the next step's entry poses are in place (last step's bookkeeping wrote them)
+  uint32_t* status_host;      // [MCR_STATUS_WORDS] mapped host memory the kernels report trouble in (mcr_kernels.h: ST_*)
+  uint32_t status_seen[MCR_STATUS_WORDS];   // what mcr_step has already reported
+  int32_t step_count;         // steps launched: the epoch of the three-chain step's per-env "contact pass done" words
+  bool bp_fresh;              // mcr_set_bodies teleported cars: the next contact pass re-creates their broadphase proxies
+  int simd_count;             // SIMDs of the device (4 per CU)
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+// Does the three-chain step run the contact pass BESIDE the main dynamics?  Only where kernels of different streams overlap
+// (probed at create), up to 4 cars per env (measured), and only for batches whose main dynamics launch puts at most one of its
+// 256-VGPR wavefronts on a SIMD: that launch waits INSIDE the kernel for words of the contact pass, which must be able to get onto
+// the machine beside it (one such wavefront per SIMD leaves half the register file and nearly all LDS free; two on every SIMD
+// could starve a contact pass dispatched second).  After a reported give-up the handle stays with the contact pass in front.  The
+// hipGraph replay (constant arguments) runs it in front as well.
+static bool cc_active(const mcr_env* h) { return h->split && h->concurrent_collide && h->use_graph <= 0; }
 
 // Do kernels of two streams really run side by side in this process?  Under a counter-collecting profiler, a debugger or
 // AMD_SERIALIZE_KERNEL they do not — and the cc_mode step (the main dynamics waits inside the kernel for words the
@@ -89,6 +101,8 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   HIPCHK(hipSetDevice(cfg->device));
   mcr_env* h = new mcr_env();
   h->cfg = *cfg; h->timing = 0; h->any_reset = false; h->use_graph = 0; h->verdict_fresh = false; h->concurrent_collide = false; h->sg[0].valid = h->sg[1].valid = false;
+  h->status_host = nullptr; h->step_count = 0; h->bp_fresh = false; memset(h->status_seen, 0, sizeof(h->status_seen));
+  { hipDeviceProp_t prop; h->simd_count = (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess ? prop.multiProcessorCount : 256) * 4; }
   for (int i = 0; i < MCR_TIMING_SLOTS; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
   const int B = cfg->num_envs, N = cfg->num_agents;
   int G = 1; while (G < N) G <<= 1;
@@ -102,6 +116,8 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   const size_t o_touch = carve(sizeof(uint32_t) * MCR_TILE_CAP * (size_t)B);
   const size_t o_tflags = carve(sizeof(uint16_t) * MCR_TILE_CAP * (size_t)B);
   const size_t o_cc = carve(sizeof(uint32_t) * (size_t)B * (MCR_CC_MAX * MCR_CC_WORDS + 4));
+  const size_t o_bpf = carve(sizeof(float) * BP_COUNT * 4 * BN);
+  const size_t o_bpstamp = carve(sizeof(uint32_t) * (size_t)B * MCR_TILE_CAP * 4 * N);
   const size_t o_part = carve(2 * (size_t)B);                 // x2: the touch verdicts of a step live in the buffer of its parity
   const size_t o_dpart = carve(B);
   const size_t o_epoch = carve(sizeof(int32_t) * (size_t)B);
@@ -129,7 +145,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   P.B = B; P.N = N; P.G = G; P.BN = (int)BN;
   P.carf = (float*)(base + o_carf); P.card = (double*)(base + o_card); P.caru = (uint32_t*)(base + o_caru);
   P.env = (McrEnvState*)(base + o_env); P.tile_touch = (uint32_t*)(base + o_touch); P.tile_flags = (uint16_t*)(base + o_tflags);
-  P.cc_store = (uint32_t*)(base + o_cc); P.shapes = (const McrShapes*)(base + o_shapes); P.slots = base + o_slots;
+  P.cc_store = (uint32_t*)(base + o_cc); P.bpf = (float*)(base + o_bpf); P.bp_stamp = (uint32_t*)(base + o_bpstamp); P.shapes = (const McrShapes*)(base + o_shapes); P.slots = base + o_slots;
   h->view_stamps = (unsigned long long*)(base + o_vscratch);
   P.viewp = (float*)(base + o_viewp);
   P.part = base + o_part; P.dpart = base + o_dpart; P.collide_epoch = (int32_t*)(base + o_epoch); P.dlist = (int32_t*)(base + o_dlist); P.rlist = (int32_t*)(base + o_rlist); P.defer_state = base + o_dstate; P.counters = (unsigned long long*)(base + o_counters); P.stats = (double*)(base + o_stats);
@@ -148,6 +164,10 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   (void)hipHostGetDevicePointer(&dptr, h->consumed_host, 0);
   P.consumed_host = (int32_t*)dptr;
   h->consumed_seen = new int32_t[B]();
+  if (hipHostMalloc((void**)&h->status_host, sizeof(uint32_t) * MCR_STATUS_WORDS, hipHostMallocMapped) != hipSuccess) { g_err = "hipHostMalloc failed"; (void)hipHostFree(h->consumed_host); delete[] h->consumed_seen; (void)hipFree(h->slab); delete h; return MCR_ERR_HIP; }
+  memset(h->status_host, 0, sizeof(uint32_t) * MCR_STATUS_WORDS);
+  (void)hipHostGetDevicePointer(&dptr, h->status_host, 0);
+  P.status = (uint32_t*)dptr;
   // Contact side stream.  k_dynamics is a serial dependency chain whose duration is set by its slowest wavefront,
   // and a wavefront holding a touching car<->car pair takes 2-3x as long as the others (sequential Gauss-Seidel
   // over the contacts).  With num_streams == 2 those envs (a handful per step) run dynamics -> reset pass ->
@@ -168,7 +188,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
         (void)hipEventCreateWithFlags(&h->ev_col, hipEventDisableTiming);
         // (beyond 4 cars per env the one-step-ahead touch verdict — a second pass over up to 28 car pairs — costs more than
         // the contact pass gains by running beside the dynamics: measured at N = 8)
-        h->concurrent_collide = N <= 4 && !getenv("MCR_SEQUENTIAL_COLLIDE") && kernels_overlap(h->s_defer, h->s_side);
+        h->concurrent_collide = N <= 4 && !getenv("MCR_SEQUENTIAL_COLLIDE") && (B * G + 63) / 64 <= h->simd_count && kernels_overlap(h->s_defer, h->s_side);
         h->split = true;
       } else (void)hipStreamDestroy(h->s_side);
     }
@@ -192,6 +212,7 @@ extern "C" int mcr_destroy(mcr_env* h) {
   }
   (void)hipFree(h->slab);
   (void)hipHostFree(h->consumed_host);
+  (void)hipHostFree(h->status_host);
   delete[] h->consumed_seen;
   delete h;
   return MCR_OK;
@@ -286,7 +307,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     P.clist = h->P.clist + par * (B + 1); P.clist_next = h->P.clist + oth * (B + 1);
     P.dlist = h->P.dlist + par * (B + 1); P.rlist = h->P.rlist + par * (B + 1);
     P.vcount = h->P.vcount + par * (B + 2); P.vorder = P.vcount + 2;
-    P.part = h->P.part + par * B; P.part_next = (h->split && h->concurrent_collide) ? h->P.part + oth * B : nullptr;
+    P.part = h->P.part + par * B; P.part_next = cc_active(h) ? h->P.part + oth * B : nullptr;
     P.next_counts[0] = h->P.dlist + oth * (B + 1); P.next_counts[1] = h->P.rlist + oth * (B + 1);
     P.next_counts[2] = h->P.vcount + oth * (B + 2); P.next_counts[3] = P.next_counts[2] + 1;
     h->step_parity ^= 1;
@@ -320,8 +341,8 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   // k_collide's per-env "done" word.  24 us + a kernel boundary off the critical path.
   // Where kernels of different streams do not overlap (mcr_create probes it: counter-collecting profilers, debuggers) the
   // contact pass simply runs first, on the caller's stream.
-  const bool cc = h->concurrent_collide;
-  P.cc_mode = cc ? 1 : 0; P.epoch = 1 + (h->step_parity & 1);
+    const bool cc = cc_active(h);
+  P.cc_mode = cc ? 1 : 0; P.epoch = h->step_count;
   if (!cc) LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), st, P, 0);
   (void)hipEventRecord(h->ev_fork, st);
   (void)hipStreamWaitEvent(h->s_side, h->ev_fork, 0);
@@ -370,6 +391,30 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   (void)hipStreamWaitEvent(st, h->ev_join2, 0);
 }
 
+// The kernels report conditions that make results wrong in mapped host memory (mcr_kernels.h: ST_*); read here without
+// synchronising, like the install counters — a condition raised by a step that is still running shows up in a later call.
+static int check_status(mcr_env* h) {
+  static const char* what[MCR_STATUS_WORDS] = {
+      "the main dynamics gave up waiting for the contact pass (three-chain step); the handle now runs the contact pass in front",
+      "the contact pass disagreed with the one-step-ahead touch verdict", "more touching car<->car fixture pairs than the manifold store holds",
+      "more tile begin events in one env-step than the replay buffer holds", "", "", "", ""};
+  for (int i = 0; i < MCR_STATUS_WORDS; ++i) {
+    const uint32_t v = ((volatile uint32_t*)h->status_host)[i];
+    if (v != h->status_seen[i]) {
+      h->status_seen[i] = v;
+      if (i == ST_SPIN_GIVEUP) { h->concurrent_collide = false; h->verdict_fresh = false; }
+      g_err = std::string("results of an earlier step are wrong: ") + what[i] + " (" + std::to_string(v) + " so far)";
+      return MCR_ERR_STATE;
+    }
+  }
+  return MCR_OK;
+}
+extern "C" int mcr_status(mcr_env* h, uint32_t* out, int n_words) {
+  if (!h || !out || n_words < 0) return MCR_ERR_ARG;
+  for (int i = 0; i < n_words && i < MCR_STATUS_WORDS; ++i) out[i] = ((volatile uint32_t*)h->status_host)[i];
+  return MCR_OK;
+}
+
 extern "C" int mcr_reset(mcr_env* h, const uint8_t* d_env_mask, uint8_t* d_obs, void* stream) {
   if (!h) { g_err = "null handle"; return MCR_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
@@ -384,14 +429,17 @@ extern "C" int mcr_reset(mcr_env* h, const uint8_t* d_env_mask, uint8_t* d_obs, 
 extern "C" int mcr_step(mcr_env* h, const float* d_actions, uint8_t* d_obs, double* d_reward, uint8_t* d_done, uint8_t* d_trunc, void* stream) {
   if (!h || !d_reward || !d_done) { g_err = "null argument"; return MCR_ERR_ARG; }
   if (!h->any_reset) { g_err = "step() before reset()"; return MCR_ERR_STATE; }
+  if (int rc = check_status(h)) return rc;
   hipStream_t st = (hipStream_t)stream;
   McrParams P = h->P;
   P.actions = d_actions; P.obs = h->cfg.obs_enabled ? d_obs : nullptr;
   P.reward_out = d_reward; P.done_out = d_done; P.trunc_out = d_trunc;
+  P.bp_fresh = h->bp_fresh ? 1 : 0; h->bp_fresh = false;
+  h->step_count += 1;
   // with auto_reset, finished envs are re-spawned on the device and take the action-less first step of their
   // new episode inside this call; the view kernel always runs (it also owns the backward/on-grass flags)
   const int vf = d_actions ? 1 : 0;
-  if (h->split && h->concurrent_collide && !h->verdict_fresh) {   // after reset() / reset_envs() / a state restore / a step without actions: which envs hold a touching car<->car pair?
+  if (cc_active(h) && !h->verdict_fresh) {   // after reset() / reset_envs() / a state restore / a step without actions: which envs hold a touching car<->car pair?
     McrParams Pt = P; Pt.role = 0; Pt.part = h->P.part + (size_t)h->step_parity * P.B;
     hipLaunchKernelGGL(k_touch, dim3(P.B), dim3(64), 0, st, Pt);
   }
@@ -431,6 +479,7 @@ extern "C" int mcr_step(mcr_env* h, const float* d_actions, uint8_t* d_obs, doub
 
 extern "C" int mcr_set_step_graph(mcr_env* h, int enable) {
   if (!h) { g_err = "null handle"; return MCR_ERR_ARG; }
+  if ((enable ? 1 : 0) != (h->use_graph > 0 ? 1 : 0)) h->verdict_fresh = false;      // the graph replay runs the contact pass in front (cc_active)
   h->use_graph = enable ? 1 : 0;
   return MCR_OK;
 }
@@ -537,6 +586,7 @@ extern "C" int mcr_set_bodies(mcr_env* h, const float* bodies) {
     cf[(CF_VX + k) * BN + c] = o[3]; cf[(CF_VY + k) * BN + c] = o[4]; cf[(CF_W + k) * BN + c] = o[5];
   }
   HIPCHK(hipMemcpy(h->P.carf, cf.data(), cf.size() * 4, hipMemcpyHostToDevice));
+  h->bp_fresh = true; h->verdict_fresh = false;      // teleported cars: their broadphase proxies are re-created by the next contact pass
   return MCR_OK;
 }
 
@@ -567,9 +617,9 @@ extern "C" int mcr_get_env_state(mcr_env* h, double* reward, int32_t* tvc, uint8
 
 // ---------------------------------------------------------------------------- full state snapshot / restore
 namespace {
-struct BlobLayout { size_t carf, card, caru, es, touch, tflags, cc, viewp, carpoly, slot, particles, total; };
+struct BlobLayout { size_t carf, card, caru, es, touch, tflags, cc, viewp, carpoly, bpf, stamp, slot, particles, total; };
 BlobLayout blob_layout(int N, bool with_particles) {
-  BlobLayout L; size_t o = 16;                                         // header: magic, N, reserved
+  BlobLayout L; size_t o = 16;                                         // header: magic (carries the layout version), N, flags (bit 0: particles), total bytes
   L.carf = o; o += sizeof(float) * CF_COUNT * N;
   o = (o + 7) & ~(size_t)7; L.card = o; o += sizeof(double) * CD_COUNT * N;
   L.caru = o; o += sizeof(uint32_t) * CU_COUNT * N;
@@ -579,12 +629,14 @@ BlobLayout blob_layout(int N, bool with_particles) {
   L.cc = o; o += sizeof(uint32_t) * (MCR_CC_MAX * MCR_CC_WORDS + 4);
   L.viewp = o; o += sizeof(float) * MCR_VIEWP_FLOATS * N;
   L.carpoly = o; o += sizeof(float) * MCR_CARPOLY_FLOATS * N;
+  L.bpf = o; o += sizeof(float) * BP_COUNT * 4 * N;
+  L.stamp = o; o += sizeof(uint32_t) * MCR_TILE_CAP * 4 * N;
   o = (o + 15) & ~(size_t)15; L.slot = o; o += MCR_SLOT_BYTES;
   L.particles = o; if (with_particles) o += sizeof(uint32_t) * MCR_PART_WORDS * N;
   L.total = o;
   return L;
 }
-const uint32_t BLOB_MAGIC = 0x3152434du;   // "MCR1"
+const uint32_t BLOB_MAGIC = 0x3352434du;   // "MCR3": bumped whenever the layout of a blob (McrEnvState, slot image, field lists) changes
 }  // namespace
 
 extern "C" size_t mcr_state_blob_bytes(const mcr_env* h) { return h ? blob_layout(h->P.N, h->P.particles != nullptr).total : 0; }
@@ -598,7 +650,7 @@ extern "C" int mcr_get_state_blob(mcr_env* h, int env, void* blob_out) {
   const BlobLayout L = blob_layout(N, P.particles != nullptr);
   uint8_t* b = (uint8_t*)blob_out;
   memset(b, 0, L.total);
-  ((uint32_t*)b)[0] = BLOB_MAGIC; ((uint32_t*)b)[1] = (uint32_t)N;
+  ((uint32_t*)b)[0] = BLOB_MAGIC; ((uint32_t*)b)[1] = (uint32_t)N; ((uint32_t*)b)[2] = P.particles ? 1u : 0u; ((uint32_t*)b)[3] = (uint32_t)L.total;
   HIPCHK(hipMemcpy2D(b + L.carf, sizeof(float) * N, P.carf + (size_t)env * N, sizeof(float) * BN, sizeof(float) * N, CF_COUNT, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy2D(b + L.card, sizeof(double) * N, P.card + (size_t)env * N, sizeof(double) * BN, sizeof(double) * N, CD_COUNT, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy2D(b + L.caru, sizeof(uint32_t) * N, P.caru + (size_t)env * N, sizeof(uint32_t) * BN, sizeof(uint32_t) * N, CU_COUNT, hipMemcpyDeviceToHost));
@@ -611,6 +663,8 @@ extern "C" int mcr_get_state_blob(mcr_env* h, int env, void* blob_out) {
   HIPCHK(hipMemcpy(b + L.cc, P.cc_store + (size_t)env * ccw, sizeof(uint32_t) * ccw, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(b + L.viewp, P.viewp + (size_t)env * N * MCR_VIEWP_FLOATS, sizeof(float) * MCR_VIEWP_FLOATS * N, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(b + L.carpoly, P.carpoly + (size_t)env * N * MCR_CARPOLY_FLOATS, sizeof(float) * MCR_CARPOLY_FLOATS * N, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy2D(b + L.bpf, sizeof(float) * 4 * N, P.bpf + (size_t)env * 4 * N, sizeof(float) * 4 * BN, sizeof(float) * 4 * N, BP_COUNT, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(b + L.stamp, P.bp_stamp + (size_t)env * MCR_TILE_CAP * 4 * N, sizeof(uint32_t) * MCR_TILE_CAP * 4 * N, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(b + L.slot, P.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES, MCR_SLOT_BYTES, hipMemcpyDeviceToHost));
   if (P.particles) HIPCHK(hipMemcpy(b + L.particles, P.particles + (size_t)env * N * MCR_PART_WORDS, sizeof(uint32_t) * MCR_PART_WORDS * N, hipMemcpyDeviceToHost));
   return MCR_OK;
@@ -621,9 +675,10 @@ extern "C" int mcr_set_state_blob(mcr_env* h, int env, const void* blob) {
   if (env < 0 || env >= h->P.B) { g_err = "env out of range"; return MCR_ERR_ARG; }
   const McrParams& P = h->P; const int N = P.N; const size_t BN = P.BN;
   const uint8_t* b = (const uint8_t*)blob;
-  if (((const uint32_t*)b)[0] != BLOB_MAGIC || ((const uint32_t*)b)[1] != (uint32_t)N) { g_err = "not a state blob of this num_agents"; return MCR_ERR_ARG; }
-  HIPCHK(hipDeviceSynchronize());
   const BlobLayout L = blob_layout(N, P.particles != nullptr);
+  if (((const uint32_t*)b)[0] != BLOB_MAGIC || ((const uint32_t*)b)[1] != (uint32_t)N) { g_err = "not a state blob of this build and num_agents"; return MCR_ERR_ARG; }
+  if (((const uint32_t*)b)[2] != (P.particles ? 1u : 0u) || ((const uint32_t*)b)[3] != (uint32_t)L.total) { g_err = "state blob was taken from a handle with another skid_particles setting"; return MCR_ERR_ARG; }
+  HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy2D(P.carf + (size_t)env * N, sizeof(float) * BN, b + L.carf, sizeof(float) * N, sizeof(float) * N, CF_COUNT, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy2D(P.card + (size_t)env * N, sizeof(double) * BN, b + L.card, sizeof(double) * N, sizeof(double) * N, CD_COUNT, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy2D(P.caru + (size_t)env * N, sizeof(uint32_t) * BN, b + L.caru, sizeof(uint32_t) * N, sizeof(uint32_t) * N, CU_COUNT, hipMemcpyHostToDevice));
@@ -640,6 +695,8 @@ extern "C" int mcr_set_state_blob(mcr_env* h, int env, const void* blob) {
   HIPCHK(hipMemcpy(P.cc_store + (size_t)env * ccw, b + L.cc, sizeof(uint32_t) * ccw, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(P.viewp + (size_t)env * N * MCR_VIEWP_FLOATS, b + L.viewp, sizeof(float) * MCR_VIEWP_FLOATS * N, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(P.carpoly + (size_t)env * N * MCR_CARPOLY_FLOATS, b + L.carpoly, sizeof(float) * MCR_CARPOLY_FLOATS * N, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy2D(P.bpf + (size_t)env * 4 * N, sizeof(float) * 4 * BN, b + L.bpf, sizeof(float) * 4 * N, sizeof(float) * 4 * N, BP_COUNT, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(P.bp_stamp + (size_t)env * MCR_TILE_CAP * 4 * N, b + L.stamp, sizeof(uint32_t) * MCR_TILE_CAP * 4 * N, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(P.slots + ((size_t)env * 2 + cur.slot) * MCR_SLOT_BYTES, b + L.slot, MCR_SLOT_BYTES, hipMemcpyHostToDevice));
   if (P.particles) HIPCHK(hipMemcpy(P.particles + (size_t)env * N * MCR_PART_WORDS, b + L.particles, sizeof(uint32_t) * MCR_PART_WORDS * N, hipMemcpyHostToDevice));
   h->any_reset = true; h->verdict_fresh = false;

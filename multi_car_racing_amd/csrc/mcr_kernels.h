@@ -14,6 +14,10 @@ struct McrParams {
   uint32_t* tile_touch;         // [B][TILE_CAP]  bit (car*4+wheel): wheel currently in contact with the tile
   uint16_t* tile_flags;         // [B][TILE_CAP]  bits 0..7 road_visited[car], bit 8 recoloured
   uint32_t* cc_store;           // [B][...] car<->car manifold store (warm starting)
+  float* bpf;                   // [BP_COUNT][4 * BN] broadphase proxies of the wheels (fat AABBs; what the last contact pass saw)
+  uint32_t* bp_stamp;           // [B][TILE_CAP][4 * N] batch label of the tile<->wheel contact: the contact pass that first saw the two fat AABBs overlap
+  int32_t bp_fresh;             // the car proxies are re-created at the current poses by this step's contact pass (after mcr_set_bodies)
+  uint32_t* status;             // [MCR_STATUS_WORDS] mapped host memory: conditions that make results wrong (mcr_step checks them without synchronising)
   const McrShapes* shapes;
   float* viewp;                 // [BN][MCR_VIEWP_FLOATS] per-car camera + HUD geometry, written by k_dynamics, read by k_view
   float* carpoly;               // [BN][MCR_CARPOLY_FLOATS] world-space vertices of the car's 12 draw polygons (Car.draw)
@@ -152,5 +156,11 @@ __device__ __noinline__ void mcr_particle_step(uint32_t* pc, int k, bool skid, b
     pc[5 + k] = 2u | (grass ? 256u : 0u);                                    // skid_start = None
   }
 }
+// status words (mapped host memory; non-zero = the results are no longer trustworthy, mcr_step returns MCR_ERR_STATE)
+enum { ST_SPIN_GIVEUP = 0,     // the main dynamics gave up waiting for the contact pass of an env (three-chain step)
+       ST_VERDICT = 1,         // the contact pass disagreed with the one-step-ahead touch verdict
+       ST_CC_OVERFLOW = 2,     // more touching car<->car fixture pairs than the manifold store / the LDS pool holds: the excess was dropped
+       ST_EVENT_OVERFLOW = 3,  // more tile begin events in one env-step than the replay buffer holds
+       MCR_STATUS_WORDS = 8 };
 #define MCR_CC_MAX 24           // touching car<->car fixture pairs kept per env (warm start)
 #define MCR_CC_WORDS 20         // u32 words per stored manifold

@@ -261,7 +261,9 @@ class VecMultiCarRacing:
         """actions: float32 device tensor [B,N,3] (steer, gas, brake) or None. Returns (obs, reward, done, info)."""
         st = torch.cuda.current_stream(self.device)
         self._raise_worker_error()
-        if self._pending and self._step_idx - self._pending[0] >= self.refill_lag:
+        with self._pending_lock:              # (the refill worker pops entries under the same lock)
+            behind = bool(self._pending) and self._step_idx - self._pending[0] >= self.refill_lag
+        if behind:
             self.wait_refills()               # the host fell behind: block instead of letting an env freeze
         self._step_idx += 1
         a_ptr = None
@@ -301,7 +303,8 @@ class VecMultiCarRacing:
 
     def render_rgb(self, e=0, width=600, height=400):
         """render('rgb_array') of env e: uint8 device tensor [N, height, width, 3] of its CURRENT state (reference
-        :511-604 with the VIDEO_W x VIDEO_H viewport; no skid particles, no score label)."""
+        :511-604 with the VIDEO_W x VIDEO_H viewport), score label included; skid particles (Car.draw(viewer, True), :564) are
+        drawn when the env was created with skid_particles=True (the facade does; batched envs leave them off)."""
         if not self._has_reset:
             raise AttributeError("render before reset()")
         out = torch.empty((self.N, int(height), int(width), 3), dtype=torch.uint8, device=self.device)
