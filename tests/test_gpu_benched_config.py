@@ -263,3 +263,71 @@ def test_freeze_and_thaw_when_host_withholds_staging(torch_cuda, oracle, streams
             d, _ = f.after_step(bool(od[j])); assert np.array_equal(orw[j], rw[j]) and d == dn[j], (k, j)
     assert env.verdict_mismatches() == 0
     env.close()
+
+
+def test_freeze_with_touching_cars_contact_pass_in_front(torch_cuda, oracle, monkeypatch):
+    """with the contact pass in FRONT of the dynamics (MCR_SEQUENTIAL_COLLIDE=1; also N > 4, serialised kernels) it
+    is k_collide that marks the contact chain's envs.  An env that freezes (episode over, nothing staged) while its cars
+    are in car<->car contact must not keep that mark — it would be skipped by every main launch and never thaw."""
+    torch = torch_cuda
+    from multi_car_racing_amd.vec_env import VecMultiCarRacing
+    monkeypatch.setenv("MCR_SEQUENTIAL_COLLIDE", "1")
+    B, N, seed, L = 6, 2, 91, 14
+    env = VecMultiCarRacing(B, N, seed=seed, use_random_direction=True, auto_reset=True, max_episode_steps=L,
+                            car_contacts=True, async_refill=False, streams=2)
+    assert not env.L.mcr_concurrent_collide(env.h)
+    env.reset()
+    env.hold_refills = True
+    fol = [_Follower(oracle, N, seed, g, L) for g in range(B)]
+    rs = np.random.RandomState(5)
+
+    def step_both(touching_drive):
+        a = np.stack([rs.uniform(-1, 1, (B, N)), rs.uniform(0, 1, (B, N)), rs.uniform(0, 0.2, (B, N))], -1).astype(np.float32)
+        if touching_drive:
+            a[:, 0, 1] = 0.0; a[:, 0, 2] = 0.8; a[:, 1, 0] *= 0.1; a[:, 1, 1] = 1.0       # car 0 brakes, car 1 pushes into it
+        obs, rew, done, _ = env.step(torch.from_numpy(a).cuda())
+        return a, obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy().astype(bool)
+
+    for k in range(L):                                   # episode 1
+        a, obs, rw, dn = step_both(False)
+        _, _, orw, od = oracle.step_batch([f.o for f in fol], a, None, threads=2)
+        for j, f in enumerate(fol):
+            d, _ = f.after_step(bool(od[j])); assert np.array_equal(orw[j], rw[j]) and d == dn[j]
+            if d:
+                f.new_episode()
+    # episode 2: car 1 is put right behind car 0 (overlapping it a little), so the pair touches until the TimeLimit ends the episode
+    st = env.get_state()["bodies"].copy()
+    for e in range(B):
+        ang = st[e, 0, 0, 2]
+        fwd = np.array([-np.sin(ang), np.cos(ang)], np.float32)
+        delta = (st[e, 0, 0, :2] - fwd * np.float32(4.9)) - st[e, 1, 0, :2]
+        st[e, 1, :, 0] += delta[0]; st[e, 1, :, 1] += delta[1]; st[e, 1, :, 2] = ang
+    env.set_bodies(st)
+    for e, f in enumerate(fol):
+        for k in range(5):
+            f.o.set_body(1, k, st[e, 1, k])
+    touching_at_end = 0
+    for k in range(L):
+        a, obs, rw, dn = step_both(True)
+        _, _, orw, od = oracle.step_batch([f.o for f in fol], a, None, threads=2)
+        for j, f in enumerate(fol):
+            d, _ = f.after_step(bool(od[j])); assert np.array_equal(orw[j], rw[j]) and d == dn[j], (k, j)
+    touching_at_end = sum(f.o.num_car_contacts() > 0 for f in fol)
+    assert dn.all() and touching_at_end >= B // 2, f"only {touching_at_end} envs ended their episode in car<->car contact"
+    for k in range(3):                                   # frozen
+        a, obs, rw, dn = step_both(False)
+        assert (rw == 0).all() and not dn.any()
+    env.hold_refills = False
+    env._settle_staging(torch.cuda.current_stream())
+    a, obs, rw, dn = step_both(False)                    # thaw step: every env, also those that froze in contact
+    assert (rw == 0).all() and not dn.any()
+    for j, f in enumerate(fol):
+        f.new_episode()
+        _cmp_pixels(obs[j], f.first_obs, f.first_amb, f"thaw env {j}")
+    _cmp_state(env, fol, range(B), "after thaw")
+    for k in range(L - 1):
+        a, obs, rw, dn = step_both(False)
+        _, _, orw, od = oracle.step_batch([f.o for f in fol], a, None, threads=2)
+        for j, f in enumerate(fol):
+            d, _ = f.after_step(bool(od[j])); assert np.array_equal(orw[j], rw[j]) and d == dn[j], (k, j)
+    env.close()

@@ -522,6 +522,65 @@ def test_random_rollout_with_contacts_enabled(torch_cuda, oracle, streams):
     env.close()
 
 
+def test_side_by_side_cars_take_shared_tiles_in_box2d_order(torch_cuda, oracle):
+    """Two cars of a start row share their tiles; driven alike they keep reaching new tiles in the SAME step, and who is served
+    first (Box2D: the contact of the later FindNewContacts batch, then the higher proxy id = the car created last) decides who
+    gets 1000/T and who the damped share (multi_car_racing.py:113-120).  Rewards are compared exactly, step by step."""
+    torch = torch_cuda
+    B, N, seed = 8, 2, 410
+    env = _make(B, N, seed, contacts=True); env.reset()
+    orcs = _oracles(oracle, B, N, seed, contacts=True)
+    es = env.get_env_state()
+    for e, o in enumerate(orcs):
+        r = o.env_state()["reward"]
+        assert np.array_equal(es["reward"][e], r)
+        assert r[1] > r[0] > 0, "spawn step: the car created last is served first on the shared tiles"
+    shared_steps = 0
+    rng = np.random.RandomState(2)
+    for k in range(220):
+        a = np.zeros((B, N, 3), np.float32)
+        a[:, :, 1] = 0.6 if k < 120 else 0.2
+        a[:, :, 0] = rng.uniform(-0.15, 0.15, (B, 1))                       # both cars steer alike: they stay side by side
+        obs, rew, done, _ = env.step(torch.from_numpy(a).cuda())
+        rw = rew.cpu().numpy()
+        for e, o in enumerate(orcs):
+            _, r, d, _ = o.step(a[e], render=False)
+            assert np.array_equal(r, rw[e]), f"step {k} env {e}: {r} vs {rw[e]}"
+            if (r > 0).all() and r[0] != r[1]:
+                shared_steps += 1                                            # both took a new tile in this step, one of them second
+    assert shared_steps > 8, f"only {shared_steps} steps in which both cars took the same new tile"
+    _assert_state_equal(env, orcs, "side by side")
+    env.close()
+
+
+def test_status_word_reports_a_starved_contact_pass(torch_cuda, lib):
+    """No silent wrong answers: if the main dynamics gives up waiting for the contact pass running beside it (three-chain
+    step), the next mcr_step fails with MCR_ERR_STATE (-> McrError) and the handle falls back to the contact pass in front."""
+    torch = torch_cuda
+    env = _make(128, 2, 5, contacts=True, streams=2)
+    if not env.L.mcr_concurrent_collide(env.h):
+        env.close(); pytest.skip("kernels of different streams do not overlap here: the contact pass already runs in front")
+    env.reset()
+    a = torch.zeros((128, 2, 3), device="cuda"); a[..., 1] = 0.5
+    for _ in range(3):
+        env.step(a)
+    lib.check(env.L.mcr_debug_set(env.h, 4096))            # env 0's "contact pass done" word is withheld; short spin bound
+    env.step(a); torch.cuda.synchronize()
+    with pytest.raises(lib.McrError, match="gave up waiting"):
+        env.step(a)
+    st = np.zeros(8, np.uint32)
+    lib.check(env.L.mcr_status(env.h, lib.ptr(st), 8))
+    assert st[0] >= 1
+    lib.check(env.L.mcr_debug_set(env.h, 0))
+    assert not env.L.mcr_concurrent_collide(env.h)
+    for _ in range(5):                                      # the handle keeps working, contact pass in front
+        env.step(a)
+    torch.cuda.synchronize()
+    lib.check(env.L.mcr_status(env.h, lib.ptr(st), 8))
+    assert st[0] >= 1 and env.verdict_mismatches() == 0
+    env.close()
+
+
 def test_device_sensor_predicate_is_box2d_gjk(torch_cuda, oracle, lib):
     """The contact pass decides "wheel touches tile" with Box2D's own b2TestOverlap (GJK b2Distance, k_gjk.h) behind a SAT
     far-field filter: >= 1e6 wheel/tile poses whose exact core separation is 0.02 +- 1e-5 (inside the f32 noise of the

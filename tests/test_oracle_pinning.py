@@ -197,3 +197,48 @@ def test_oracle_raster_vs_independent_scanline(oracle, N, seed):
                 checked += 1
     assert checked == 6 * N
     o.close()
+
+
+# ----------------------------------------------------------------------------- Box2D's callback order (broadphase model)
+def test_spawn_step_serves_the_car_created_last(oracle):
+    """reset() -> step(None): every tile<->wheel contact is made by ONE FindNewContacts (e_newFixture), so Collide serves them
+    in descending (tile, car, wheel) proxy order: on the tiles the cars of a start row share, the car created LAST is the first
+    visitor (full 1000/T), the others get the damped shares in descending car order (multi_car_racing.py:113-120)."""
+    for N, seed in ((2, 7), (4, 8), (3, 9)):
+        ep = oracle_episode(oracle, N, seed, 0)
+        o = oracle.OracleEnv(N); o.reset(ep, render=False)
+        es = o.env_state()
+        T = len(ep["track"])
+        order = ep["car_order"]                                            # car_id -> grid slot; slots 2r, 2r+1 share row r
+        for row in range((N + 1) // 2):
+            cars = sorted(c for c in range(N) if order[c] // 2 == row)
+            if len(cars) < 2:
+                continue
+            lo, hi = cars
+            assert es["tile_visited_count"][lo] == es["tile_visited_count"][hi] > 0
+            n = es["tile_visited_count"][hi]
+            # rows are 5 tiles apart: no tile is shared across rows at the spawn step, so the row's two cars split each tile
+            # (first visitor 1, second 1 - 1/N)
+            assert abs(es["reward"][hi] - n * 1000.0 / T) < 1e-9 and abs(es["reward"][lo] - n * (1 - 1 / N) * 1000.0 / T) < 1e-9, (N, row, es["reward"])
+        o.close()
+
+
+def test_event_order_is_a_function_of_the_fat_aabbs(oracle):
+    """The legacy order (rounds 1-2: tile^, car^, wheel^) and Box2D's differ in who gets the first-visitor share, never in
+    WHICH tiles are visited or when: counts, visited sets and done flags agree step by step."""
+    N = 2
+    ep = oracle_episode(oracle, N, 21, 0)
+    a = oracle.OracleEnv(N); b = oracle.OracleEnv(N)
+    b.L.orc_set_event_order(b.h, 1)
+    a.reset(ep, render=False); b.reset(ep, render=False)
+    ra, rb = a.env_state()["reward"], b.env_state()["reward"]
+    assert ra[1] > ra[0] and rb[0] > rb[1] and abs(ra.sum() - rb.sum()) < 1e-9
+    rng = np.random.RandomState(0)
+    for k in range(150):
+        act = np.zeros((N, 3), np.float32); act[:, 1] = 0.5; act[:, 0] = rng.uniform(-0.1, 0.1)
+        _, r1, d1, _ = a.step(act, render=False); _, r2, d2, _ = b.step(act, render=False)
+        assert d1 == d2 and abs(r1.sum() - r2.sum()) < 1e-9
+        ea, eb = a.env_state(), b.env_state()
+        assert np.array_equal(ea["tile_visited_count"], eb["tile_visited_count"]) and np.array_equal(ea["visited"], eb["visited"])
+        assert np.array_equal(a.state()["bodies"], b.state()["bodies"])
+    a.close(); b.close()
