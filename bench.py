@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event time all three kernels (adds overhead)")
     ap.add_argument("--action-seed", type=int, default=1234)
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket the raster launch with HIP events (no roofline object; lets --graph 1 replay)")
+    ap.add_argument("--emulate-world", type=int, default=0, help="W > 1: ONE GPU, but the host side of a W-rank job on this node: the process is pinned to 1/W of the "
+                    "cores the cgroup allows and its track generator takes the threads VecMultiCarRacing gives a rank of a W-rank job; reports "
+                    "env-steps/s, the time step() was blocked on the refill thread and the env-steps frozen waiting for the host")
     ap.add_argument("--graph", type=int, default=0, help="1: mcr_step replays a hipGraph of the step (bypassed while kernels are timed; measured gain 0.4 %); 0 (default): plain launches")
     args = ap.parse_args()
 
@@ -135,8 +138,18 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     B, N, K, W = args.envs, args.agents, args.steps, args.warmup
+    emu = None
+    extra = {}
+    if args.emulate_world > 1 and world == 1:
+        # the host share of ONE rank of a W-rank job on this node: the ranks split the cores the cgroup allows (vec_env.py)
+        from multi_car_racing_amd._lib import effective_cpus
+        allowed = sorted(os.sched_getaffinity(0)); total = effective_cpus()
+        share = max(1, total // args.emulate_world)
+        os.sched_setaffinity(0, set(allowed[:share]))             # threads created from here on inherit it (generator pool, refill worker)
+        extra["gen_threads"] = max(1, total // args.emulate_world - 1)
+        emu = {"world": args.emulate_world, "cores_allowed_to_the_job": total, "cores_this_rank": share, "gen_threads": extra["gen_threads"]}
     env = ShardedVecEnv(B * world, N, seed=0, rank=rank, world_size=world, device=dev, obs=bool(args.obs),
-                        auto_reset=True, use_random_direction=True, streams=args.streams, graph=bool(args.graph))
+                        auto_reset=True, use_random_direction=True, streams=args.streams, graph=bool(args.graph), **extra)
     env.reset()
     # synthetic actions, generated ON THE DEVICE by a counter-based stream keyed (seed, global env, agent, t):
     # i.i.d. steer~U(-1,1), gas~U(0,1), brake~U(0,1); one small kernel per ACT_BLOCK steps inside the timed region (the
@@ -173,6 +186,7 @@ def main():
         from multi_car_racing_amd import _lib as _L
         _L.check(env.env.L.mcr_debug_set(env.env.h, args.debug_bits))
     env.timing(0)
+    blocked0 = env.env.blocked_s
     gen0 = env.env.episodes_generated
     env.env.rollout_stats(reset=True)
     ctr0 = env.env.debug_counters()
@@ -258,6 +272,9 @@ def main():
                        "contact_pass_beside_dynamics": bool(env.env.L.mcr_concurrent_collide(env.env.h))},
             "roofline": roofline,
         }
+        out["config"]["step_blocked_on_refill_s_rank0"] = env.env.blocked_s - blocked0
+        if emu:
+            out["config"]["emulated_host_share"] = emu
         if K < 200:
             out["config"]["note"] = ("short run: %d steps = %.0f ms of timed work; the default (1000 steps = one TimeLimit period, "
                                      "every env resets once) is the representative figure" % (K, m["elapsed_s"] * 1e3))

@@ -19,6 +19,7 @@ import weakref
 import os
 import queue
 import threading
+import time
 
 import numpy as np
 import torch
@@ -70,6 +71,7 @@ class VecMultiCarRacing:
         # than any episode can last — and the freeze path stays a safety net (debug_counters()[3] counts its env-steps).
         self.refill_lag = max(1, min(int(refill_lag), int(max_episode_steps) - 1)) if int(max_episode_steps) > 0 else max(1, int(refill_lag))
         self._step_idx = 0
+        self.blocked_s = 0.0          # wall time step() spent waiting for the refill thread (host behind the device)
         self._pending = collections.deque()      # step index at which each queued refill batch was queued
         self._pending_lock = threading.Lock()
         self._worker_exc = None
@@ -264,7 +266,9 @@ class VecMultiCarRacing:
         with self._pending_lock:              # (the refill worker pops entries under the same lock)
             behind = bool(self._pending) and self._step_idx - self._pending[0] >= self.refill_lag
         if behind:
+            t0 = time.perf_counter()
             self.wait_refills()               # the host fell behind: block instead of letting an env freeze
+            self.blocked_s += time.perf_counter() - t0
         self._step_idx += 1
         a_ptr = None
         if actions is not None:
