@@ -969,8 +969,11 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
       if (p.role < 2 && respawn && p.respawn_list) p.rlist[1 + atomicAdd(&p.rlist[0], 1)] = env;
       else if (p.role < 2 && (respawn || !(done && p.auto_reset))) {
         const bool heavy = respawn || es.t + 1.0 / MCR_FPS < 1.0;
-        if (heavy) p.vorder[atomicAdd(&p.vcount[0], 1)] = env;
-        else p.vorder[p.B - 1 - atomicAdd(&p.vcount[1], 1)] = env;
+        const int vslot = respawn ? (es.slot ^ 1) : es.slot;
+        const int vP = ((const McrSlotHeader*)(p.slots + ((size_t)env * 2 + vslot) * MCR_SLOT_BYTES))->P;
+        const int entry = env | (vslot << MCR_VORDER_SLOT_SHIFT) | (vP << MCR_VORDER_P_SHIFT);
+        if (heavy) p.vorder[atomicAdd(&p.vcount[0], 1)] = entry;
+        else p.vorder[p.B - 1 - atomicAdd(&p.vcount[1], 1)] = entry;
       }
     } else {
       E->t = es.t + 1.0 / MCR_FPS;

@@ -112,15 +112,23 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
   //   role >= 2 (side streams): the envs of the contact / deferred lists;  use_vorder (step path): the order k_dynamics
   //   recorded, heavy (zoomed-out) envs first;  role 1: not the envs the side streams draw;  only_just_reset: reset().
   if (PERSIST) __builtin_amdgcn_s_setprio(3);                               // a few envs beside the main launch that fills every CU: they go first
-  int my_env = -1, my_slot = 0;
+  int my_env = -1, my_slot = 0, my_P = -1;
   {
     const int s = (int)blockIdx.x + (PERSIST ? lane * (int)gridDim.x : 0);
     int e = -1;
     if (p.role >= 2) { e = mcr_env_of_slot(p, s); if (e >= p.env0 + p.nenv) e = -1; }
-    else if (p.use_vorder) { const int nh = p.vcount[0], nn = p.vcount[1]; if (s < nh + nn) e = p.vorder[s < nh ? s : p.B - 1 - (s - nh)]; }
+    else if (p.use_vorder) {
+      // one load instead of a chain of four (list counts -> list entry -> env record -> slot header): the entry k_dynamics left
+      // carries the env, its episode slot and the slot's entry count; only envs this launch draws are listed (active, not
+      // the contact chain's, not deferred), unused entries hold -1 and every used one is reset below for its next use
+      const int v = s < p.B ? p.vorder[s] : -1;
+      if (v != -1) { e = v & MCR_VORDER_ENV_MASK; my_slot = (v >> MCR_VORDER_SLOT_SHIFT) & 1; my_P = (v >> MCR_VORDER_P_SHIFT) & 1023; }
+    }
     else if (s < p.nenv) e = p.env0 + s;
-    if (e >= 0 && p.role == 1 && (p.part[e] || p.dpart[e])) e = -1;
-    if (e >= 0) {
+    if (e >= 0 && !p.use_vorder) {
+      if (p.role == 1 && (p.part[e] || p.dpart[e])) e = -1;
+    }
+    if (e >= 0 && (!p.use_vorder || p.role >= 2)) {
       const McrEnvState es = p.env[e];
       // side-stream raster: a contact env re-spawned by this step's dynamics is drawn after its reset pass
       if (!es.active || (only_just_reset && !es.just_reset) || (p.role >= 2 && !only_just_reset && es.resetting)) e = -1;
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
   // what a candidate needs from HBM, requested one round ahead
   struct Raw { float4 a, b, c, d; uint32_t m; };     // quad: a = v0 v1, b = v2 v3, m = meta | car polygon: a..d = 8 vertices, m = vertex count
   Raw nxt; nxt.a = nxt.b = nxt.c = nxt.d = make_float4(0.0f, 0.0f, 0.0f, 0.0f); nxt.m = 0u;
-  P = ((const McrSlotHeader*)slot)->P;
+  P = (!PERSIST && my_P >= 0) ? my_P : ((const McrSlotHeader*)slot)->P;
   const int dbg = p.debug;
   unsigned long long pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = PHASES ? __builtin_readcyclecounter() : 0ull;
 
@@ -246,6 +254,7 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
     PHASE_ACC(0);
     __syncthreads();                                                        // this view's record and block list are in LDS; the previous view's resolve is through with the key buffer
     PHASE_ACC(1);
+    if (!PERSIST && vs == 0 && tid == 0 && my_P >= 0) p.vorder[blockIdx.x] = -1;   // every wavefront has read the entry: free it for the step after next
     // the next view's record, block list and (new env) tile flags / entry count travel while this one is drawn
     if (nv_ok && tid >= 64 && tid < 64 + MCR_VIEWP_FLOATS) vrec[buf ^ 1][tid - 64] = p.viewp[(size_t)vw_v * MCR_VIEWP_FLOATS + (tid - 64)];
     if (nv_ok && wave == 3) list_blocks(slot_v, vw_v, buf ^ 1);

@@ -61,6 +61,7 @@ struct mcr_env {
   int32_t step_count;         // steps launched: the epoch of the three-chain step's per-env "contact pass done" words
   bool bp_fresh;              // mcr_set_bodies teleported cars: the next contact pass re-creates their broadphase proxies
   int simd_count;             // SIMDs of the device (4 per CU)
+  bool vorder_dirty[2];       // the raster order list of that step parity was filled by a step that did not draw
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -97,10 +98,11 @@ static bool kernels_overlap(hipStream_t sa, hipStream_t sb) {
 
 extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   if (!cfg || !out) { g_err = "null argument"; return MCR_ERR_ARG; }
-  if (cfg->num_envs < 1 || cfg->num_agents < 1 || cfg->num_agents > MCR_MAX_AGENTS) { g_err = "num_envs/num_agents out of range"; return MCR_ERR_ARG; }
+  if (cfg->num_envs < 1 || cfg->num_envs > MCR_VORDER_ENV_MASK || cfg->num_agents < 1 || cfg->num_agents > MCR_MAX_AGENTS) { g_err = "num_envs/num_agents out of range"; return MCR_ERR_ARG; }
   HIPCHK(hipSetDevice(cfg->device));
   mcr_env* h = new mcr_env();
   h->cfg = *cfg; h->timing = 0; h->any_reset = false; h->use_graph = 0; h->verdict_fresh = false; h->concurrent_collide = false; h->sg[0].valid = h->sg[1].valid = false;
+  h->vorder_dirty[0] = h->vorder_dirty[1] = false;
   h->status_host = nullptr; h->step_count = 0; h->bp_fresh = false; memset(h->status_seen, 0, sizeof(h->status_seen));
   { hipDeviceProp_t prop; h->simd_count = (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess ? prop.multiProcessorCount : 256) * 4; }
   for (int i = 0; i < MCR_TIMING_SLOTS; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
@@ -139,6 +141,8 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   h->slab_bytes = off;
   if (hipMalloc(&h->slab, off) != hipSuccess) { g_err = "hipMalloc failed"; delete h; return MCR_ERR_HIP; }
   (void)hipMemset(h->slab, 0, o_slots);
+  for (int par = 0; par < 2; ++par)      // raster order lists (per step parity: 2 counts, then B entries): -1 = unused entry
+    (void)hipMemset((uint8_t*)h->slab + o_vorder + sizeof(int32_t) * ((size_t)par * (B + 2) + 2), 0xff, sizeof(int32_t) * (size_t)B);
   uint8_t* base = (uint8_t*)h->slab;
   McrParams& P = h->P;
   memset(&P, 0, sizeof(P));
@@ -301,6 +305,10 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   // list launches (contact / deferred / re-spawned envs): small grids whose workgroups walk the device-side lists
   const int lg_col = std::min(B, MCR_LIST_GRID), lg_dyn = std::min((B + MCR_SIDE_ENVS_PER_WAVE - 1) / MCR_SIDE_ENVS_PER_WAVE, MCR_LIST_GRID / MCR_SIDE_ENVS_PER_WAVE);
   const bool draw = P.obs != nullptr;
+  // (the raster workgroups reset the raster order entries they consume; a step that filled the list of its parity without
+  // drawing — mcr_step without an observation buffer on a handle that has one — left it unconsumed: wipe it before its next use)
+  if (h->vorder_dirty[h->step_parity]) { (void)hipMemsetAsync(h->P.vcount + (size_t)h->step_parity * (B + 2) + 2, 0xff, sizeof(int32_t) * (size_t)B, st); h->vorder_dirty[h->step_parity] = false; }
+  if (!draw && h->cfg.obs_enabled) h->vorder_dirty[h->step_parity] = true;
   P.role = 0; P.split = h->split ? 1 : 0; P.defer_after = 0; P.respawn_list = 0;
   {   // the device-side lists of a step are double-buffered by step parity: no memset, and nobody zeroes a list somebody reads
     const size_t par = (size_t)h->step_parity, oth = par ^ 1;

@@ -47,8 +47,10 @@ struct McrParams {
   double* stats;                // [2] rollout statistics accumulated on the device: episodes finished, sum of their returns over all agents
   unsigned long long* counters; // [4] diagnostics: 0 envs deferred, 1 envs resumed, 2 contact envs routed to the side stream
   int32_t defer_after;          // position sweeps the main launch grants before it defers an env (0: never)
-  int32_t* vorder;              // [B] raster order of the main launch: heavy envs from the front, the others from the back
-  int32_t* vcount;              // [2] number of heavy / other envs in vorder (zeroed by k_collide pass 0)
+  int32_t* vorder;              // [B] raster order of the main launch: heavy envs from the front, the others from the back, -1 in between.
+                                // An entry is env | episode slot << 20 | road_poly entries of that slot << 21 (everything a raster
+                                // workgroup needs to start loading); the workgroup that draws it resets it to -1
+  int32_t* vcount;              // [2] number of heavy / other envs in vorder (zeroed by the previous step's main k_dynamics)
   int32_t use_vorder;           // k_view maps workgroups to envs through vorder (step path, roles 0/1)
   int32_t role;                 // 0: every env; 1: main stream (skips part envs); 2: contact envs (clist); 3: deferred envs (dlist); 4: both lists
   // step I/O
@@ -66,6 +68,9 @@ struct McrParams {
   double h_ratio;
 };
 
+#define MCR_VORDER_ENV_MASK 0xfffff
+#define MCR_VORDER_SLOT_SHIFT 20
+#define MCR_VORDER_P_SHIFT 21
 // per-car view parameters (f32): camera (:540-556) and HUD rectangles (:634-674) in pixel units
 #define MCR_VIEWP_FLOATS 48
 enum { VP_CAM = 0 /*m00 m01 m10 m11 tx ty*/, VP_INV = 6 /*ax bx cx0 ay by cy0*/, VP_IND = 12 /*7 x (x0 x1 y0 y1)*/, VP_HUDTOP = 40,
