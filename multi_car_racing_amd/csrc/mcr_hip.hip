@@ -30,6 +30,7 @@ extern "C" const char* mcr_version(void) { return "mcr-hip 0.1 (gfx950)"; }
     }                                                                                                     \
   } while (0)
 
+#define MCR_LIST_GRID 128        // workgroups of a list launch (they walk the device-side list)
 struct TimedLaunch { int id; hipEvent_t a, b; };
 
 struct mcr_env {
@@ -61,6 +62,7 @@ struct mcr_env {
   int32_t step_count;         // steps launched: the epoch of the three-chain step's per-env "contact pass done" words
   bool bp_fresh;              // mcr_set_bodies teleported cars: the next contact pass re-creates their broadphase proxies
   int simd_count;             // SIMDs of the device (4 per CU)
+  int chain_grid;             // workgroups of a list chain launch (each walks the list, 2 envs at a time)
   bool vorder_dirty[2];       // the raster order list of that step parity was filled by a step that did not draw
 };
 
@@ -103,6 +105,11 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   mcr_env* h = new mcr_env();
   h->cfg = *cfg; h->timing = 0; h->any_reset = false; h->use_graph = 0; h->verdict_fresh = false; h->concurrent_collide = false; h->sg[0].valid = h->sg[1].valid = false;
   h->vorder_dirty[0] = h->vorder_dirty[1] = false;
+  // A list chain is a serial solver chain per wavefront (2 envs each): with two cars per env the contact list holds ~15 envs
+  // of 4096 and 64 workgroups walk it in one round; with more cars per env it is long (N = 8: hundreds of envs) and every
+  // further round of the walk adds a whole chain (~300 us) to the side stream, so the grid grows with N.
+  h->chain_grid = cfg->num_agents <= 2 ? MCR_LIST_GRID / MCR_SIDE_ENVS_PER_WAVE : 4 * MCR_LIST_GRID;
+  if (const char* g = getenv("MCR_CHAIN_GRID")) { const int v = atoi(g); if (v > 0) h->chain_grid = v; }
   h->status_host = nullptr; h->step_count = 0; h->bp_fresh = false; memset(h->status_seen, 0, sizeof(h->status_seen));
   { hipDeviceProp_t prop; h->simd_count = (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess ? prop.multiProcessorCount : 256) * 4; }
   for (int i = 0; i < MCR_TIMING_SLOTS; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
@@ -190,8 +197,12 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
         (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&h->ev_col, hipEventDisableTiming);
-        // (beyond 4 cars per env the one-step-ahead touch verdict — a second pass over up to 28 car pairs — costs more than
-        // the contact pass gains by running beside the dynamics: measured at N = 8)
+        // (beyond 4 cars per env the one-step-ahead touch verdict — a second pass over up to 28 car pairs — costs more than the
+        // contact pass gains by running beside the dynamics: measured at N = 8, round 2: 3.66 vs 4.28 M env-steps/s.  Round 3 tried a
+        // CONSERVATIVE verdict there instead — bounding discs + car boxes, no narrowphase, the contact chain taking every env it
+        // marks: with ~340 of 4096 envs in contact and as many near misses per step the side stream's chain, bookkeeping and raster
+        // grow faster than the 110 us of k_collide that leave the critical path: 1.40 vs 0.975 ms per step.  What bounds N = 8 is the
+        // contact chain itself — 585 us for its slowest wavefront, a sequential Gauss-Seidel over the contacts between the joint sweeps)
         h->concurrent_collide = N <= 4 && !getenv("MCR_SEQUENTIAL_COLLIDE") && (B * G + 63) / 64 <= h->simd_count && kernels_overlap(h->s_defer, h->s_side);
         h->split = true;
       } else (void)hipStreamDestroy(h->s_side);
@@ -267,12 +278,13 @@ void mcr_view_launch(int variant, int grid, hipStream_t st, const McrParams& P, 
 // raster launch (k_view.h).  Main launches: one workgroup per work slot.  List launches (role >= 2): MCR_LIST_GRID
 // persistent workgroups that walk the list (lane k of a wavefront holds a workgroup's k-th env, so never fewer than
 // slots / 64 workgroups).
-#define MCR_LIST_GRID 128
-static int list_grid(int slots) { return std::min(slots, std::max(MCR_LIST_GRID, (slots + 63) / 64)); }
+static int list_grid(int slots, int want) { return std::min(slots, std::max(want, (slots + 63) / 64)); }
 static void launch_view(mcr_env* h, int kid, int slots, hipStream_t st, const McrParams& P, int only_just_reset) {
   TimedLaunch tl; const bool tm = (h->timing >> kid) & 1;
   if (tm) { tl.id = kid; tl.a = get_event(h); tl.b = get_event(h); (void)hipEventRecord(tl.a, st); }
-  if (P.role >= 2) mcr_view_launch(2, list_grid(slots), st, P, h->view_stamps, only_just_reset);
+  // (list launches: with more than two cars per env the contact list is long — N = 8: ~340 envs x 8 views per step — and 128
+  // workgroups would draw ~20 views each, one after the other, at the end of the side stream's chain)
+  if (P.role >= 2) mcr_view_launch(2, list_grid(slots, P.N <= 2 ? MCR_LIST_GRID : 8 * MCR_LIST_GRID), st, P, h->view_stamps, only_just_reset);
   else mcr_view_launch((P.debug & 32) ? 1 : 0, slots, st, P, h->view_stamps, only_just_reset);
   if (tm) { (void)hipEventRecord(tl.b, st); h->pending.push_back(tl); }
 }
@@ -303,7 +315,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   const int B = P.B, N = P.N;
   const int dyn_blocks = (B * P.G + 63) / 64;
   // list launches (contact / deferred / re-spawned envs): small grids whose workgroups walk the device-side lists
-  const int lg_col = std::min(B, MCR_LIST_GRID), lg_dyn = std::min((B + MCR_SIDE_ENVS_PER_WAVE - 1) / MCR_SIDE_ENVS_PER_WAVE, MCR_LIST_GRID / MCR_SIDE_ENVS_PER_WAVE);
+  const int lg_col = std::min(B, MCR_LIST_GRID), lg_dyn = std::min((B + MCR_SIDE_ENVS_PER_WAVE - 1) / MCR_SIDE_ENVS_PER_WAVE, h->chain_grid);
   const bool draw = P.obs != nullptr;
   // (the raster workgroups reset the raster order entries they consume; a step that filled the list of its parity without
   // drawing — mcr_step without an observation buffer on a handle that has one — left it unconsumed: wipe it before its next use)
@@ -360,7 +372,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   // bookkeeping of a chain's cars: fused into the chain for N <= 2 (2 envs x N cars take their turns on one wavefront),
   // a list launch of its own beyond that
   const int fuse_flags = (view_flags && N <= 2) ? 1 : 0;
-  const int lg_flags = std::min(B * N, 4 * MCR_LIST_GRID);
+  const int lg_flags = std::min(B * N, (N <= 2 ? 4 : 32) * MCR_LIST_GRID);
   P.role = 2;
   LAUNCH_LDS(5, k_list_chain, lg_dyn, 64, col::lds_bytes(N), h->s_side, P, fuse_flags);
   if (view_flags && !fuse_flags) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, h->s_side, P);
