@@ -62,29 +62,22 @@ __device__ __forceinline__ void span_edge(float ax, float ay, float bx, float by
   cl = Au > 0.0f ? c : -BIG;
   ch = Au < 0.0f ? c : BIG;
 }
-// Span record(s) of one convex polygon in pixel space that survived the cull with pixel-centre ranges [i0,i1] x [j0,j1]:
-// 4 vertices, or 8 (`eight`: the tail is padded by repeating the last vertex, such edges bound nothing) in two slots.
-// Returns the record's meta word (0: degenerate, nothing to draw).
-__device__ __forceinline__ uint32_t setup_poly(const float* px, const float* py, bool eight, uint32_t key, int i0, int i1, int j0, int j1,
+// Span record of four consecutive edges v0->v1->v2->v3->v4 of a convex polygon in pixel space that survived the cull with
+// pixel-centre ranges [i0,i1] x [j0,j1] (a quad: v4 = v0; an 8-gon takes two records in adjacent slots, the halves 0..4 and
+// 4..7,0, written by two threads that share the polygon's orientation, scan axis and line range).  `area`: the polygon's
+// signed area x 2.  Returns the scan-axis / line-range bits of the meta word (0: degenerate, nothing to draw).
+__device__ __forceinline__ uint32_t setup_half(const float* x5, const float* y5, float area, int i0, int i1, int j0, int j1,
                                                float4 (*rdat)[3], int slot) {
-  const float c3x = eight ? px[4] : px[0], c3y = eight ? py[4] : py[0];               // end point of edge 3
-  float area = (px[0] * py[1] - px[1] * py[0]) + (px[1] * py[2] - px[2] * py[1]) + (px[2] * py[3] - px[3] * py[2]) + (px[3] * c3y - c3x * py[3]);
-  if (eight) area += (px[4] * py[5] - px[5] * py[4]) + (px[5] * py[6] - px[6] * py[5]) + (px[6] * py[7] - px[7] * py[6]) + (px[7] * py[0] - px[0] * py[7]);
   uint32_t meta = 0u;
   if (area != 0.0f) {
     const float sg = area > 0.0f ? 1.0f : -1.0f;
     const bool row = (j1 - j0) >= (i1 - i0);                       // scan along the longer axis: many short spans
     const int l0 = row ? j0 : i0, nl = (row ? j1 : i1) - l0 + 1;
     float4 S4, L4, H4;
-    span_edge(px[0], py[0], px[1], py[1], sg, row, S4.x, L4.x, H4.x); span_edge(px[1], py[1], px[2], py[2], sg, row, S4.y, L4.y, H4.y);
-    span_edge(px[2], py[2], px[3], py[3], sg, row, S4.z, L4.z, H4.z); span_edge(px[3], py[3], c3x, c3y, sg, row, S4.w, L4.w, H4.w);
+    span_edge(x5[0], y5[0], x5[1], y5[1], sg, row, S4.x, L4.x, H4.x); span_edge(x5[1], y5[1], x5[2], y5[2], sg, row, S4.y, L4.y, H4.y);
+    span_edge(x5[2], y5[2], x5[3], y5[3], sg, row, S4.z, L4.z, H4.z); span_edge(x5[3], y5[3], x5[4], y5[4], sg, row, S4.w, L4.w, H4.w);
     rdat[slot][0] = S4; rdat[slot][1] = L4; rdat[slot][2] = H4;
-    if (eight) {
-      span_edge(px[4], py[4], px[5], py[5], sg, row, S4.x, L4.x, H4.x); span_edge(px[5], py[5], px[6], py[6], sg, row, S4.y, L4.y, H4.y);
-      span_edge(px[6], py[6], px[7], py[7], sg, row, S4.z, L4.z, H4.z); span_edge(px[7], py[7], px[0], py[0], sg, row, S4.w, L4.w, H4.w);
-      rdat[slot + 1][0] = S4; rdat[slot + 1][1] = L4; rdat[slot + 1][2] = H4;
-    }
-    meta = key | (row ? REC_ROW : 0u) | (eight ? REC_CHAIN : 0u) | ((uint32_t)l0 << 18) | ((uint32_t)nl << 25);
+    meta = (row ? REC_ROW : 0u) | ((uint32_t)l0 << 18) | ((uint32_t)nl << 25);
   }
   return meta;
 }
@@ -212,8 +205,8 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
       if (q < pe) { r.a = ((const float4*)(sl + MCR_OFF_QA))[q]; r.b = ((const float4*)(sl + MCR_OFF_QB))[q]; r.m = ((const uint32_t*)(sl + MCR_OFF_QMETA))[q]; }
     } else if (c >= sb && c - sb < 14 * N) {
       const int cc = (c - sb) / 14, sl14 = (c - sb) - cc * 14;
-      const int j = sl14 < 11 ? sl14 : sl14 - 1;                            // slot 11 is the second half of polygon 10 (the 8-gon), slot 13 a pad
-      if (sl14 != 11 && sl14 != 13) {
+      const int j = sl14 < 11 ? sl14 : sl14 - 1;                            // slot 11 sets up the second half of polygon 10 (the 8-gon): same data; slot 13 is a pad
+      if (sl14 != 13) {
         const float* __restrict__ cp = p.carpoly + (size_t)(e * N + cc) * MCR_CARPOLY_FLOATS;
         const float4* cv = (const float4*)(cp + j * 16);
         r.a = cv[0]; r.b = cv[1]; r.c = cv[2]; r.d = cv[3];
@@ -305,55 +298,54 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
       }
       const bool mine = tid < RC;
       uint32_t my_meta = 0u;                                                // a culled slot has no lines
+      // Every candidate, whatever its kind, is "4 (or 8) vertices in world or pixel space + a key": a short kind-specific head
+      // produces them, ONE common tail transforms, culls and sets the span record up — a wavefront that holds several kinds
+      // of candidates (road quads and cars; gauges; grass) runs the tail once, not once per kind.
+      float wx[8], wy[8];
+      uint32_t key = 0u; int cminY = 12, nn = 0;                            // nn: 0 nothing; 4 / 8 vertices in world space; -4: 4 vertices in pixel space
+      bool half2 = false;                                                   // this slot sets up the SECOND half (edges 4..7) of an 8-gon
       const int q = (mine && c < Pv) ? quad_of(c, buf) : P;
       if (q < P) {
         // ---- road_poly entry
-        const float wx[4] = {cur.a.x, cur.a.z, cur.b.x, cur.b.z}, wy[4] = {cur.a.y, cur.a.w, cur.b.y, cur.b.w};
         const uint32_t meta = cur.m;
         const uint32_t tile1 = (meta >> 8) & 0x3ffu;
         if (!(dbg & 18)) {
-          float px[4], py[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { px[i] = __builtin_fmaf(m00, wx[i], __builtin_fmaf(m01, wy[i], ctx)); py[i] = __builtin_fmaf(m10, wx[i], __builtin_fmaf(m11, wy[i], cty)); }
-          const float x0 = fminf(fminf(px[0], px[1]), fminf(px[2], px[3])), x1 = fmaxf(fmaxf(px[0], px[1]), fmaxf(px[2], px[3]));
-          const float y0 = fminf(fminf(py[0], py[1]), fminf(py[2], py[3])), y1 = fmaxf(fmaxf(py[0], py[1]), fmaxf(py[2], py[3]));
-          int i0, i1, j0, j1;
-          if (centre_range(x0, x1, 0, 95, i0, i1) && centre_range(y0, y1, 12, 95, j0, j1)) {    // rows < 12: HUD bar
-            uint32_t col = meta & 0xffu;
-            if (tile1 && ((tfl[(tile1 - 1) >> 1] >> (((tile1 - 1) & 1u) * 16u)) & 0x100u)) col = MCR_COL_ROAD0;     // touched tile -> ROAD_COLOR (:102-104)
-            const uint32_t pal = col == MCR_COL_ROAD0 ? PAL_ROAD0 : col == MCR_COL_ROAD1 ? PAL_ROAD1 : col == MCR_COL_ROAD2 ? PAL_ROAD2 : col == MCR_COL_KERB_WHITE ? PAL_WHITE : PAL_RED255;
-            my_meta = setup_poly(px, py, false, mk_key(RANK_SLOT0 + tid, pal), i0, i1, j0, j1, rdat, tid);
-          }
+          wx[0] = cur.a.x; wy[0] = cur.a.y; wx[1] = cur.a.z; wy[1] = cur.a.w; wx[2] = cur.b.x; wy[2] = cur.b.y; wx[3] = cur.b.z; wy[3] = cur.b.w;
+          uint32_t col = meta & 0xffu;
+          if (tile1 && ((tfl[(tile1 - 1) >> 1] >> (((tile1 - 1) & 1u) * 16u)) & 0x100u)) col = MCR_COL_ROAD0;     // touched tile -> ROAD_COLOR (:102-104)
+          const uint32_t pal = col == MCR_COL_ROAD0 ? PAL_ROAD0 : col == MCR_COL_ROAD1 ? PAL_ROAD1 : col == MCR_COL_ROAD2 ? PAL_ROAD2 : col == MCR_COL_KERB_WHITE ? PAL_WHITE : PAL_RED255;
+          key = mk_key(RANK_SLOT0 + tid, pal); nn = 4;
         }
-      } else if (const int sidx = special_of(c, spread, SB, F, G); mine && sidx >= 0) {
+      } else if (const int sidx = mine ? special_of(c, spread, SB, F, G) : -1; sidx >= 0) {
         // ---- specials
-        float px[8], py[8]; uint32_t key = 0; int cminY = 12, nn = 0;    // nn: 4 / 8 vertices in world space, -4: 4 vertices in pixel space
-        float wx[8], wy[8];
         if (sidx < 14 * N) {                                                // Car.draw polygon
           const int cc = sidx / 14, sl = sidx - cc * 14;
           const int j = sl < 11 ? sl : sl - 1;
           const int n = (int)cur.m;
-          if (sl != 11 && sl != 13 && n > 0 && !(dbg & 4)) {
+          if (sl != 13 && n > 0 && !(dbg & 4) && (sl != 11 || n > 4)) {
             wx[0] = cur.a.x; wy[0] = cur.a.y; wx[1] = cur.a.z; wy[1] = cur.a.w; wx[2] = cur.b.x; wy[2] = cur.b.y; wx[3] = cur.b.z; wy[3] = cur.b.w;
             wx[4] = cur.c.x; wy[4] = cur.c.y; wx[5] = cur.c.z; wy[5] = cur.c.w; wx[6] = cur.d.x; wy[6] = cur.d.y; wx[7] = cur.d.z; wy[7] = cur.d.w;
             uint32_t colr;
             if (j < 8) colr = (j & 1) ? PAL_WHEELWHITE : PAL_BLACK;
             else { colr = PAL_CAR0 + (cc & 7); if (p.use_ego_color) colr = (cc == agent) ? PAL_CAR0 + 0 : PAL_CAR0 + 1; }   // :402, :560-563
-            key = mk_key(RANK_SLOT0 + tid, colr);
-            nn = (n > 4 && sl == 10) ? 8 : 4;                               // only HULL_POLY3 has more than 4 vertices (mcr_create checks); k_dynamics pads to 8
+            // only HULL_POLY3 (slots 10 + 11) has more than 4 vertices (mcr_create checks); k_dynamics pads to 8.  Both of its
+            // slots carry the key of the FIRST one: the fill reads the second record through the first one's meta word
+            half2 = sl == 11;
+            key = mk_key(RANK_SLOT0 + tid - (half2 ? 1 : 0), colr);
+            nn = (n > 4 && sl >= 10) ? 8 : 4;
           }
         } else if (sidx < F) {
           const int h = sidx - 14 * N;
           if (h < 7) {                                                      // gauges (:643-663), already in pixel units
             const float gx0 = vr[VP_IND + h * 4], gx1 = vr[VP_IND + h * 4 + 1], gy0 = vr[VP_IND + h * 4 + 2], gy1 = vr[VP_IND + h * 4 + 3];
             if (gx1 > gx0 && gy1 > gy0) {
-              px[0] = gx0; py[0] = gy0; px[1] = gx1; py[1] = gy0; px[2] = gx1; py[2] = gy1; px[3] = gx0; py[3] = gy1;
+              wx[0] = gx0; wy[0] = gy0; wx[1] = gx1; wy[1] = gy0; wx[2] = gx1; wy[2] = gy1; wx[3] = gx0; wy[3] = gy1;
               const uint32_t col = h == 0 ? PAL_WHITE : h <= 2 ? PAL_BLUE255 : h <= 4 ? PAL_PURPLE : h == 5 ? PAL_GREEN255 : PAL_RED255;
               key = mk_key(RANK_SLOT0 + tid, col) | REC_HUD; nn = -4; cminY = 0;
             }
           } else if (h == 7) {                                              // backwards flag (:669-674): drawn with last step's flag
             if ((old_flags & 1u) && p.backwards_flag) {
-              px[0] = 900.0f * kx; py[0] = 30.0f * ky; px[1] = 925.0f * kx; py[1] = 70.0f * ky; px[2] = 950.0f * kx; py[2] = 30.0f * ky; px[3] = px[2]; py[3] = py[2];
+              wx[0] = 900.0f * kx; wy[0] = 30.0f * ky; wx[1] = 925.0f * kx; wy[1] = 70.0f * ky; wx[2] = 950.0f * kx; wy[2] = 30.0f * ky; wx[3] = wx[2]; wy[3] = wy[2];
               key = mk_key(RANK_SLOT0 + tid, PAL_BLUE255) | REC_HUD; nn = -4; cminY = 0;
             }
           } else {                                                          // playfield quad (:615-619), only when the view leaves it
@@ -367,25 +359,42 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
           wx[0] = ghi[tu]; wy[0] = glo[tv]; wx[1] = glo[tu]; wy[1] = glo[tv]; wx[2] = glo[tu]; wy[2] = ghi[tv]; wx[3] = ghi[tu]; wy[3] = ghi[tv];
           key = mk_key(RANK_GRASS, PAL_GRASS1); nn = 4;
         }
+      }
+      // ---- common tail
+      if (nn != 0) {
         const bool eight = nn == 8;
+        float px[8], py[8];
         if (nn > 0) {                                                       // camera transform (world -> pixel)
 #pragma unroll
           for (int i = 0; i < 4; ++i) { px[i] = __builtin_fmaf(m00, wx[i], __builtin_fmaf(m01, wy[i], ctx)); py[i] = __builtin_fmaf(m10, wx[i], __builtin_fmaf(m11, wy[i], cty)); }
-          if (eight) {
+        } else {
 #pragma unroll
-            for (int i = 4; i < 8; ++i) { px[i] = __builtin_fmaf(m00, wx[i], __builtin_fmaf(m01, wy[i], ctx)); py[i] = __builtin_fmaf(m10, wx[i], __builtin_fmaf(m11, wy[i], cty)); }
-          }
+          for (int i = 0; i < 4; ++i) { px[i] = wx[i]; py[i] = wy[i]; }
         }
-        if (nn != 0) {
-          float x0 = fminf(fminf(px[0], px[1]), fminf(px[2], px[3])), x1 = fmaxf(fmaxf(px[0], px[1]), fmaxf(px[2], px[3]));
-          float y0 = fminf(fminf(py[0], py[1]), fminf(py[2], py[3])), y1 = fmaxf(fmaxf(py[0], py[1]), fmaxf(py[2], py[3]));
-          if (eight) {
-            x0 = fminf(x0, fminf(fminf(px[4], px[5]), fminf(px[6], px[7]))); x1 = fmaxf(x1, fmaxf(fmaxf(px[4], px[5]), fmaxf(px[6], px[7])));
-            y0 = fminf(y0, fminf(fminf(py[4], py[5]), fminf(py[6], py[7]))); y1 = fmaxf(y1, fmaxf(fmaxf(py[4], py[5]), fmaxf(py[6], py[7])));
+        float x0 = fminf(fminf(px[0], px[1]), fminf(px[2], px[3])), x1 = fmaxf(fmaxf(px[0], px[1]), fmaxf(px[2], px[3]));
+        float y0 = fminf(fminf(py[0], py[1]), fminf(py[2], py[3])), y1 = fmaxf(fmaxf(py[0], py[1]), fmaxf(py[2], py[3]));
+        float area = (px[0] * py[1] - px[1] * py[0]) + (px[1] * py[2] - px[2] * py[1]) + (px[2] * py[3] - px[3] * py[2]);
+        float x5[5], y5[5];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x5[i] = px[i]; y5[i] = py[i]; }
+        x5[4] = px[0]; y5[4] = py[0];
+        if (eight) {
+#pragma unroll
+          for (int i = 4; i < 8; ++i) { px[i] = __builtin_fmaf(m00, wx[i], __builtin_fmaf(m01, wy[i], ctx)); py[i] = __builtin_fmaf(m10, wx[i], __builtin_fmaf(m11, wy[i], cty)); }
+          x0 = fminf(x0, fminf(fminf(px[4], px[5]), fminf(px[6], px[7]))); x1 = fmaxf(x1, fmaxf(fmaxf(px[4], px[5]), fmaxf(px[6], px[7])));
+          y0 = fminf(y0, fminf(fminf(py[4], py[5]), fminf(py[6], py[7]))); y1 = fmaxf(y1, fmaxf(fmaxf(py[4], py[5]), fmaxf(py[6], py[7])));
+          area = (area + (px[3] * py[4] - px[4] * py[3])) + ((px[4] * py[5] - px[5] * py[4]) + (px[5] * py[6] - px[6] * py[5]) + (px[6] * py[7] - px[7] * py[6]) + (px[7] * py[0] - px[0] * py[7]));
+          x5[4] = px[4]; y5[4] = py[4];
+          if (half2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { x5[i] = px[4 + i]; y5[i] = py[4 + i]; }
+            x5[4] = px[0]; y5[4] = py[0];
           }
-          int i0, i1, j0, j1;
-          if (centre_range(x0, x1, 0, 95, i0, i1) && centre_range(y0, y1, cminY, 95, j0, j1))
-            my_meta = setup_poly(px, py, eight, key, i0, i1, j0, j1, rdat, tid);
+        } else area += px[3] * py[0] - px[0] * py[3];
+        int i0, i1, j0, j1;
+        if (centre_range(x0, x1, 0, 95, i0, i1) && centre_range(y0, y1, cminY, 95, j0, j1)) {          // rows < 12: HUD bar
+          const uint32_t geo = setup_half(x5, y5, area, i0, i1, j0, j1, rdat, tid);
+          if (geo && !half2) my_meta = key | geo | (eight ? REC_CHAIN : 0u);
         }
       }
       if (tid < RC) rmeta[tid] = my_meta;
@@ -433,17 +442,25 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
         __syncthreads();
         PHASE_ACC(5);
         const int nlines = min(TASK4_CAP, total - t0) * 4;
-        for (int i0 = 0; i0 < nlines; i0 += VIEW_THREADS) {
-          const int i = i0 + tid;
-          int len = 0, addr = 0, stride = 1; uint32_t key = 0;
-          if (i < nlines) {
-            const uint32_t e = tasks4[i >> 2];
-            const int sl = (int)(e >> 5), k = (int)((e & 31u) << 2) | (i & 3);
-            const uint32_t meta = rmeta[sl];
-            if (k < (int)(meta >> 25)) {
+        // Two line tasks per lane and trip: the three dependent LDS reads of a task (task entry -> record meta -> record) are
+        // issued for both before either is used — the phase is bound by that latency chain, not by the arithmetic.  Lanes
+        // without a task read entry 0 (harmless) and end up with an empty span.
+        for (int i0 = 0; i0 < nlines; i0 += 2 * VIEW_THREADS) {
+          const int iA = i0 + tid, iB = iA + VIEW_THREADS;
+          const bool inA = iA < nlines, inB = iB < nlines;
+          const uint32_t eA = tasks4[inA ? iA >> 2 : 0], eB = tasks4[inB ? iB >> 2 : 0];
+          const int slA = min((int)(eA >> 5), RC - 1), slB = min((int)(eB >> 5), RC - 1);
+          const int kA = (int)((eA & 31u) << 2) | (iA & 3), kB = (int)((eB & 31u) << 2) | (iB & 3);
+          const uint32_t mA = rmeta[slA], mB = rmeta[slB];
+          const float4 SA = rdat[slA][0], LA = rdat[slA][1], HA = rdat[slA][2];
+          const float4 SB4 = rdat[slB][0], LB = rdat[slB][1], HB = rdat[slB][2];
+          const uint32_t cA = palc[mA & 31u], cB = palc[mB & 31u];
+          auto span = [&](bool in, uint32_t meta, int sl, int k, const float4 Sl, const float4 Lo, const float4 Hi, uint32_t col,
+                          int& len, int& addr, int& stride, uint32_t& key) {
+            len = 0; addr = 0; stride = 1; key = 0u;
+            if (in && k < (int)(meta >> 25)) {
               const int line = (int)((meta >> 18) & 127u) + k;
               const float v = (float)line + 0.5f;
-              const float4 Sl = rdat[sl][0], Lo = rdat[sl][1], Hi = rdat[sl][2];
               float lo = fmaxf(fmaxf(__builtin_fmaf(Sl.x, v, Lo.x), __builtin_fmaf(Sl.y, v, Lo.y)), fmaxf(__builtin_fmaf(Sl.z, v, Lo.z), __builtin_fmaf(Sl.w, v, Lo.w)));
               float hi = fminf(fminf(__builtin_fmaf(Sl.x, v, Hi.x), __builtin_fmaf(Sl.y, v, Hi.y)), fminf(__builtin_fmaf(Sl.z, v, Hi.z), __builtin_fmaf(Sl.w, v, Hi.w)));
               if (meta & REC_CHAIN) {
@@ -451,7 +468,7 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
                 lo = fmaxf(lo, fmaxf(fmaxf(__builtin_fmaf(S2.x, v, L2.x), __builtin_fmaf(S2.y, v, L2.y)), fmaxf(__builtin_fmaf(S2.z, v, L2.z), __builtin_fmaf(S2.w, v, L2.w))));
                 hi = fminf(hi, fminf(fminf(__builtin_fmaf(S2.x, v, H2.x), __builtin_fmaf(S2.y, v, H2.y)), fminf(__builtin_fmaf(S2.z, v, H2.z), __builtin_fmaf(S2.w, v, H2.w))));
               }
-              key = ((meta << 19) & 0xff000000u) | palc[meta & 31u];
+              key = ((meta << 19) & 0xff000000u) | col;
               const bool row = (meta & REC_ROW) != 0u;
               // rows < 12 belong to the HUD: scene polygons stop at y = 12 (row scans are clipped by their line range)
               const float cmin = (meta & (REC_ROW | REC_HUD)) ? 0.0f : 12.0f;
@@ -461,12 +478,13 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
               addr = (row ? line : a) * KS + (row ? a : line);
               stride = row ? 1 : KS;
             }
-          }
-          // a lane leaves the loop when its span is drawn (the wavefront iterates to its longest span)
-          if (len > 0) {
-            int j = 0;
-            do { atomicMax(&keyb[addr], key); addr += stride; } while (++j < len);
-          }
+          };
+          int lenA, addrA, strideA, lenB, addrB, strideB; uint32_t keyA, keyB;
+          span(inA, mA, slA, kA, SA, LA, HA, cA, lenA, addrA, strideA, keyA);
+          span(inB, mB, slB, kB, SB4, LB, HB, cB, lenB, addrB, strideB, keyB);
+          // a lane leaves a loop when its span is drawn (the wavefront iterates to its longest span)
+          if (lenA > 0) { int j = 0; do { atomicMax(&keyb[addrA], keyA); addrA += strideA; } while (++j < lenA); }
+          if (lenB > 0) { int j = 0; do { atomicMax(&keyb[addrB], keyB); addrB += strideB; } while (++j < lenB); }
         }
         PHASE_ACC(6);
         __syncthreads();                                                    // the next chunk / round rewrites tasks and records
