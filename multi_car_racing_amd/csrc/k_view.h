@@ -483,8 +483,10 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
           span(inA, mA, slA, kA, SA, LA, HA, cA, lenA, addrA, strideA, keyA);
           span(inB, mB, slB, kB, SB4, LB, HB, cB, lenB, addrB, strideB, keyB);
           // a lane leaves a loop when its span is drawn (the wavefront iterates to its longest span)
-          if (lenA > 0) { int j = 0; do { atomicMax(&keyb[addrA], keyA); addrA += strideA; } while (++j < lenA); }
-          if (lenB > 0) { int j = 0; do { atomicMax(&keyb[addrB], keyB); addrB += strideB; } while (++j < lenB); }
+          // (two pixels per trip: the loop's bookkeeping — 3 scalar + 2 vector instructions — is what the phase issues most of;
+          // the second ds_max of an odd span's last trip carries key 0, which changes nothing wherever it lands)
+          if (lenA > 0) { int j = 0; do { atomicMax(&keyb[addrA], keyA); atomicMax(&keyb[addrA + strideA], j + 1 < lenA ? keyA : 0u); addrA += 2 * strideA; j += 2; } while (j < lenA); }
+          if (lenB > 0) { int j = 0; do { atomicMax(&keyb[addrB], keyB); atomicMax(&keyb[addrB + strideB], j + 1 < lenB ? keyB : 0u); addrB += 2 * strideB; j += 2; } while (j < lenB); }
         }
         PHASE_ACC(6);
         __syncthreads();                                                    // the next chunk / round rewrites tasks and records
