@@ -146,7 +146,7 @@ def main():
         allowed = sorted(os.sched_getaffinity(0)); total = effective_cpus()
         share = max(1, total // args.emulate_world)
         os.sched_setaffinity(0, set(allowed[:share]))             # threads created from here on inherit it (generator pool, refill worker)
-        extra["gen_threads"] = max(1, total // args.emulate_world - 1)
+        extra["gen_threads"] = max(1, total // args.emulate_world)     # what VecMultiCarRacing gives a rank of a W-rank job
         emu = {"world": args.emulate_world, "cores_allowed_to_the_job": total, "cores_this_rank": share, "gen_threads": extra["gen_threads"]}
     env = ShardedVecEnv(B * world, N, seed=0, rank=rank, world_size=world, device=dev, obs=bool(args.obs),
                         auto_reset=True, use_random_direction=True, streams=args.streams, graph=bool(args.graph), **extra)
@@ -204,7 +204,7 @@ def main():
     TIME_EVERY = 8
     tmask = 0 if args.no_kernel_timing else (255 if args.time_all_kernels else 4)
     FENCE = LOOKAHEAD // 4
-    evs = [torch.cuda.Event() for _ in range(4)]
+    evs = [torch.cuda.Event(blocking=True) for _ in range(4)]       # the host sleeps at the look-ahead fence instead of spinning on a core the refill thread needs
     t0 = time.perf_counter()
     for k in range(K):
         if tmask:

@@ -461,11 +461,11 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
     // launch: 24 -> 146 us, measured) to publish lines nobody reads across XCDs; debug bit 11 selects it for measurements.
     if (p.debug & 2048) {
       __syncthreads();
-      if (lane == 0) __hip_atomic_store(&p.collide_epoch[env], p.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) __hip_atomic_store(&p.collide_epoch[env], mcr_epoch(p), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __syncthreads();
-      if (lane == 0) __hip_atomic_store(&p.collide_epoch[env], p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) __hip_atomic_store(&p.collide_epoch[env], mcr_epoch(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }

@@ -888,9 +888,10 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
     // this launch's one wavefront per SIMD); a give-up is REPORTED (status word -> mcr_step fails, the handle falls back to the
     // contact pass in front), never silent.  debug bit 12 shortens the bound (tests).
     const int bound = (p.debug & 4096) ? (1 << 14) : (1 << 24);
+    const int epoch = mcr_epoch(p);
     int spin = 0;
-    if (p.debug & 2048) { for (; spin < bound && __hip_atomic_load(&p.collide_epoch[env], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != p.epoch; ++spin) __builtin_amdgcn_s_sleep(8); }
-    else { for (; spin < bound && __hip_atomic_load(&p.collide_epoch[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch; ++spin) __builtin_amdgcn_s_sleep(8); }
+    if (p.debug & 2048) { for (; spin < bound && __hip_atomic_load(&p.collide_epoch[env], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch; ++spin) __builtin_amdgcn_s_sleep(8); }
+    else { for (; spin < bound && __hip_atomic_load(&p.collide_epoch[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch; ++spin) __builtin_amdgcn_s_sleep(8); }
     if (spin == bound) { atomicAdd(&p.counters[5], 1ull); atomicAdd(&p.status[ST_SPIN_GIVEUP], 1u); }
   }
   const bool cc_wait = p.cc_mode && mode == 0 && p.role == 1;

@@ -62,6 +62,7 @@ struct mcr_env {
   int32_t step_count;         // steps launched: the epoch of the three-chain step's per-env "contact pass done" words
   bool bp_fresh;              // mcr_set_bodies teleported cars: the next contact pass re-creates their broadphase proxies
   int simd_count;             // SIMDs of the device (4 per CU)
+  int32_t* dev_step_ctr;      // device-side step counter (the epoch of a replayed step graph)
   int chain_grid;             // workgroups of a list chain launch (each walks the list, 2 envs at a time)
   bool vorder_dirty[2];       // the raster order list of that step parity was filled by a step that did not draw
 };
@@ -71,9 +72,8 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // (probed at create), up to 4 cars per env (measured), and only for batches whose main dynamics launch puts at most one of its
 // 256-VGPR wavefronts on a SIMD: that launch waits INSIDE the kernel for words of the contact pass, which must be able to get onto
 // the machine beside it (one such wavefront per SIMD leaves half the register file and nearly all LDS free; two on every SIMD
-// could starve a contact pass dispatched second).  After a reported give-up the handle stays with the contact pass in front.  The
-// hipGraph replay (constant arguments) runs it in front as well.
-static bool cc_active(const mcr_env* h) { return h->split && h->concurrent_collide && h->use_graph <= 0; }
+// could starve a contact pass dispatched second).  After a reported give-up the handle stays with the contact pass in front.
+static bool cc_active(const mcr_env* h) { return h->split && h->concurrent_collide; }
 
 // Do kernels of two streams really run side by side in this process?  Under a counter-collecting profiler, a debugger or
 // AMD_SERIALIZE_KERNEL they do not — and the cc_mode step (the main dynamics waits inside the kernel for words the
@@ -84,6 +84,7 @@ __global__ void k_probe_wait(int* flag, int* result) {
   for (int i = 0; i < 20000 && !seen; ++i) { seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __builtin_amdgcn_s_sleep(32); }
   *result = seen;
 }
+__global__ void k_step_begin(int32_t* step_ctr) { *step_ctr += 1; }
 __global__ void k_probe_set(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 static bool kernels_overlap(hipStream_t sa, hipStream_t sb) {
   int* d = nullptr; int r = 0;
@@ -129,7 +130,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   const size_t o_bpstamp = carve(sizeof(uint32_t) * (size_t)B * MCR_TILE_CAP * 4 * N);
   const size_t o_part = carve(2 * (size_t)B);                 // x2: the touch verdicts of a step live in the buffer of its parity
   const size_t o_dpart = carve(B);
-  const size_t o_epoch = carve(sizeof(int32_t) * (size_t)B);
+  const size_t o_epoch = carve(sizeof(int32_t) * ((size_t)B + 1));
   const size_t o_dlist = carve(sizeof(int32_t) * 2 * ((size_t)B + 1));      // x2: the lists of a step live in the buffers of its parity
   const size_t o_rlist = carve(sizeof(int32_t) * 2 * ((size_t)B + 1));
   const size_t o_dstate = carve(BN);
@@ -159,7 +160,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   P.cc_store = (uint32_t*)(base + o_cc); P.bpf = (float*)(base + o_bpf); P.bp_stamp = (uint32_t*)(base + o_bpstamp); P.shapes = (const McrShapes*)(base + o_shapes); P.slots = base + o_slots;
   h->view_stamps = (unsigned long long*)(base + o_vscratch);
   P.viewp = (float*)(base + o_viewp);
-  P.part = base + o_part; P.dpart = base + o_dpart; P.collide_epoch = (int32_t*)(base + o_epoch); P.dlist = (int32_t*)(base + o_dlist); P.rlist = (int32_t*)(base + o_rlist); P.defer_state = base + o_dstate; P.counters = (unsigned long long*)(base + o_counters); P.stats = (double*)(base + o_stats);
+  P.part = base + o_part; P.dpart = base + o_dpart; P.collide_epoch = (int32_t*)(base + o_epoch); h->dev_step_ctr = P.collide_epoch + B; P.dlist = (int32_t*)(base + o_dlist); P.rlist = (int32_t*)(base + o_rlist); P.defer_state = base + o_dstate; P.counters = (unsigned long long*)(base + o_counters); P.stats = (double*)(base + o_stats);
   h->stage_ids = (int32_t*)(base + o_stage_ids); P.vcount = (int32_t*)(base + o_vorder); P.vorder = P.vcount + 2; P.dbg_stamps = (unsigned long long*)(base + o_stamps); P.clist = (int32_t*)(base + o_clist);
   P.carpoly = (float*)(base + o_carpoly);
   P.particles = cfg->skid_particles ? (uint32_t*)(base + o_particles) : nullptr;
@@ -362,7 +363,13 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   // Where kernels of different streams do not overlap (mcr_create probes it: counter-collecting profilers, debuggers) the
   // contact pass simply runs first, on the caller's stream.
     const bool cc = cc_active(h);
-  P.cc_mode = cc ? 1 : 0; P.epoch = h->step_count;
+  P.cc_mode = cc ? 1 : 0; P.epoch = h->step_count; P.epoch_ptr = nullptr;
+  if (h->use_graph > 0) {
+    // a replayed graph has constant arguments: the epoch lives in a device-side counter that the first node of the step advances
+    // (before the fork: the contact pass and the dynamics read the same value)
+    hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, st, h->dev_step_ctr);
+    P.epoch = 0; P.epoch_ptr = h->dev_step_ctr;
+  }
   if (!cc) LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), st, P, 0);
   (void)hipEventRecord(h->ev_fork, st);
   (void)hipStreamWaitEvent(h->s_side, h->ev_fork, 0);
@@ -499,7 +506,10 @@ extern "C" int mcr_step(mcr_env* h, const float* d_actions, uint8_t* d_obs, doub
 
 extern "C" int mcr_set_step_graph(mcr_env* h, int enable) {
   if (!h) { g_err = "null handle"; return MCR_ERR_ARG; }
-  if ((enable ? 1 : 0) != (h->use_graph > 0 ? 1 : 0)) h->verdict_fresh = false;      // the graph replay runs the contact pass in front (cc_active)
+  if (enable && h->use_graph <= 0) {     // the device-side epoch counter continues the host's (both advance once per step from here on)
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(h->dev_step_ctr, &h->step_count, sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   h->use_graph = enable ? 1 : 0;
   return MCR_OK;
 }

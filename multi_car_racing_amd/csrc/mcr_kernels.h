@@ -35,7 +35,8 @@ struct McrParams {
   int32_t* dlist;               // [1+B] count + env ids deferred by the main k_dynamics (zeroed by k_collide pass 0)
   int32_t* rlist;               // [1+B] count + env ids the main k_dynamics re-spawned in this step (zeroed by k_collide pass 0); filled when respawn_list
   int32_t* collide_epoch;       // [B] k_collide pass 0 stores `epoch` here when it is through with the env (release); see cc_mode
-  int32_t epoch;                // 1 + step parity
+  int32_t epoch;                // the handle's step counter (unique per step) ...
+  const int32_t* epoch_ptr;     // ... or, when the step is replayed as a hipGraph (constant arguments), where a device-side counter holds it
   int32_t cc_mode;              // 1: the main k_dynamics runs CONCURRENTLY with k_collide pass 0 (three-chain step): it finds the envs whose
                                 // car boxes overlap by itself (they are the contact chain's), and waits for collide_epoch[env] before it reads
                                 // what the collide pass produces for the step's bookkeeping (reward, tile count, wheel/tile bits)
@@ -68,6 +69,7 @@ struct McrParams {
   double h_ratio;
 };
 
+__device__ __forceinline__ int mcr_epoch(const McrParams& p) { return p.epoch_ptr ? *p.epoch_ptr : p.epoch; }
 #define MCR_VORDER_ENV_MASK 0xfffff
 #define MCR_VORDER_SLOT_SHIFT 20
 #define MCR_VORDER_P_SHIFT 21

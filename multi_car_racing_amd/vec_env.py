@@ -63,8 +63,10 @@ class VecMultiCarRacing:
             streams = 2 if int(num_envs) >= 64 and int(num_agents) > 1 and car_contacts else 1
         self.auto_reset = bool(auto_reset)
         self.direction_mode = 2 if use_random_direction else _DIRECTION_MODE[direction]
-        # host threads of the track generator: the ranks of one node share the cores the cgroup allows
-        self.gen_threads = gen_threads or max(1, _lib.effective_cpus() // max(1, int(world_size)) - 1)
+        # host threads of the track generator: the ranks of one node share the cores the cgroup allows.  (No core is set aside for
+        # the stepping thread: it sleeps at its fences — blocking events — and one generator thread per rank runs at ~85 % duty at
+        # 12 M env-steps/s, too close to the edge: bench.py --emulate-world 8 measured 10.9 M with one thread on a 2-core share)
+        self.gen_threads = gen_threads or max(1, _lib.effective_cpus() // max(1, int(world_size)))
         # A re-spawned env consumes its staged episode; the refill thread generates + stages the next one.  An env could
         # only FREEZE (k_dynamics: inactive, zero outputs until the episode arrives) if it finished a whole episode before
         # that refill landed, so step() waits for any refill batch queued more than `refill_lag` steps ago — fewer steps
@@ -108,6 +110,7 @@ class VecMultiCarRacing:
         self._ids = np.zeros(self.B, np.int32)
         self.episodes_generated = 0
         self._copy_stream = torch.cuda.Stream(device=self.device)
+        self._copy_done = torch.cuda.Event(blocking=True)
         self._async = bool(async_refill)
         self._q = None
         self._worker = None
@@ -151,7 +154,11 @@ class VecMultiCarRacing:
     def _refill(self, ids):
         rows = self._generate(ids)
         self._stage(ids, rows, self._copy_stream)
-        self._copy_stream.synchronize()      # the bounce buffer may be overwritten as soon as this returns
+        # the bounce buffer may be overwritten as soon as the copies are done.  A BLOCKING event: hipStreamSynchronize spins, and a
+        # refill thread that spins takes a core from the track generator — with the ranks of a node sharing few cores
+        # (bench.py --emulate-world) that is what the host side runs out of first
+        self._copy_done.record(self._copy_stream)
+        self._copy_done.synchronize()
 
     def _worker_main(self):
         torch.cuda.set_device(self.device)
