@@ -63,6 +63,9 @@ struct mcr_env {
   bool bp_fresh;              // mcr_set_bodies teleported cars: the next contact pass re-creates their broadphase proxies
   int simd_count;             // SIMDs of the device (4 per CU)
   int32_t* dev_step_ctr;      // device-side step counter (the epoch of a replayed step graph)
+  bool fuse_flags;            // N <= 2: the list chains do their cars' bookkeeping themselves (one launch less per chain)
+  int chain_lds_pad;          // bytes of dynamic LDS the resume chain's workgroups ask for beyond what they use (see launch_step)
+  bool resume_on_caller;      // three-chain step: the resume chain keeps the caller's stream, bookkeeping + main raster hop to the third stream
   int chain_grid;             // workgroups of a list chain launch (each walks the list, 2 envs at a time)
   bool vorder_dirty[2];       // the raster order list of that step parity was filled by a step that did not draw
 };
@@ -106,10 +109,18 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   mcr_env* h = new mcr_env();
   h->cfg = *cfg; h->timing = 0; h->any_reset = false; h->use_graph = 0; h->verdict_fresh = false; h->concurrent_collide = false; h->sg[0].valid = h->sg[1].valid = false;
   h->vorder_dirty[0] = h->vorder_dirty[1] = false;
-  // A list chain is a serial solver chain per wavefront (2 envs each): with two cars per env the contact list holds ~15 envs
-  // of 4096 and 64 workgroups walk it in one round; with more cars per env it is long (N = 8: hundreds of envs) and every
-  // further round of the walk adds a whole chain (~300 us) to the side stream, so the grid grows with N.
-  h->chain_grid = cfg->num_agents <= 2 ? MCR_LIST_GRID / MCR_SIDE_ENVS_PER_WAVE : 4 * MCR_LIST_GRID;
+  // A list chain is a serial solver chain per wavefront (2 envs each).  With i.i.d. random actions and two cars per env the
+  // contact list holds ~15 envs of 4096, but a policy that actually drives (or N = 8: ~340 envs) fills it with hundreds, and
+  // every further round of the walk adds a whole chain (~300 us) to the side stream: the grid covers 1024 envs in one round;
+  // surplus workgroups exit on their first load.
+  h->chain_grid = 4 * MCR_LIST_GRID;
+  h->resume_on_caller = true;
+  h->fuse_flags = true;
+  if (const char* g = getenv("MCR_FUSE_FLAGS")) h->fuse_flags = atoi(g) != 0;
+  h->chain_lds_pad = 0;
+  if (const char* g = getenv("MCR_CHAIN_LDS_PAD")) h->chain_lds_pad = atoi(g);
+  if (h->chain_lds_pad > 0 && hipFuncSetAttribute((const void*)k_list_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(col::lds_bytes(cfg->num_agents) + h->chain_lds_pad)) != hipSuccess) { (void)hipGetLastError(); h->chain_lds_pad = 0; }
+  if (const char* g = getenv("MCR_RESUME_ON_CALLER")) h->resume_on_caller = atoi(g) != 0;
   if (const char* g = getenv("MCR_CHAIN_GRID")) { const int v = atoi(g); if (v > 0) h->chain_grid = v; }
   h->status_host = nullptr; h->step_count = 0; h->bp_fresh = false; memset(h->status_seen, 0, sizeof(h->status_seen));
   { hipDeviceProp_t prop; h->simd_count = (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess ? prop.multiProcessorCount : 256) * 4; }
@@ -378,7 +389,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   P.split = 0;
   // bookkeeping of a chain's cars: fused into the chain for N <= 2 (2 envs x N cars take their turns on one wavefront),
   // a list launch of its own beyond that
-  const int fuse_flags = (view_flags && N <= 2) ? 1 : 0;
+  const int fuse_flags = (view_flags && N <= 2 && h->fuse_flags) ? 1 : 0;
   const int lg_flags = std::min(B * N, (N <= 2 ? 4 : 32) * MCR_LIST_GRID);
   P.role = 2;
   LAUNCH_LDS(5, k_list_chain, lg_dyn, 64, col::lds_bytes(N), h->s_side, P, fuse_flags);
@@ -387,33 +398,44 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   P.role = 1;
   LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 0);
   (void)hipEventRecord(h->ev_fork2, st);
+  // Which of the two remaining chains stays on the caller's stream?  The kernel that follows the dynamics IN-STREAM starts ~5 us
+  // after it, one that has to hop to another stream ~20 us (kernel trace, round 3).  The longer chain is the resume chain (115-140
+  // us beside the raster + its own raster, 16 us) — not bookkeeping + main raster (15 + 100 us): it keeps the caller's stream, gets
+  // its wavefronts placed before the raster starts (a chain that starts beside a raster that fills every CU runs 2-3x slower),
+  // and the main envs' bookkeeping + raster take the hop.
+  hipStream_t s_resume = h->resume_on_caller ? st : h->s_defer, s_mainview = h->resume_on_caller ? h->s_defer : st;
   (void)hipStreamWaitEvent(h->s_defer, h->ev_fork2, 0);
-  (void)hipStreamWaitEvent(h->s_defer, h->ev_col, 0);
+  // (the resume chain touches the contact pass's results of ITS envs only — main envs, whose "contact pass done" words the main
+  // dynamics has waited for (cc_mode) or whose contact pass ran in-stream before it: no event wait on its critical path)
+  if (s_resume != st) (void)hipStreamWaitEvent(s_resume, h->ev_col, 0);
   (void)hipStreamWaitEvent(h->s_side, h->ev_fork2, 0);
   P.role = 3;
-  LAUNCH_LDS(7, k_list_chain, lg_dyn, 64, col::lds_bytes(N), h->s_defer, P, fuse_flags);
-  if (view_flags && !fuse_flags) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, h->s_defer, P);
-  if (draw) launch_view(h, 7, B, h->s_defer, P, 0);
+  // (the resume chain is the step's critical path and its few wavefronts run 30-40 % slower when raster wavefronts share their
+  // SIMDs: `chain_lds_pad` bytes of unused dynamic LDS make a chain workgroup fill its CU's LDS so far that no raster workgroup
+  // (53 KB) fits beside it — a handful of CUs, ~2 % of the machine, belong to the chain while it runs)
+  LAUNCH_LDS(7, k_list_chain, std::min(lg_dyn, MCR_LIST_GRID / 2), 64, col::lds_bytes(N) + h->chain_lds_pad, s_resume, P, fuse_flags);
+  if (view_flags && !fuse_flags) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, s_resume, P);
+  if (draw) launch_view(h, 7, B, s_resume, P, 0);
   P.role = 1;
   if (P.auto_reset) {   // the envs the main dynamics re-spawned: reset pass (:408, ~50 us of serial solver work) and first observation
     // on the stream whose chain is the shorter one: with two cars per env the contact list is nearly always empty (chain:
     // 6 us median), with more cars it is the long one (N = 8: 600 us) and the resume chain (90-140 us) the short one
-    hipStream_t sr = N <= 2 ? h->s_side : h->s_defer;
+    hipStream_t sr = N <= 2 ? h->s_side : s_resume;
     P.role = 4; P.list_envs_per_block = 1;                         // one env per workgroup: they run side by side
     LAUNCH_LDS(3, k_reset_list, lg_col, 64, col::lds_bytes(N), sr, P);
     if (draw) launch_view(h, 4, B, sr, P, 0);
     P.role = 1; P.list_envs_per_block = MCR_SIDE_ENVS_PER_WAVE;
   }
   (void)hipEventRecord(h->ev_join, h->s_side);
-  (void)hipEventRecord(h->ev_join2, h->s_defer);
   // The bookkeeping of the main envs (:446-495; k_flags.h, one wavefront per car) needs the poses only.  It runs right
   // before the raster, and those ~16 us are what the list chains — forked off at the same moment — need to get their
   // wavefronts placed: a chain that starts beside a raster that already fills every CU runs 2-3x slower (measured).
-  if (view_flags) hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, st, P);
-  (void)hipStreamWaitEvent(st, h->ev_col, 0);                      // the raster reads the tiles' recolour flags (long done)
+  if (view_flags) hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, s_mainview, P);
+  (void)hipStreamWaitEvent(s_mainview, h->ev_col, 0);              // the raster reads the tiles' recolour flags (long done)
   P.use_vorder = 1;
-  if (draw) launch_view(h, 2, B, st, P, 0);
+  if (draw) launch_view(h, 2, B, s_mainview, P, 0);
   P.use_vorder = 0;
+  (void)hipEventRecord(h->ev_join2, h->s_defer);
   (void)hipStreamWaitEvent(st, h->ev_join, 0);
   (void)hipStreamWaitEvent(st, h->ev_join2, 0);
 }
