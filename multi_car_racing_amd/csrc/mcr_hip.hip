@@ -405,9 +405,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   // and the main envs' bookkeeping + raster take the hop.
   hipStream_t s_resume = h->resume_on_caller ? st : h->s_defer, s_mainview = h->resume_on_caller ? h->s_defer : st;
   (void)hipStreamWaitEvent(h->s_defer, h->ev_fork2, 0);
-  // (the resume chain touches the contact pass's results of ITS envs only — main envs, whose "contact pass done" words the main
-  // dynamics has waited for (cc_mode) or whose contact pass ran in-stream before it: no event wait on its critical path)
-  if (s_resume != st) (void)hipStreamWaitEvent(s_resume, h->ev_col, 0);
+  (void)hipStreamWaitEvent(s_resume, h->ev_col, 0);              // the resume chain reads the contact pass's results of its envs (a deferred env never got to the main dynamics' in-kernel wait)
   (void)hipStreamWaitEvent(h->s_side, h->ev_fork2, 0);
   P.role = 3;
   // (the resume chain is the step's critical path and its few wavefronts run 30-40 % slower when raster wavefronts share their
