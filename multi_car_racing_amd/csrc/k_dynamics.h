@@ -1034,7 +1034,15 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
   // values gym's Transform hands to glTranslatef/glRotatef/glScalef; HUD rectangles (:634-674).
   float bxl = MCR_MAXFLT, byl = MCR_MAXFLT, bxh = -MCR_MAXFLT, byh = -MCR_MAXFLT;   // world box of the car's draw polygons (= its fixtures)
   bool have_box = false;
-  if (p.obs != nullptr && !respawn) {
+  // (three-chain step, main launch: the record and the polygons are produced by the car's bookkeeping wavefront instead —
+  // k_viewprep.h, lane-parallel — and only the two words this kernel holds are written here)
+  const bool prep_later = p.viewprep_in_flags && p.role == 1 && mode == 0;
+  if (p.obs != nullptr && !respawn && prep_later) {
+    float* vp = p.viewp + (size_t)ci * MCR_VIEWP_FLOATS;
+    vp[VP_SCORE] = __int_as_float(mcr_label_value(reward_shown));
+    vp[VP_OLDFLAGS] = __uint_as_float(flags);
+  }
+  if (p.obs != nullptr && !respawn && !prep_later) {
     float* vp = p.viewp + (size_t)ci * MCR_VIEWP_FLOATS;
     const Xf hxf = xf_of(v2(b[0].cx, b[0].cy), b[0].a, v2(lcx, lcy));
     const double t = es.t + 1.0 / MCR_FPS;

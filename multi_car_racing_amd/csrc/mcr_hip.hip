@@ -63,6 +63,7 @@ struct mcr_env {
   bool bp_fresh;              // mcr_set_bodies teleported cars: the next contact pass re-creates their broadphase proxies
   int simd_count;             // SIMDs of the device (4 per CU)
   int32_t* dev_step_ctr;      // device-side step counter (the epoch of a replayed step graph)
+  bool viewprep_in_flags;     // three-chain step: k_flags produces the main envs' view records / car polygons (k_viewprep.h)
   bool fuse_flags;            // N <= 2: the list chains do their cars' bookkeeping themselves (one launch less per chain)
   int chain_lds_pad;          // bytes of dynamic LDS the resume chain's workgroups ask for beyond what they use (see launch_step)
   bool resume_on_caller;      // three-chain step: the resume chain keeps the caller's stream, bookkeeping + main raster hop to the third stream
@@ -115,6 +116,8 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   // surplus workgroups exit on their first load.
   h->chain_grid = 4 * MCR_LIST_GRID;
   h->resume_on_caller = true;
+  h->viewprep_in_flags = true;
+  if (const char* g = getenv("MCR_VIEWPREP_IN_FLAGS")) h->viewprep_in_flags = atoi(g) != 0;
   h->fuse_flags = true;
   if (const char* g = getenv("MCR_FUSE_FLAGS")) h->fuse_flags = atoi(g) != 0;
   h->chain_lds_pad = 0;
@@ -396,6 +399,9 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   if (view_flags && !fuse_flags) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, h->s_side, P);
   if (draw) launch_view(h, 6, B, h->s_side, P, 0);
   P.role = 1;
+  // the main envs' view records and car polygons: by their bookkeeping wavefronts (k_viewprep.h) when that kernel runs in front
+  // of the raster, i.e. in a drawn step with actions; otherwise by the dynamics' own epilogue
+  P.viewprep_in_flags = (view_flags && draw && h->viewprep_in_flags) ? 1 : 0;
   LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 0);
   (void)hipEventRecord(h->ev_fork2, st);
   // Which of the two remaining chains stays on the caller's stream?  The kernel that follows the dynamics IN-STREAM starts ~5 us
