@@ -439,8 +439,10 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   P.use_vorder = 1;
   if (draw) launch_view(h, 2, B, s_mainview, P, 0);
   P.use_vorder = 0;
+  // one join on the caller's stream instead of two (each wait is a barrier packet of a few microseconds at the very end of the
+  // step's critical path): the third stream picks the side stream's completion up first
+  (void)hipStreamWaitEvent(h->s_defer, h->ev_join, 0);
   (void)hipEventRecord(h->ev_join2, h->s_defer);
-  (void)hipStreamWaitEvent(st, h->ev_join, 0);
   (void)hipStreamWaitEvent(st, h->ev_join2, 0);
 }
 

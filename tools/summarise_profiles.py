@@ -19,59 +19,60 @@ except Exception as e:
     b = {}
     lines.append(f"(bench_plain missing: {e})\n")
 
-KERNELS = ("k_collide", "k_dynamics", "k_view", "k_flags", "k_list_chain", "k_reset_list", "k_install", "fillBuffer", "copyBuffer")
+KERNELS = ("k_collide", "k_dynamics", "k_view", "k_flags_list", "k_flags", "k_list_chain", "k_reset_list", "k_install", "k_touch", "k_step_begin", "fillBuffer", "copyBuffer")
 def kname(s):
     for k in KERNELS:
         if k in s: return k
     return s[:60]
 
-# launches of a step by queue, in launch order (mcr_hip.hip: launch_step)
-MAIN_ORDER = {"k_collide": ["collide (all envs)"], "k_dynamics": ["dynamics (main envs)"], "k_flags": ["bookkeeping (main envs)"], "k_view": ["view (main envs)"]}
-SIDE_ORDER = {"k_list_chain": ["chain (contact envs, side stream)"], "k_reset_list": ["reset pass (re-spawned envs, side stream)"],
-              "k_view": ["view (contact envs, side stream)", "view (re-spawned envs, side stream)"]}
-DEFER_ORDER = {"k_list_chain": ["chain (resume of deferred envs, third stream)"], "k_view": ["view (deferred envs, third stream)"]}
-STEP_KERNELS = ("k_collide", "k_dynamics", "k_view", "k_flags", "k_list_chain", "k_reset_list")
+# launches of a step by queue, in launch order (mcr_hip.hip: launch_step, round 3):
+#   caller's queue : [collide, when the contact pass runs in front] dynamics (main envs) -> chain (resume) [-> bookkeeping] -> view
+#   side queue     : [collide, beside the dynamics] -> chain (contact envs) [-> bookkeeping] -> view -> reset pass (re-spawned envs) -> view
+#   third queue    : bookkeeping + view records (main envs) -> view (main envs)
+CALLER = {"k_collide": ["collide (all envs)"], "k_dynamics": ["dynamics (main envs)"], "k_list_chain": ["chain (resume of deferred envs, caller's stream)"],
+          "k_flags_list": ["bookkeeping (deferred envs)"], "k_view": ["view (deferred envs, caller's stream)"]}
+SIDE = {"k_collide": ["collide (all envs)"], "k_list_chain": ["chain (contact envs, side stream)"], "k_flags_list": ["bookkeeping (contact envs)"],
+        "k_reset_list": ["reset pass (re-spawned envs, side stream)"], "k_view": ["view (contact envs, side stream)", "view (re-spawned envs, side stream)"]}
+THIRD = {"k_flags": ["bookkeeping + view records (main envs, third stream)"], "k_view": ["view (main envs)"]}
+STEP_KERNELS = ("k_collide", "k_dynamics", "k_view", "k_flags", "k_flags_list", "k_list_chain", "k_reset_list")
 
 def label(df, order_col):
-    """adds column Label for the launches of the last STEPS steps.  The caller's queue is the one that carries k_flags.  A
-    step starts with the caller's-queue k_dynamics launch that precedes a k_flags launch — or with the k_collide launch right
-    before it where the contact pass runs first (single stream; counter passes: mcr_create finds kernels serialised and
-    does not put the contact pass beside the dynamics) — and every launch of the other queues belongs to the step during
-    which it appears (a step joins its streams before it returns)."""
+    """adds column Label for the launches of the last STEPS steps.  A step starts with its contact pass (the k_collide launch that
+    does not follow a k_install: that one belongs to reset() / reset_envs()) — the first launch of a step on either queue —
+    and every launch up to the next such k_collide belongs to it.  Queues: the caller's carries k_dynamics, the side queue
+    k_reset_list, the third one the main envs' k_flags."""
     df = df.sort_values(order_col).reset_index(drop=True)
     df["K"] = df["Kernel_Name"].map(kname)
     df["Label"] = None
-    fl = df[df.K == "k_flags"]
-    if fl.empty:
-        return df
-    main_q = fl.Queue_Id.value_counts().index[0]
+    dq = df[df.K == "k_dynamics"].Queue_Id.value_counts()
+    fq = df[df.K == "k_flags"].Queue_Id.value_counts()
     rq = df[df.K == "k_reset_list"].Queue_Id.value_counts()
-    side_q = rq.index[0] if len(rq) else None                 # the side stream is the one that carries the reset pass
-    mq = df.index[df.Queue_Id == main_q].tolist()
-    pos = {i: n for n, i in enumerate(mq)}
-    starts = []
-    for i in fl.index[fl.Queue_Id == main_q]:
-        n = pos[i]
-        if n == 0 or df.at[mq[n - 1], "K"] != "k_dynamics":
-            continue
-        s0 = mq[n - 1]
-        if n >= 2 and df.at[mq[n - 2], "K"] == "k_collide":
-            s0 = mq[n - 2]
-        starts.append(s0)
-    if len(starts) < STEPS:
+    if dq.empty:
         return df
-    starts = starts[-STEPS:] + [len(df)]
+    main_q = dq.index[0]
+    third_q = fq.index[0] if len(fq) else None
+    side_q = rq.index[0] if len(rq) else None
+    if third_q == main_q:                                   # serialised / single-stream runs: the main envs' kernels share the caller's queue
+        third_q = None
+    col = df.index[df.K == "k_collide"].tolist()
+    starts = [i for i in col if i == 0 or df.at[i - 1, "K"] != "k_install"]
+    if len(starts) < STEPS + 1:
+        return df
+    starts = starts[-(STEPS + 1):]
     for a, e in zip(starts[:-1], starts[1:]):
         seen = {}
         for i in range(a, e):
             k = df.at[i, "K"]
             if k not in STEP_KERNELS: continue
             q = df.at[i, "Queue_Id"]
-            if k == "k_collide":
-                df.at[i, "Label"] = "collide (all envs)"; continue
             key = (k, q); n = seen.get(key, 0); seen[key] = n + 1
-            names = (MAIN_ORDER if q == main_q else (SIDE_ORDER if q == side_q else DEFER_ORDER)).get(k, [])
-            df.at[i, "Label"] = names[n] if n < len(names) else f"{k} #{n}"
+            if q == main_q:
+                names = dict(CALLER)
+                if third_q is None: names.update({"k_flags": THIRD["k_flags"], "k_view": THIRD["k_view"] + CALLER["k_view"]})
+                names = names.get(k, [])
+            elif q == third_q: names = THIRD.get(k, [])
+            else: names = SIDE.get(k, [])
+            df.at[i, "Label"] = names[n] if n < len(names) else f"{k} #{n} (queue {q})"
     return df
 
 st = pd.read_csv(f"{src}/stats/s_kernel_stats.csv")
