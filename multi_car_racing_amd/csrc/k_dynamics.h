@@ -1034,8 +1034,8 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
   // values gym's Transform hands to glTranslatef/glRotatef/glScalef; HUD rectangles (:634-674).
   float bxl = MCR_MAXFLT, byl = MCR_MAXFLT, bxh = -MCR_MAXFLT, byh = -MCR_MAXFLT;   // world box of the car's draw polygons (= its fixtures)
   bool have_box = false;
-  // (three-chain step, main launch: the record and the polygons are produced by the car's bookkeeping wavefront instead —
-  // k_viewprep.h, lane-parallel — and only the two words this kernel holds are written here)
+  // (three-chain step, main launch: the record and the polygons are produced by k_viewprep, beside the bookkeeping kernel,
+  // and only the two words this kernel holds are written here)
   const bool prep_later = p.viewprep_in_flags && p.role == 1 && mode == 0;
   if (p.obs != nullptr && !respawn && prep_later) {
     float* vp = p.viewp + (size_t)ci * MCR_VIEWP_FLOATS;

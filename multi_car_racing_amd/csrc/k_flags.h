@@ -13,7 +13,6 @@
 #pragma once
 #include "k_raster_common.h"
 #include "k_touch.h"
-#include "k_viewprep.h"
 
 __device__ __forceinline__ void flags_block(const McrParams& p, const int blk) {
   const int lane = threadIdx.x;
@@ -37,7 +36,6 @@ __device__ __forceinline__ void flags_block(const McrParams& p, const int blk) {
     }
   };
   if (!es.active || es.just_reset) { settle_verdict(); return; }   // reset() -> step(None) skips the block (:435); a re-spawned car keeps its zeroed flags
-  if (p.viewprep_in_flags && p.role == 1 && p.obs != nullptr) viewprep_wave(p, ci, es.t);   // what the raster needs from this car's pose
   const uint8_t* __restrict__ slot = p.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES;
   const McrSlotHeader* H = (const McrSlotHeader*)slot;
   const int T = H->T, P = H->P;

@@ -1,24 +1,23 @@
-// k_viewprep.h — what the rasteriser needs from a car's pose, evaluated by the car's BOOKKEEPING wavefront (k_flags.h) in
-// the three-chain step instead of one lane of k_dynamics: the per-car view record (camera 2x3 + inverse, HUD rectangles, grass
-// range; multi_car_racing.py:540-556, 634-674, 615-627) and the world-space vertices of the 12 Car.draw polygons.  In
-// k_dynamics this epilogue is ~12 us of serial work at the end of the step's longest kernel (one lane per car, eight f64 sin/cos);
-// here the pieces run side by side on the lanes of a wavefront that exists anyway:
-//   lane 0      camera + grass range            lane 1      HUD rectangles
-//   lanes 8-11  wheel k: box + stripe polygon   lanes 16-19 hull polygon k
-// Same expressions, operand order and types as the epilogue of dynamics_block (the list chains and the single-stream step
-// still use that one): identical records.  VP_SCORE and VP_OLDFLAGS stay with k_dynamics (it holds the values).
+// k_viewprep.h — what the rasteriser needs from a car's pose — the per-car view record (camera 2x3 + inverse, HUD rectangles,
+// grass range; multi_car_racing.py:540-556, 634-674, 615-627) and the world-space vertices of the 12 Car.draw polygons — as a
+// kernel of its own in the three-chain step instead of the last 12 us of the step's longest kernel (k_dynamics' epilogue: one
+// lane per car, eight f64 sin/cos): it runs on the third stream in front of the main envs' bookkeeping kernel and raster, whose
+// chain has slack (the step's critical path after the dynamics is the resume chain, on the caller's stream).  One lane per car like the epilogue (a wavefront per car was tried: 8192 wavefronts each issuing the whole f64 camera
+// code for one car cost k_flags 20 us).  Same expressions, operand order and types as the epilogue of dynamics_block (the
+// list chains, the single-stream step and the reset pass still use that one): identical records.  VP_SCORE and VP_OLDFLAGS
+// stay with k_dynamics (it holds the values).
 #pragma once
 #include "mcr_kernels.h"
 
 __device__ __forceinline__ double vprep_sign(double x) { return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : 0.0); }
 
-__device__ __forceinline__ void viewprep_wave(const McrParams& p, const int ci, const double t_now) {
-  const int lane = threadIdx.x & 63, BN = p.BN;
+__device__ __forceinline__ void viewprep_car(const McrParams& p, const int ci, const double t_now) {
+  const int BN = p.BN;
   const McrShapes& S = *p.shapes;
   float* vp = p.viewp + (size_t)ci * MCR_VIEWP_FLOATS;
   float4* cp4 = (float4*)(p.carpoly + (size_t)ci * MCR_CARPOLY_FLOATS);
   int* cnt = (int*)(p.carpoly + (size_t)ci * MCR_CARPOLY_FLOATS + MCR_CARPOLY_NOFF);
-  if (lane == 0) {
+  {
     const float hcx = p.carf[(CF_CX + 0) * BN + ci], hcy = p.carf[(CF_CY + 0) * BN + ci], ha = p.carf[(CF_A + 0) * BN + ci];
     const float hvx = p.carf[(CF_VX + 0) * BN + ci], hvy = p.carf[(CF_VY + 0) * BN + ci];
     const Xf hxf = xf_of(v2(hcx, hcy), ha, v2(S.hull_lcx, S.hull_lcy));
@@ -62,7 +61,8 @@ __device__ __forceinline__ void viewprep_wave(const McrParams& p, const int ci, 
       vp[VP_GRASS + 2] = __int_as_float(b0); vp[VP_GRASS + 3] = __int_as_float(max(b1 - b0 + 1, 0));
       vp[VP_GRASS + 4] = __int_as_float(inside_field ? 1 : 0);
     }
-  } else if (lane == 1) {
+  }
+  {
     const float hvx = p.carf[(CF_VX + 0) * BN + ci], hvy = p.carf[(CF_VY + 0) * BN + ci];
     const float ha = p.carf[(CF_A + 0) * BN + ci], w1a = p.carf[(CF_A + 1) * BN + ci], hw = p.carf[(CF_W + 0) * BN + ci];
     const double vx = (double)hvx, vy = (double)hvy;
@@ -90,8 +90,8 @@ __device__ __forceinline__ void viewprep_wave(const McrParams& p, const int ci, 
       vp[VP_IND + (5 + i) * 4 + 2] = (float)(2 * hH) * ky; vp[VP_IND + (5 + i) * 4 + 3] = (float)(4 * hH) * ky;
     }
     vp[VP_HUDTOP] = hud_top;
-  } else if (lane >= 8 && lane < 12) {
-    const int k = lane - 8;
+  }
+  for (int k = 0; k < 4; ++k) {
     const Xf wxf = xf_of(v2(p.carf[(CF_CX + 1 + k) * BN + ci], p.carf[(CF_CY + 1 + k) * BN + ci]), p.carf[(CF_A + 1 + k) * BN + ci], v2(0.0f, 0.0f));
     V2 w[4];
 #pragma unroll
@@ -118,8 +118,8 @@ __device__ __forceinline__ void viewprep_wave(const McrParams& p, const int ci, 
       stripe[2] = make_float4(u[3].x, u[3].y, u[3].x, u[3].y); stripe[3] = stripe[2];
     }
     cnt[2 * k + 1] = ns;
-  } else if (lane >= 16 && lane < 20) {
-    const int k = lane - 16;
+  }
+  for (int k = 0; k < 4; ++k) {
     const Xf hxf = xf_of(v2(p.carf[(CF_CX + 0) * BN + ci], p.carf[(CF_CY + 0) * BN + ci]), p.carf[(CF_A + 0) * BN + ci], v2(S.hull_lcx, S.hull_lcy));
     const McrPoly& P = S.hull[k];
     const int n = P.n;
@@ -131,4 +131,14 @@ __device__ __forceinline__ void viewprep_wave(const McrParams& p, const int ci, 
     for (int i = 0; i < 4; ++i) hp[i] = make_float4(w[2 * i].x, w[2 * i].y, w[2 * i + 1].x, w[2 * i + 1].y);
     cnt[8 + k] = n;
   }
+}
+
+// one lane per car of the main launch's envs (role 1 semantics: not the contact chain's, not the deferred, not the re-spawned ones)
+__global__ __launch_bounds__(64) void k_viewprep(McrParams p) {
+  const int g = blockIdx.x * 64 + threadIdx.x;
+  const int env = mcr_env_of_slot(p, g / p.G), agent = g % p.G;
+  if (env >= p.env0 + p.nenv || agent >= p.N) return;
+  const McrEnvState es = p.env[env];
+  if (!es.active || es.just_reset) return;
+  viewprep_car(p, env * p.N + agent, es.t);
 }

@@ -6,6 +6,7 @@
 #include "k_collide.h"
 #include "k_raster_common.h"
 #include "k_flags.h"
+#include "k_viewprep.h"
 #include "k_list_chain.h"
 #include "k_render.h"
 #include <hip/hip_runtime.h>
@@ -63,8 +64,9 @@ struct mcr_env {
   bool bp_fresh;              // mcr_set_bodies teleported cars: the next contact pass re-creates their broadphase proxies
   int simd_count;             // SIMDs of the device (4 per CU)
   int32_t* dev_step_ctr;      // device-side step counter (the epoch of a replayed step graph)
-  bool viewprep_in_flags;     // three-chain step: k_flags produces the main envs' view records / car polygons (k_viewprep.h)
+  bool viewprep_in_flags;     // three-chain step: k_viewprep (side stream, beside the bookkeeping) produces the main envs' view records / car polygons
   bool fuse_flags;            // N <= 2: the list chains do their cars' bookkeeping themselves (one launch less per chain)
+  int list_view_grid;         // workgroups of a list raster launch
   int chain_lds_pad;          // bytes of dynamic LDS the resume chain's workgroups ask for beyond what they use (see launch_step)
   bool resume_on_caller;      // three-chain step: the resume chain keeps the caller's stream, bookkeeping + main raster hop to the third stream
   int chain_grid;             // workgroups of a list chain launch (each walks the list, 2 envs at a time)
@@ -116,10 +118,12 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   // surplus workgroups exit on their first load.
   h->chain_grid = 4 * MCR_LIST_GRID;
   h->resume_on_caller = true;
-  h->viewprep_in_flags = true;
+  h->viewprep_in_flags = cfg->num_agents <= 2;     // beyond two cars per env the bookkeeping + raster chain is the step's critical path: the epilogue stays in the dynamics (N = 4: 0.539 vs 0.561 ms)
   if (const char* g = getenv("MCR_VIEWPREP_IN_FLAGS")) h->viewprep_in_flags = atoi(g) != 0;
   h->fuse_flags = true;
   if (const char* g = getenv("MCR_FUSE_FLAGS")) h->fuse_flags = atoi(g) != 0;
+  h->list_view_grid = cfg->num_agents <= 2 ? MCR_LIST_GRID : 8 * MCR_LIST_GRID;
+  if (const char* g = getenv("MCR_LIST_VIEW_GRID")) { const int v = atoi(g); if (v > 0) h->list_view_grid = v; }
   h->chain_lds_pad = 0;
   if (const char* g = getenv("MCR_CHAIN_LDS_PAD")) h->chain_lds_pad = atoi(g);
   if (h->chain_lds_pad > 0 && hipFuncSetAttribute((const void*)k_list_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(col::lds_bytes(cfg->num_agents) + h->chain_lds_pad)) != hipSuccess) { (void)hipGetLastError(); h->chain_lds_pad = 0; }
@@ -299,7 +303,7 @@ static void launch_view(mcr_env* h, int kid, int slots, hipStream_t st, const Mc
   if (tm) { tl.id = kid; tl.a = get_event(h); tl.b = get_event(h); (void)hipEventRecord(tl.a, st); }
   // (list launches: with more than two cars per env the contact list is long — N = 8: ~340 envs x 8 views per step — and 128
   // workgroups would draw ~20 views each, one after the other, at the end of the side stream's chain)
-  if (P.role >= 2) mcr_view_launch(2, list_grid(slots, P.N <= 2 ? MCR_LIST_GRID : 8 * MCR_LIST_GRID), st, P, h->view_stamps, only_just_reset);
+  if (P.role >= 2) mcr_view_launch(2, list_grid(slots, h->list_view_grid), st, P, h->view_stamps, only_just_reset);
   else mcr_view_launch((P.debug & 32) ? 1 : 0, slots, st, P, h->view_stamps, only_just_reset);
   if (tm) { (void)hipEventRecord(tl.b, st); h->pending.push_back(tl); }
 }
@@ -399,8 +403,8 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   if (view_flags && !fuse_flags) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, h->s_side, P);
   if (draw) launch_view(h, 6, B, h->s_side, P, 0);
   P.role = 1;
-  // the main envs' view records and car polygons: by their bookkeeping wavefronts (k_viewprep.h) when that kernel runs in front
-  // of the raster, i.e. in a drawn step with actions; otherwise by the dynamics' own epilogue
+  // the main envs' view records and car polygons: by k_viewprep on the side stream, beside the bookkeeping kernel, in a drawn step
+  // with actions; otherwise by the dynamics' own epilogue
   P.viewprep_in_flags = (view_flags && draw && h->viewprep_in_flags) ? 1 : 0;
   LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 0);
   (void)hipEventRecord(h->ev_fork2, st);
@@ -434,6 +438,8 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   // The bookkeeping of the main envs (:446-495; k_flags.h, one wavefront per car) needs the poses only.  It runs right
   // before the raster, and those ~16 us are what the list chains — forked off at the same moment — need to get their
   // wavefronts placed: a chain that starts beside a raster that already fills every CU runs 2-3x slower (measured).
+  // (k_viewprep in front of it, in-stream: the side stream may be held by a long contact chain, and a further stream slows every queue)
+  if (P.viewprep_in_flags) hipLaunchKernelGGL(k_viewprep, dim3(dyn_blocks), dim3(64), 0, s_mainview, P);
   if (view_flags) hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, s_mainview, P);
   (void)hipStreamWaitEvent(s_mainview, h->ev_col, 0);              // the raster reads the tiles' recolour flags (long done)
   P.use_vorder = 1;
