@@ -105,11 +105,15 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
   //   role >= 2 (side streams): the envs of the contact / deferred lists;  use_vorder (step path): the order k_dynamics
   //   recorded, heavy (zoomed-out) envs first;  role 1: not the envs the side streams draw;  only_just_reset: reset().
   if (PERSIST) __builtin_amdgcn_s_setprio(3);                               // a few envs beside the main launch that fills every CU: they go first
-  int my_env = -1, my_slot = 0, my_P = -1;
+  int my_env = -1, my_slot = 0, my_P = -1, my_agent = 0;
+  // List launches with `split_views`: a work slot is ONE VIEW (list entry s / N, agent s % N) instead of an env with its N views —
+  // the few envs of a list are the tail of a chain on the step's critical path, and their views side by side take half the time
+  // of one after the other (what an env's views share is fetched once per view then).
+  const bool split_views = PERSIST && p.split_views != 0;
   {
     const int s = (int)blockIdx.x + (PERSIST ? lane * (int)gridDim.x : 0);
     int e = -1;
-    if (p.role >= 2) { e = mcr_env_of_slot(p, s); if (e >= p.env0 + p.nenv) e = -1; }
+    if (p.role >= 2) { e = mcr_env_of_slot(p, split_views ? s / N : s); if (e >= p.env0 + p.nenv) e = -1; my_agent = split_views ? s % N : 0; }
     else if (p.use_vorder) {
       // one load instead of a chain of four (list counts -> list entry -> env record -> slot header): the entry k_dynamics left
       // carries the env, its episode slot and the slot's entry count; only envs this launch draws are listed (active, not
@@ -134,9 +138,9 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
   auto slot_of = [&](int k) -> const uint8_t* {
     return p.slots + ((size_t)__builtin_amdgcn_readlane(my_env, k) * 2 + __builtin_amdgcn_readlane(my_slot, k)) * MCR_SLOT_BYTES;
   };
-  int env, P;
+  int env, P, a_lo;
   const uint8_t* __restrict__ slot;
-  { const int k = UNI(__builtin_ctzll(todo)); todo &= todo - 1; env = __builtin_amdgcn_readlane(my_env, k); slot = slot_of(k); }
+  { const int k = UNI(__builtin_ctzll(todo)); todo &= todo - 1; env = __builtin_amdgcn_readlane(my_env, k); slot = slot_of(k); a_lo = __builtin_amdgcn_readlane(my_agent, k); }
   // what a candidate needs from HBM, requested one round ahead
   struct Raw { float4 a, b, c, d; uint32_t m; };     // quad: a = v0 v1, b = v2 v3, m = meta | car polygon: a..d = 8 vertices, m = vertex count
   Raw nxt; nxt.a = nxt.b = nxt.c = nxt.d = make_float4(0.0f, 0.0f, 0.0f, 0.0f); nxt.m = 0u;
@@ -189,8 +193,8 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
   if (tid < 32) palc[tid] = PALETTE_RGB[tid];
   if (tid >= 128 && tid < 128 + 77) glyphs[tid - 128] = ((const uint8_t*)LABEL_GLYPHS)[tid - 128];
   tfl[tid] = ((const uint32_t*)(p.tile_flags + (size_t)env * MCR_TILE_CAP))[tid];
-  if (tid >= 64 && tid < 64 + MCR_VIEWP_FLOATS) vrec[0][tid - 64] = p.viewp[(size_t)(env * N) * MCR_VIEWP_FLOATS + (tid - 64)];
-  if (wave == 3) list_blocks(slot, env * N, 0);
+  if (tid >= 64 && tid < 64 + MCR_VIEWP_FLOATS) vrec[0][tid - 64] = p.viewp[(size_t)(env * N + a_lo) * MCR_VIEWP_FLOATS + (tid - 64)];
+  if (wave == 3) list_blocks(slot, env * N + a_lo, 0);
   // grass lattice as the reference builds it (:620-627): f32(k*x) and f32(k*x + k) for x = -20, -18, .., 18
   if (tid >= 224 && tid < 244) { const double k = MCR_PLAYFIELD / 20.0, x = 2.0 * (double)(tid - 224 - 10); glo[tid - 224] = (float)(k * x + 0); ghi[tid - 224] = (float)(k * x + k); }
   const float kx = 96.0f / 1000.0f, ky = 96.0f / 800.0f;
@@ -231,18 +235,19 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
   for (;;) {
   // the workgroup's next env, if any
   const bool has_next = PERSIST && todo != 0ull;
-  int env_n = env; const uint8_t* __restrict__ slot_n = slot;
-  if (has_next) { const int k = UNI(__builtin_ctzll(todo)); todo &= todo - 1; env_n = __builtin_amdgcn_readlane(my_env, k); slot_n = slot_of(k); }
+  int env_n = env, a_lo_n = 0; const uint8_t* __restrict__ slot_n = slot;
+  if (has_next) { const int k = UNI(__builtin_ctzll(todo)); todo &= todo - 1; env_n = __builtin_amdgcn_readlane(my_env, k); slot_n = slot_of(k); a_lo_n = __builtin_amdgcn_readlane(my_agent, k); }
+  const int a_hi = split_views ? a_lo + 1 : N;
   uint32_t tfl_n = 0u; int P_nv = 0;
 #pragma nounroll
-  for (int agent = 0; agent < N; ++agent, ++vs) {
+  for (int agent = a_lo; agent < a_hi; ++agent, ++vs) {
     const int vw = env * N + agent;
     const int buf = vs & 1;
     const float* __restrict__ vr = vrec[buf];
     // the view after this one: the env's next agent, or agent 0 of the workgroup's next env
-    const bool last = agent + 1 == N;
+    const bool last = agent + 1 == a_hi;
     const bool nv_ok = !last || has_next;
-    const int env_v = last ? env_n : env, vw_v = last ? env_n * N : vw + 1;
+    const int env_v = last ? env_n : env, vw_v = last ? env_n * N + a_lo_n : vw + 1;
     const uint8_t* __restrict__ slot_v = last ? slot_n : slot;
     PHASE_ACC(0);
     __syncthreads();                                                        // this view's record and block list are in LDS; the previous view's resolve is through with the key buffer
@@ -524,6 +529,6 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
   }
   if (!has_next) break;
   // hand-over: every thread is past the last barrier of the view's span fill, nobody reads the tile flags any more
-  env = env_n; slot = slot_n; P = UNI(P_nv); tfl[tid] = tfl_n;
+  env = env_n; slot = slot_n; P = UNI(P_nv); tfl[tid] = tfl_n; a_lo = a_lo_n;
   }
 }

@@ -66,6 +66,7 @@ struct mcr_env {
   int32_t* dev_step_ctr;      // device-side step counter (the epoch of a replayed step graph)
   bool viewprep_in_flags;     // three-chain step: k_viewprep (side stream, beside the bookkeeping) produces the main envs' view records / car polygons
   bool fuse_flags;            // N <= 2: the list chains do their cars' bookkeeping themselves (one launch less per chain)
+  bool split_views;           // list raster launches draw one view per workgroup
   int list_view_grid;         // workgroups of a list raster launch
   int chain_lds_pad;          // bytes of dynamic LDS the resume chain's workgroups ask for beyond what they use (see launch_step)
   bool resume_on_caller;      // three-chain step: the resume chain keeps the caller's stream, bookkeeping + main raster hop to the third stream
@@ -124,6 +125,8 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   if (const char* g = getenv("MCR_FUSE_FLAGS")) h->fuse_flags = atoi(g) != 0;
   h->list_view_grid = cfg->num_agents <= 2 ? MCR_LIST_GRID : 8 * MCR_LIST_GRID;
   if (const char* g = getenv("MCR_LIST_VIEW_GRID")) { const int v = atoi(g); if (v > 0) h->list_view_grid = v; }
+  h->split_views = true;
+  if (const char* g = getenv("MCR_SPLIT_VIEWS")) h->split_views = atoi(g) != 0;
   h->chain_lds_pad = 0;
   if (const char* g = getenv("MCR_CHAIN_LDS_PAD")) h->chain_lds_pad = atoi(g);
   if (h->chain_lds_pad > 0 && hipFuncSetAttribute((const void*)k_list_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(col::lds_bytes(cfg->num_agents) + h->chain_lds_pad)) != hipSuccess) { (void)hipGetLastError(); h->chain_lds_pad = 0; }
@@ -303,7 +306,7 @@ static void launch_view(mcr_env* h, int kid, int slots, hipStream_t st, const Mc
   if (tm) { tl.id = kid; tl.a = get_event(h); tl.b = get_event(h); (void)hipEventRecord(tl.a, st); }
   // (list launches: with more than two cars per env the contact list is long — N = 8: ~340 envs x 8 views per step — and 128
   // workgroups would draw ~20 views each, one after the other, at the end of the side stream's chain)
-  if (P.role >= 2) mcr_view_launch(2, list_grid(slots, h->list_view_grid), st, P, h->view_stamps, only_just_reset);
+  if (P.role >= 2) { McrParams Q = P; Q.split_views = h->split_views ? 1 : 0; mcr_view_launch(2, list_grid(slots * (Q.split_views ? P.N : 1), h->list_view_grid), st, Q, h->view_stamps, only_just_reset); }
   else mcr_view_launch((P.debug & 32) ? 1 : 0, slots, st, P, h->view_stamps, only_just_reset);
   if (tm) { (void)hipEventRecord(tl.b, st); h->pending.push_back(tl); }
 }

@@ -53,6 +53,7 @@ struct McrParams {
                                 // workgroup needs to start loading); the workgroup that draws it resets it to -1
   int32_t* vcount;              // [2] number of heavy / other envs in vorder (zeroed by the previous step's main k_dynamics)
   int32_t viewprep_in_flags;    // the main envs' view records / car polygons are produced by k_viewprep (beside the bookkeeping kernel), not by the main k_dynamics' epilogue
+  int32_t split_views;          // list raster launches: one workgroup per VIEW of a listed env instead of one per env
   int32_t use_vorder;           // k_view maps workgroups to envs through vorder (step path, roles 0/1)
   int32_t role;                 // 0: every env; 1: main stream (skips part envs); 2: contact envs (clist); 3: deferred envs (dlist); 4: both lists
   // step I/O
