@@ -20,39 +20,44 @@ __device__ __forceinline__ void list_reset_pass(const McrParams& p, const int bl
   __syncthreads();
 }
 
-// role 4: nothing but the reset pass (the main launch did the step; one env per workgroup: they run side by side)
-__global__ __launch_bounds__(64) void k_reset_list(McrParams p) {
+// roles 2 / 3: dynamics (for role 3: the rest of it) -> reset pass if the episode ended -> bookkeeping (k_flags.h).
+// The launch can carry a SECOND list with its own parameter block: workgroups [ga, gridDim) run the reset pass of the envs the
+// main dynamics re-spawned (role 4, what k_reset_list does) beside the chain of the first list — one launch, so that neither
+// waits for the other in a stream (the re-spawned envs used to queue behind the contact chain, which is long in 1 step of 6).
+__global__ __launch_bounds__(64) void k_list_chain(McrParams pa, McrParams pb, const int with_flags, const int ga) {
   __builtin_amdgcn_s_setprio(3);
-  const int nb = mcr_virtual_blocks(p, p.list_envs_per_block);
-  for (int blk = blockIdx.x; blk < nb; blk += gridDim.x) {
-    list_reset_pass(p, blk);
-    // the next step's touch verdict of the re-spawned envs: this launch is its only writer (the main dynamics left a 0, so the
-    // main envs' bookkeeping kernel does not look at these envs; their cars take no bookkeeping in this step: first observation)
-    if (p.part_next) {
-      __threadfence();
-      for (int k = 0; k < p.list_envs_per_block; ++k) {
-        const int env = mcr_env_of_slot(p, blk * p.list_envs_per_block + k);
-        if (env >= p.env0 + p.nenv) continue;
-        const bool v = p.env[env].active ? mcr_touch_verdict(p, env) : false;
-        if (threadIdx.x == 0) p.part_next[env] = v ? 1 : 0;
+  // (two branches instead of one body on `first ? pa : pb`: selecting between the two argument blocks makes the compiler copy
+  // one into scratch memory, 1 KB per lane)
+  if ((int)blockIdx.x < ga) {
+    const McrParams& p = pa;
+    const int nb = mcr_virtual_blocks(p, p.list_envs_per_block);
+    for (int blk = blockIdx.x; blk < nb; blk += ga) {
+      dynamics_block(p, 0, blk);
+      __syncthreads();
+      if (p.auto_reset) list_reset_pass(p, blk);
+      if (with_flags) {
+        __threadfence();                                         // poses and env state as the dynamics left them
+        for (int c = 0; c < p.list_envs_per_block * p.N; ++c) flags_block(p, blk * p.list_envs_per_block * p.N + c);
+      }
+      __syncthreads();
+    }
+  } else {
+    const McrParams& p = pb;
+    const int nb = mcr_virtual_blocks(p, p.list_envs_per_block), stride = (int)gridDim.x - ga;
+    for (int blk = (int)blockIdx.x - ga; blk < nb; blk += stride) {
+      list_reset_pass(p, blk);
+      // the next step's touch verdict of the re-spawned envs: this launch is its only writer (the main dynamics left a 0, so the
+      // main envs' bookkeeping kernel does not look at these envs; their cars take no bookkeeping in this step: first observation)
+      if (p.part_next) {
+        __threadfence();
+        for (int k = 0; k < p.list_envs_per_block; ++k) {
+          const int env = mcr_env_of_slot(p, blk * p.list_envs_per_block + k);
+          if (env >= p.env0 + p.nenv) continue;
+          const bool v = p.env[env].active ? mcr_touch_verdict(p, env) : false;
+          if (threadIdx.x == 0) p.part_next[env] = v ? 1 : 0;
+        }
       }
     }
-  }
-}
-
-// roles 2 / 3: dynamics (for role 3: the rest of it) -> reset pass if the episode ended -> bookkeeping (k_flags.h)
-__global__ __launch_bounds__(64) void k_list_chain(McrParams p, const int with_flags) {
-  __builtin_amdgcn_s_setprio(3);
-  const int nb = mcr_virtual_blocks(p, p.list_envs_per_block);
-  for (int blk = blockIdx.x; blk < nb; blk += gridDim.x) {
-    dynamics_block(p, 0, blk);
-    __syncthreads();
-    if (p.auto_reset) list_reset_pass(p, blk);
-    if (with_flags) {
-      __threadfence();                                         // poses and env state as the dynamics left them
-      for (int c = 0; c < p.list_envs_per_block * p.N; ++c) flags_block(p, blk * p.list_envs_per_block * p.N + c);
-    }
-    __syncthreads();
   }
 }
 

@@ -50,7 +50,7 @@ struct mcr_env {
   int step_parity;            // which contact-list buffer the next step fills
   int32_t* stage_ids;         // [B] device scratch of mcr_stage_episodes
   hipStream_t s_side, s_defer; // internal streams: the contact envs' chain, the deferred envs' chain
-  hipEvent_t ev_fork, ev_join, ev_fork2, ev_join2, ev_col;
+  hipEvent_t ev_fork, ev_join, ev_fork2, ev_join2, ev_col, ev_chain;
   unsigned long long* view_stamps;   // [BN][16] phase clocks of the rasteriser (debug bit 5)
   // hipGraph of one step (mcr_set_step_graph): one per contact-list parity, re-captured when any argument changes
   struct StepGraph { bool valid; McrParams P; hipStream_t st; int view_flags; hipGraph_t graph; hipGraphExec_t exec; };
@@ -218,7 +218,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
       if (hipStreamCreateWithPriority(&h->s_defer, hipStreamNonBlocking, prio_hi) == hipSuccess) {
         (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&h->ev_col, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&h->ev_col, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming);
         // (beyond 4 cars per env the one-step-ahead touch verdict — a second pass over up to 28 car pairs — costs more than the
         // contact pass gains by running beside the dynamics: measured at N = 8, round 2: 3.66 vs 4.28 M env-steps/s.  Round 3 tried a
         // CONSERVATIVE verdict there instead — bounding discs + car boxes, no narrowphase, the contact chain taking every env it
@@ -245,7 +245,7 @@ extern "C" int mcr_destroy(mcr_env* h) {
   for (auto e : h->free_events) (void)hipEventDestroy(e);
   if (h->split) {
     (void)hipStreamDestroy(h->s_side); (void)hipStreamDestroy(h->s_defer);
-    (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_fork2); (void)hipEventDestroy(h->ev_join2); (void)hipEventDestroy(h->ev_col);
+    (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_fork2); (void)hipEventDestroy(h->ev_join2); (void)hipEventDestroy(h->ev_col); (void)hipEventDestroy(h->ev_chain);
   }
   (void)hipFree(h->slab);
   (void)hipHostFree(h->consumed_host);
@@ -402,7 +402,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   const int fuse_flags = (view_flags && N <= 2 && h->fuse_flags) ? 1 : 0;
   const int lg_flags = std::min(B * N, (N <= 2 ? 4 : 32) * MCR_LIST_GRID);
   P.role = 2;
-  LAUNCH_LDS(5, k_list_chain, lg_dyn, 64, col::lds_bytes(N), h->s_side, P, fuse_flags);
+  LAUNCH_LDS(5, k_list_chain, lg_dyn, 64, col::lds_bytes(N), h->s_side, P, P, fuse_flags, lg_dyn);
   if (view_flags && !fuse_flags) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, h->s_side, P);
   if (draw) launch_view(h, 6, B, h->s_side, P, 0);
   P.role = 1;
@@ -421,22 +421,19 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   (void)hipStreamWaitEvent(s_resume, h->ev_col, 0);              // the resume chain reads the contact pass's results of its envs (a deferred env never got to the main dynamics' in-kernel wait)
   (void)hipStreamWaitEvent(h->s_side, h->ev_fork2, 0);
   P.role = 3;
-  // (the resume chain is the step's critical path and its few wavefronts run 30-40 % slower when raster wavefronts share their
-  // SIMDs: `chain_lds_pad` bytes of unused dynamic LDS make a chain workgroup fill its CU's LDS so far that no raster workgroup
-  // (53 KB) fits beside it — a handful of CUs, ~2 % of the machine, belong to the chain while it runs)
-  LAUNCH_LDS(7, k_list_chain, std::min(lg_dyn, MCR_LIST_GRID / 2), 64, col::lds_bytes(N) + h->chain_lds_pad, s_resume, P, fuse_flags);
-  if (view_flags && !fuse_flags) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, s_resume, P);
-  if (draw) launch_view(h, 7, B, s_resume, P, 0);
-  P.role = 1;
-  if (P.auto_reset) {   // the envs the main dynamics re-spawned: reset pass (:408, ~50 us of serial solver work) and first observation
-    // on the stream whose chain is the shorter one: with two cars per env the contact list is nearly always empty (chain:
-    // 6 us median), with more cars it is the long one (N = 8: 600 us) and the resume chain (90-140 us) the short one
-    hipStream_t sr = N <= 2 ? h->s_side : s_resume;
-    P.role = 4; P.list_envs_per_block = 1;                         // one env per workgroup: they run side by side
-    LAUNCH_LDS(3, k_reset_list, lg_col, 64, col::lds_bytes(N), sr, P);
-    if (draw) launch_view(h, 4, B, sr, P, 0);
-    P.role = 1; P.list_envs_per_block = MCR_SIDE_ENVS_PER_WAVE;
+  {
+    // the resume chain and — same launch, workgroups of their own — the reset pass (:408, ~50 us of serial solver work) of the
+    // envs the main dynamics re-spawned; then the deferred envs' frames here and the re-spawned envs' first observations on the
+    // side stream (behind the contact chain's raster: off the critical path unless that chain is a long one)
+    const int ga = std::min(lg_dyn, MCR_LIST_GRID / 2), gb = P.auto_reset ? lg_col : 0;
+    McrParams Pr = P; Pr.role = 4; Pr.list_envs_per_block = 1;     // one re-spawned env per workgroup: they run side by side
+    LAUNCH_LDS(7, k_list_chain, ga + gb, 64, col::lds_bytes(N) + h->chain_lds_pad, s_resume, P, Pr, fuse_flags, ga);
+    (void)hipEventRecord(h->ev_chain, s_resume);
+    if (view_flags && !fuse_flags) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, s_resume, P);
+    if (draw) launch_view(h, 7, B, s_resume, P, 0);
+    if (P.auto_reset && draw) { (void)hipStreamWaitEvent(h->s_side, h->ev_chain, 0); launch_view(h, 4, B, h->s_side, Pr, 0); }
   }
+  P.role = 1;
   (void)hipEventRecord(h->ev_join, h->s_side);
   // The bookkeeping of the main envs (:446-495; k_flags.h, one wavefront per car) needs the poses only.  It runs right
   // before the raster, and those ~16 us are what the list chains — forked off at the same moment — need to get their
