@@ -370,9 +370,10 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   uint32_t* store = p.cc_store + (size_t)env * (MCR_CC_MAX * MCR_CC_WORDS + 4);
   // cheap exit: no pair of car boxes (tight AABB + 0.05) overlaps -> no fixture pair can touch
   bool any_pair = false;
+  uint32_t amask = 0u;                                         // bit a: car a's box overlaps the box of some car b > a
   if (p.car_contacts && N > 1) {
     for (int a = 0; a < N - 1; ++a) for (int b = a + 1; b < N; ++b)
-      any_pair = any_pair || !(cbox[a][0] > cbox[b][2] || cbox[a][2] < cbox[b][0] || cbox[a][1] > cbox[b][3] || cbox[a][3] < cbox[b][1]);
+      if (!(cbox[a][0] > cbox[b][2] || cbox[a][2] < cbox[b][0] || cbox[a][1] > cbox[b][3] || cbox[a][3] < cbox[b][1])) { any_pair = true; amask |= 1u << a; }
   }
   int nn_final = 0;                                            // touching car<->car pairs of this env (wave-uniform)
   if (p.car_contacts && N > 1 && !any_pair) {
@@ -383,7 +384,11 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
     int total = 0;
     for (int a = 0; a < N - 1; ++a) total += 64 * (N - 1 - a);
     int base = 0;
-    for (int r0 = 0; r0 < total; r0 += 64) {
+    for (int r0 = 0, a_of = 0, a_end = 64 * (N - 1); r0 < total; r0 += 64) {
+      // (the 64 x (N-1-a) pair slots of car a are whole 64-lane chunks: a chunk whose car a has no partner b > a with an overlapping
+      // box cannot hold a touching pair — at N = 8 that skips most of the 28 chunks)
+      while (r0 >= a_end) { ++a_of; a_end += 64 * (N - 1 - a_of); }
+      if (!((amask >> a_of) & 1u)) continue;
       const int idx = r0 + lane;
       bool valid = idx < total;
       int a = 0, fa = 0, b = 1, fb = 0;

@@ -57,16 +57,19 @@ __device__ __forceinline__ bool mcr_touch_verdict(const McrParams& p, const int 
   const float cb0 = lox - 0.05f, cb1 = loy - 0.05f, cb2 = hix + 0.05f, cb3 = hiy + 0.05f;     // the car's box, on all 8 lanes of the car
   // cheap exit, as in k_collide: no pair of car boxes overlaps -> no fixture pair can touch
   bool any_pair = false;
+  uint32_t amask = 0u;                                            // bit a: car a's box overlaps the box of some car b > a
   for (int a = 0; a < N - 1; ++a)
     for (int b = a + 1; b < N; ++b) {
       const float a0 = __shfl(cb0, a * 8), a1 = __shfl(cb1, a * 8), a2 = __shfl(cb2, a * 8), a3 = __shfl(cb3, a * 8);
       const float b0 = __shfl(cb0, b * 8), b1 = __shfl(cb1, b * 8), b2 = __shfl(cb2, b * 8), b3 = __shfl(cb3, b * 8);
-      any_pair = any_pair || !(a0 > b2 || a2 < b0 || a1 > b3 || a3 < b1);
+      if (!(a0 > b2 || a2 < b0 || a1 > b3 || a3 < b1)) { any_pair = true; amask |= 1u << a; }
     }
   if (!any_pair) return false;
   int total = 0;
   for (int a = 0; a < N - 1; ++a) total += 64 * (N - 1 - a);
-  for (int r0 = 0; r0 < total; r0 += 64) {
+  for (int r0 = 0, a_of = 0, a_end = 64 * (N - 1); r0 < total; r0 += 64) {
+    while (r0 >= a_end) { ++a_of; a_end += 64 * (N - 1 - a_of); }          // the chunk's car a (k_collide.h: same skip)
+    if (!((amask >> a_of) & 1u)) continue;
     const int idx = r0 + lane;
     bool valid = idx < total;
     int a = 0, fa = 0, b = 1, fb = 0;
