@@ -19,7 +19,7 @@ except Exception as e:
     b = {}
     lines.append(f"(bench_plain missing: {e})\n")
 
-KERNELS = ("k_collide", "k_dynamics", "k_view", "k_flags_list", "k_flags", "k_list_chain", "k_reset_list", "k_install", "k_touch", "k_step_begin", "fillBuffer", "copyBuffer")
+KERNELS = ("k_collide", "k_dynamics", "k_viewprep", "k_view", "k_flags_list", "k_flags", "k_list_chain", "k_reset_list", "k_install", "k_touch", "k_step_begin", "fillBuffer", "copyBuffer")
 def kname(s):
     for k in KERNELS:
         if k in s: return k
@@ -28,13 +28,13 @@ def kname(s):
 # launches of a step by queue, in launch order (mcr_hip.hip: launch_step, round 3):
 #   caller's queue : [collide, when the contact pass runs in front] dynamics (main envs) -> chain (resume) [-> bookkeeping] -> view
 #   side queue     : [collide, beside the dynamics] -> chain (contact envs) [-> bookkeeping] -> view -> reset pass (re-spawned envs) -> view
-#   third queue    : bookkeeping + view records (main envs) -> view (main envs)
+#   third queue    : view records (k_viewprep, N <= 2) -> bookkeeping (main envs) -> view (main envs)
 CALLER = {"k_collide": ["collide (all envs)"], "k_dynamics": ["dynamics (main envs)"], "k_list_chain": ["chain (resume of deferred envs, caller's stream)"],
           "k_flags_list": ["bookkeeping (deferred envs)"], "k_view": ["view (deferred envs, caller's stream)"]}
 SIDE = {"k_collide": ["collide (all envs)"], "k_list_chain": ["chain (contact envs, side stream)"], "k_flags_list": ["bookkeeping (contact envs)"],
         "k_reset_list": ["reset pass (re-spawned envs, side stream)"], "k_view": ["view (contact envs, side stream)", "view (re-spawned envs, side stream)"]}
-THIRD = {"k_flags": ["bookkeeping + view records (main envs, third stream)"], "k_view": ["view (main envs)"]}
-STEP_KERNELS = ("k_collide", "k_dynamics", "k_view", "k_flags", "k_flags_list", "k_list_chain", "k_reset_list")
+THIRD = {"k_viewprep": ["view records + car polygons (main envs, third stream)"], "k_flags": ["bookkeeping (main envs, third stream)"], "k_view": ["view (main envs)"]}
+STEP_KERNELS = ("k_collide", "k_dynamics", "k_viewprep", "k_view", "k_flags", "k_flags_list", "k_list_chain", "k_reset_list")
 
 def label(df, order_col):
     """adds column Label for the launches of the last STEPS steps.  A step starts with its contact pass (the k_collide launch that
@@ -68,7 +68,7 @@ def label(df, order_col):
             key = (k, q); n = seen.get(key, 0); seen[key] = n + 1
             if q == main_q:
                 names = dict(CALLER)
-                if third_q is None: names.update({"k_flags": THIRD["k_flags"], "k_view": THIRD["k_view"] + CALLER["k_view"]})
+                if third_q is None: names.update({"k_viewprep": THIRD["k_viewprep"], "k_flags": THIRD["k_flags"], "k_view": THIRD["k_view"] + CALLER["k_view"]})
                 names = names.get(k, [])
             elif q == third_q: names = THIRD.get(k, [])
             else: names = SIDE.get(k, [])
@@ -92,7 +92,7 @@ for name, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     c = label(pd.read_csv(f"{src}/{name}/p_counter_collection.csv"), "Dispatch_Id")
     gsel = c[(c.Label == "view (main envs)") & (c.Counter_Name == ctr)]
     traffic[ctr] = float(gsel.Counter_Value.mean())
-    side = c[(c.K == "k_view") & c.Label.notna() & (c.Label != "view (main envs)") & (c.Counter_Name == ctr)]
+    side = c[(c.K == "k_view") & c.Label.notna() & (c.Label != "view (main envs)") & (c.Counter_Name == ctr)]     # the list launches of the raster (k_viewprep is a kernel of its own)
     traffic[ctr + "_side"] = float(side.Counter_Value.sum() / STEPS) if len(side) else 0.0
 # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB; MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reads exactly 1/2 of
 # the bytes of a wide coalesced stream -> x2; WRITE_SIZE is taken as reported (uncalibrated).
