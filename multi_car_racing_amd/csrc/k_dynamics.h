@@ -1193,6 +1193,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
 // main launches (roles 0 / 1): 64 / G envs per wavefront (the list launches of roles >= 2 call dynamics_block from k_list_chain.h)
 __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
   if (mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) {         // the next step's lists: every reader of these buffers finished last step
+    if (p.soft_sync && p.role == 1) mcr_post(p, W_BEGIN);         // the caller's stream is here: the side stream may start this step
     if (p.role == 1) p.clist_next[0] = 0;
     for (int i = 0; i < 4; ++i) if (p.next_counts[i]) *p.next_counts[i] = 0;
   }

@@ -26,6 +26,18 @@ __device__ __forceinline__ void list_reset_pass(const McrParams& p, const int bl
 // waits for the other in a stream (the re-spawned envs used to queue behind the contact chain, which is long in 1 step of 6).
 __global__ __launch_bounds__(64) void k_list_chain(McrParams pa, McrParams pb, const int with_flags, const int ga) {
   __builtin_amdgcn_s_setprio(3);
+  // soft_sync (mcr_kernels.h): the contact chain follows the contact pass in its stream — its start IS the contact pass's completion
+  if (pa.soft_sync && pa.role == 2 && pa.cc_mode && blockIdx.x == 0 && threadIdx.x == 0) mcr_post(pa, W_COL);
+  if (pa.soft_sync && pa.role == 3) {
+    // the resume chain follows the main dynamics in its stream: its start IS the dynamics' completion (the third stream's kernels wait for
+    // that); and its envs read what the contact pass left for them (a deferred env never got to the main dynamics' in-kernel wait)
+    if (blockIdx.x == 0 && threadIdx.x == 0) mcr_post(pa, W_DYN);
+    if (pa.cc_mode) {
+      if (threadIdx.x == 0) (void)mcr_await(pa, W_COL);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __syncthreads();
+    }
+  }
   // (two branches instead of one body on `first ? pa : pb`: selecting between the two argument blocks makes the compiler copy
   // one into scratch memory, 1 KB per lane)
   if ((int)blockIdx.x < ga) {
@@ -67,4 +79,10 @@ __global__ __launch_bounds__(64) void k_flags_list(McrParams p) {
   __builtin_amdgcn_s_setprio(3);
   const int nb = mcr_list_len(p) * p.N;
   for (int blk = blockIdx.x; blk < nb; blk += gridDim.x) flags_block(p, blk);
+}
+
+// soft_sync's one-thread kernels (see mcr_post / mcr_await)
+__global__ void k_post(McrParams p, int w) { if (threadIdx.x == 0) mcr_post(p, w); }
+__global__ void k_await(McrParams p, int w0, int w1) {
+  if (threadIdx.x == 0) { if (w0 >= 0) (void)mcr_await(p, w0); if (w1 >= 0) (void)mcr_await(p, w1); }
 }

@@ -113,7 +113,14 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
   {
     const int s = (int)blockIdx.x + (PERSIST ? lane * (int)gridDim.x : 0);
     int e = -1;
-    if (p.role >= 2) { e = mcr_env_of_slot(p, split_views ? s / N : s); if (e >= p.env0 + p.nenv) e = -1; my_agent = split_views ? s % N : 0; }
+    bool ojr = only_just_reset != 0;
+    if (p.role == 5) {
+      // the tail of the caller's stream: the deferred envs, then the envs the main dynamics re-spawned (their first observation) — one launch
+      const int idx = split_views ? s / N : s, nd = p.dlist[0], nr = p.rlist[0];
+      if (idx < nd) e = p.dlist[1 + idx]; else if (idx - nd < nr) { e = p.rlist[1 + idx - nd]; ojr = true; }
+      my_agent = split_views ? s % N : 0;
+    }
+    else if (p.role >= 2) { e = mcr_env_of_slot(p, split_views ? s / N : s); if (e >= p.env0 + p.nenv) e = -1; my_agent = split_views ? s % N : 0; }
     else if (p.use_vorder) {
       // one load instead of a chain of four (list counts -> list entry -> env record -> slot header): the entry k_dynamics left
       // carries the env, its episode slot and the slot's entry count; only envs this launch draws are listed (active, not
@@ -128,13 +135,15 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
     if (e >= 0 && (!p.use_vorder || p.role >= 2)) {
       const McrEnvState es = p.env[e];
       // side-stream raster: a contact env re-spawned by this step's dynamics is drawn after its reset pass
-      if (!es.active || (only_just_reset && !es.just_reset) || (p.role >= 2 && !only_just_reset && es.resetting)) e = -1;
+      if (!es.active || (ojr && !es.just_reset) || (p.role >= 2 && !ojr && es.resetting)) e = -1;
       my_slot = es.slot;
     }
     my_env = e;
   }
   unsigned long long todo = PERSIST ? __ballot(my_env >= 0) : (my_env >= 0 ? 1ull : 0ull);
-  if (!todo) return;
+  // (soft_sync: the step's join, see McrParams::await_tail)
+  auto join_tail = [&]() { if (PERSIST && p.await_tail && blockIdx.x == 0 && threadIdx.x == 0) { (void)mcr_await(p, W_SIDE); (void)mcr_await(p, W_MAIN); } };
+  if (!todo) { join_tail(); return; }
   auto slot_of = [&](int k) -> const uint8_t* {
     return p.slots + ((size_t)__builtin_amdgcn_readlane(my_env, k) * 2 + __builtin_amdgcn_readlane(my_slot, k)) * MCR_SLOT_BYTES;
   };
@@ -531,4 +540,5 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
   // hand-over: every thread is past the last barrier of the view's span fill, nobody reads the tile flags any more
   env = env_n; slot = slot_n; P = UNI(P_nv); tfl[tid] = tfl_n; a_lo = a_lo_n;
   }
+  join_tail();
 }

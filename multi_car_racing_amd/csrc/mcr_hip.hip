@@ -10,6 +10,7 @@
 #include "k_list_chain.h"
 #include "k_render.h"
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <string>
 #include <vector>
 #include <cstring>
@@ -69,6 +70,9 @@ struct mcr_env {
   bool split_views;           // list raster launches draw one view per workgroup
   int list_view_grid;         // workgroups of a list raster launch
   int chain_lds_pad;          // bytes of dynamic LDS the resume chain's workgroups ask for beyond what they use (see launch_step)
+  bool merge_list_views = true;   // the deferred and the re-spawned envs' frames in one list launch at the tail of the resume chain
+  bool soft_sync = false;     // the step's streams meet through phase words in device memory (mcr_kernels.h: mcr_post / mcr_await) instead of events
+  bool stop_events = true;    // events completed by the launches they mark (hipExtLaunchKernelGGL) instead of marker packets behind them
   bool resume_on_caller;      // three-chain step: the resume chain keeps the caller's stream, bookkeeping + main raster hop to the third stream
   int chain_grid;             // workgroups of a list chain launch (each walks the list, 2 envs at a time)
   bool vorder_dirty[2];       // the raster order list of that step parity was filled by a step that did not draw
@@ -152,6 +156,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   const size_t o_part = carve(2 * (size_t)B);                 // x2: the touch verdicts of a step live in the buffer of its parity
   const size_t o_dpart = carve(B);
   const size_t o_epoch = carve(sizeof(int32_t) * ((size_t)B + 1));
+  const size_t o_sync = carve(sizeof(int32_t) * 16 * MCR_SYNC_WORDS);
   const size_t o_dlist = carve(sizeof(int32_t) * 2 * ((size_t)B + 1));      // x2: the lists of a step live in the buffers of its parity
   const size_t o_rlist = carve(sizeof(int32_t) * 2 * ((size_t)B + 1));
   const size_t o_dstate = carve(BN);
@@ -181,7 +186,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   P.cc_store = (uint32_t*)(base + o_cc); P.bpf = (float*)(base + o_bpf); P.bp_stamp = (uint32_t*)(base + o_bpstamp); P.shapes = (const McrShapes*)(base + o_shapes); P.slots = base + o_slots;
   h->view_stamps = (unsigned long long*)(base + o_vscratch);
   P.viewp = (float*)(base + o_viewp);
-  P.part = base + o_part; P.dpart = base + o_dpart; P.collide_epoch = (int32_t*)(base + o_epoch); h->dev_step_ctr = P.collide_epoch + B; P.dlist = (int32_t*)(base + o_dlist); P.rlist = (int32_t*)(base + o_rlist); P.defer_state = base + o_dstate; P.counters = (unsigned long long*)(base + o_counters); P.stats = (double*)(base + o_stats);
+  P.part = base + o_part; P.dpart = base + o_dpart; P.collide_epoch = (int32_t*)(base + o_epoch); h->dev_step_ctr = P.collide_epoch + B; P.sync_words = (int32_t*)(base + o_sync); P.dlist = (int32_t*)(base + o_dlist); P.rlist = (int32_t*)(base + o_rlist); P.defer_state = base + o_dstate; P.counters = (unsigned long long*)(base + o_counters); P.stats = (double*)(base + o_stats);
   h->stage_ids = (int32_t*)(base + o_stage_ids); P.vcount = (int32_t*)(base + o_vorder); P.vorder = P.vcount + 2; P.dbg_stamps = (unsigned long long*)(base + o_stamps); P.clist = (int32_t*)(base + o_clist);
   P.carpoly = (float*)(base + o_carpoly);
   P.particles = cfg->skid_particles ? (uint32_t*)(base + o_particles) : nullptr;
@@ -216,9 +221,12 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
     int prio_lo = 0, prio_hi = 0; (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     if (hipStreamCreateWithPriority(&h->s_side, hipStreamNonBlocking, prio_hi) == hipSuccess) {
       if (hipStreamCreateWithPriority(&h->s_defer, hipStreamNonBlocking, prio_hi) == hipSuccess) {
-        (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&h->ev_col, hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming);
+        const unsigned evf = hipEventDisableTiming | ((getenv("MCR_EVENT_DEVICE_SCOPE") && atoi(getenv("MCR_EVENT_DEVICE_SCOPE"))) ? hipEventReleaseToDevice : 0u);
+        for (hipEvent_t* e : {&h->ev_fork, &h->ev_join, &h->ev_fork2, &h->ev_join2, &h->ev_col, &h->ev_chain}) (void)hipEventCreateWithFlags(e, evf);
+        if (const char* g = getenv("MCR_STOP_EVENTS")) h->stop_events = atoi(g) != 0;
+        h->soft_sync = kernels_overlap(h->s_defer, h->s_side);     // (a waiting kernel needs the kernels it waits for to run beside it)
+        if (const char* g = getenv("MCR_SOFT_SYNC")) h->soft_sync = h->soft_sync && atoi(g) != 0;
+        if (const char* g = getenv("MCR_MERGE_LIST_VIEWS")) h->merge_list_views = atoi(g) != 0;
         // (beyond 4 cars per env the one-step-ahead touch verdict — a second pass over up to 28 car pairs — costs more than the
         // contact pass gains by running beside the dynamics: measured at N = 8, round 2: 3.66 vs 4.28 M env-steps/s.  Round 3 tried a
         // CONSERVATIVE verdict there instead — bounding discs + car boxes, no narrowphase, the contact chain taking every env it
@@ -288,6 +296,14 @@ static hipEvent_t get_event(mcr_env* h) {
   hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
 #define LAUNCH(kid_, kernel, grid, block, st, ...) LAUNCH_LDS(kid_, kernel, grid, block, 0, st, __VA_ARGS__)
+// a launch that completes the event `stop_` itself (nullptr: none): see mcr_view_launch
+#define LAUNCH_LDS_STOP(kid_, kernel, grid, block, lds_, st, stop_, ...)                               \
+  do {                                                                                   \
+    TimedLaunch tl_; bool tm_ = (h->timing >> (kid_)) & 1;                                              \
+    if (tm_) { tl_.id = (kid_); tl_.a = get_event(h); tl_.b = get_event(h); (void)hipEventRecord(tl_.a, st); } \
+    hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds_, st, nullptr, stop_, 0, __VA_ARGS__);          \
+    if (tm_) { (void)hipEventRecord(tl_.b, st); h->pending.push_back(tl_); }                   \
+  } while (0)
 #define LAUNCH_LDS(kid_, kernel, grid, block, lds_, st, ...)                                         \
   do {                                                                                   \
     TimedLaunch tl_; bool tm_ = (h->timing >> (kid_)) & 1;                                              \
@@ -296,18 +312,18 @@ static hipEvent_t get_event(mcr_env* h) {
     if (tm_) { (void)hipEventRecord(tl_.b, st); h->pending.push_back(tl_); }                   \
   } while (0)
 
-void mcr_view_launch(int variant, int grid, hipStream_t st, const McrParams& P, unsigned long long* stamps, int only_just_reset);   // mcr_view.hip
+void mcr_view_launch(int variant, int grid, hipStream_t st, const McrParams& P, unsigned long long* stamps, int only_just_reset, hipEvent_t stop);   // mcr_view.hip
 // raster launch (k_view.h).  Main launches: one workgroup per work slot.  List launches (role >= 2): MCR_LIST_GRID
 // persistent workgroups that walk the list (lane k of a wavefront holds a workgroup's k-th env, so never fewer than
 // slots / 64 workgroups).
 static int list_grid(int slots, int want) { return std::min(slots, std::max(want, (slots + 63) / 64)); }
-static void launch_view(mcr_env* h, int kid, int slots, hipStream_t st, const McrParams& P, int only_just_reset) {
+static void launch_view(mcr_env* h, int kid, int slots, hipStream_t st, const McrParams& P, int only_just_reset, hipEvent_t stop = nullptr) {
   TimedLaunch tl; const bool tm = (h->timing >> kid) & 1;
   if (tm) { tl.id = kid; tl.a = get_event(h); tl.b = get_event(h); (void)hipEventRecord(tl.a, st); }
   // (list launches: with more than two cars per env the contact list is long — N = 8: ~340 envs x 8 views per step — and 128
   // workgroups would draw ~20 views each, one after the other, at the end of the side stream's chain)
-  if (P.role >= 2) { McrParams Q = P; Q.split_views = h->split_views ? 1 : 0; mcr_view_launch(2, list_grid(slots * (Q.split_views ? P.N : 1), h->list_view_grid), st, Q, h->view_stamps, only_just_reset); }
-  else mcr_view_launch((P.debug & 32) ? 1 : 0, slots, st, P, h->view_stamps, only_just_reset);
+  if (P.role >= 2) { McrParams Q = P; Q.split_views = h->split_views ? 1 : 0; mcr_view_launch(2, list_grid(slots * (Q.split_views ? P.N : 1), h->list_view_grid), st, Q, h->view_stamps, only_just_reset, stop); }
+  else mcr_view_launch((P.debug & 32) ? 1 : 0, slots, st, P, h->view_stamps, only_just_reset, stop);
   if (tm) { (void)hipEventRecord(tl.b, st); h->pending.push_back(tl); }
 }
 
@@ -391,65 +407,126 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, st, h->dev_step_ctr);
     P.epoch = 0; P.epoch_ptr = h->dev_step_ctr;
   }
-  if (!cc) LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), st, P, 0);
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &capturing);
+  if (h->soft_sync && h->use_graph <= 0 && capturing == hipStreamCaptureStatusNone && h->resume_on_caller && (!draw || h->merge_list_views)) {
+    // ---- the three chains ordered by phase words (mcr_kernels.h: soft_sync) — no marker / barrier packets on any stream:
+    //   s_side  : await(BEGIN) -> [collide -> post(COL)] -> chain(contact envs) -> raster -> post(SIDE)
+    //   st      : [posts BEGIN] dynamics(main envs) -> [posts DYN, awaits COL] chain(resume + re-spawned envs) -> raster -> await(SIDE, MAIN)
+    //   s_defer : await(DYN, COL) -> view records -> bookkeeping(main envs) -> raster(main envs) -> post(MAIN)
+    // (kernel trace, round 3: the resume chain starts 2 us after the dynamics instead of 11, the next step's dynamics @@ us after
+    // the step's last kernel instead of 20)
+    P.soft_sync = 1;
+    const int fuse_flags = (view_flags && N <= 2 && h->fuse_flags) ? 1 : 0;
+    const int lg_flags = std::min(B * N, (N <= 2 ? 4 : 32) * MCR_LIST_GRID);
+    const bool flags_list = view_flags && !fuse_flags;
+    if (!cc) LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), st, P, 0);
+    hipLaunchKernelGGL(k_await, dim3(1), dim3(64), 0, h->s_side, P, (int)W_BEGIN, -1);
+    if (cc) LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), h->s_side, P, 0);     // (W_COL: posted by the chain that follows)
+    P.split = 0;
+    P.role = 2;
+    LAUNCH_LDS(5, k_list_chain, lg_dyn, 64, col::lds_bytes(N), h->s_side, P, P, fuse_flags, lg_dyn);
+    if (flags_list) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, h->s_side, P);
+    if (draw) launch_view(h, 6, B, h->s_side, P, 0);
+    hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, h->s_side, P, (int)W_SIDE);
+    P.role = 1;
+    P.viewprep_in_flags = (view_flags && draw && h->viewprep_in_flags) ? 1 : 0;
+    LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 0);
+    P.role = 3;
+    {
+      const int ga = std::min(lg_dyn, MCR_LIST_GRID / 2), gb = P.auto_reset ? lg_col : 0;
+      McrParams Pr = P; Pr.role = 4; Pr.list_envs_per_block = 1;
+      LAUNCH_LDS(7, k_list_chain, ga + gb, 64, col::lds_bytes(N) + h->chain_lds_pad, st, P, Pr, fuse_flags, ga);
+      if (flags_list) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, st, P);
+      if (draw) { McrParams Pv = P; Pv.role = P.auto_reset ? 5 : 3; Pv.await_tail = 1; launch_view(h, 7, B, st, Pv, 0); }     // ... and the step's join
+    }
+    P.role = 1;
+    hipLaunchKernelGGL(k_await, dim3(1), dim3(64), 0, h->s_defer, P, (int)W_DYN, cc ? (int)W_COL : -1);
+    if (P.viewprep_in_flags) hipLaunchKernelGGL(k_viewprep, dim3(dyn_blocks), dim3(64), 0, h->s_defer, P);
+    if (view_flags) hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, h->s_defer, P);
+    P.use_vorder = 1;
+    if (draw) launch_view(h, 2, B, h->s_defer, P, 0);
+    P.use_vorder = 0;
+    hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, h->s_defer, P, (int)W_MAIN);
+    if (!draw) hipLaunchKernelGGL(k_await, dim3(1), dim3(64), 0, st, P, (int)W_SIDE, (int)W_MAIN);
+    return;
+  }
+  // Events: where the kernel an event marks is known, the launch completes the event itself (hipExtLaunchKernelGGL's stop event:
+  // the dispatch packet's own completion signal).  A hipEventRecord is a marker packet BEHIND the kernel: +3 us before the next
+  // kernel of the same stream, 11 instead of 7.5 us for a dependent kernel on another stream (tools/ubench/event_gap.hip), and the
+  // step has four of them on its critical path.  Not inside a graph capture (plain records there).
+  const bool sev = h->stop_events && h->use_graph <= 0;
+#define STOP(ev) (sev ? (ev) : (hipEvent_t) nullptr)
+#define RECORD_UNLESS_STOP(ev, stream) do { if (!sev) (void)hipEventRecord(ev, stream); } while (0)
+  if (!cc) LAUNCH_LDS_STOP(0, k_collide, B, 64, col::lds_bytes(N), st, STOP(h->ev_col), P, 0);
   (void)hipEventRecord(h->ev_fork, st);
   (void)hipStreamWaitEvent(h->s_side, h->ev_fork, 0);
-  if (cc) LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), h->s_side, P, 0);
-  (void)hipEventRecord(h->ev_col, cc ? h->s_side : st);
+  if (cc) LAUNCH_LDS_STOP(0, k_collide, B, 64, col::lds_bytes(N), h->s_side, STOP(h->ev_col), P, 0);
+  RECORD_UNLESS_STOP(h->ev_col, cc ? h->s_side : st);
   P.split = 0;
   // bookkeeping of a chain's cars: fused into the chain for N <= 2 (2 envs x N cars take their turns on one wavefront),
   // a list launch of its own beyond that
   const int fuse_flags = (view_flags && N <= 2 && h->fuse_flags) ? 1 : 0;
   const int lg_flags = std::min(B * N, (N <= 2 ? 4 : 32) * MCR_LIST_GRID);
+  const bool merged = draw && h->merge_list_views;     // the re-spawned envs' frames: with the deferred envs' (one launch), not on the side stream
+  const bool flags_list = view_flags && !fuse_flags;
   P.role = 2;
-  LAUNCH_LDS(5, k_list_chain, lg_dyn, 64, col::lds_bytes(N), h->s_side, P, P, fuse_flags, lg_dyn);
-  if (view_flags && !fuse_flags) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, h->s_side, P);
-  if (draw) launch_view(h, 6, B, h->s_side, P, 0);
+  // (the side stream's last kernel completes ev_join; which one that is depends on the step's shape)
+  const bool side_ends_with_view = draw && (merged || !P.auto_reset);
+  LAUNCH_LDS_STOP(5, k_list_chain, lg_dyn, 64, col::lds_bytes(N), h->s_side, STOP((!draw && !flags_list) ? h->ev_join : nullptr), P, P, fuse_flags, lg_dyn);
+  if (flags_list) hipExtLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, h->s_side, nullptr, STOP(!draw ? h->ev_join : nullptr), 0, P);
+  if (draw) launch_view(h, 6, B, h->s_side, P, 0, STOP(side_ends_with_view ? h->ev_join : nullptr));
   P.role = 1;
   // the main envs' view records and car polygons: by k_viewprep on the side stream, beside the bookkeeping kernel, in a drawn step
   // with actions; otherwise by the dynamics' own epilogue
   P.viewprep_in_flags = (view_flags && draw && h->viewprep_in_flags) ? 1 : 0;
-  LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 0);
-  (void)hipEventRecord(h->ev_fork2, st);
-  // Which of the two remaining chains stays on the caller's stream?  The kernel that follows the dynamics IN-STREAM starts ~5 us
-  // after it, one that has to hop to another stream ~20 us (kernel trace, round 3).  The longer chain is the resume chain (115-140
-  // us beside the raster + its own raster, 16 us) — not bookkeeping + main raster (15 + 100 us): it keeps the caller's stream, gets
+  LAUNCH_LDS_STOP(1, k_dynamics, dyn_blocks, 64, 0, st, STOP(h->ev_fork2), P, 0);
+  RECORD_UNLESS_STOP(h->ev_fork2, st);
+  // Which of the two remaining chains stays on the caller's stream?  The kernel that follows the dynamics IN-STREAM starts ~2 us
+  // after it, one that has to hop to another stream ~8 us (kernel trace, round 3).  The longer chain is the resume chain (85-150
+  // us beside the raster + its own raster, 25-70 us) — not bookkeeping + main raster (40 + 100 us): it keeps the caller's stream, gets
   // its wavefronts placed before the raster starts (a chain that starts beside a raster that fills every CU runs 2-3x slower),
   // and the main envs' bookkeeping + raster take the hop.
   hipStream_t s_resume = h->resume_on_caller ? st : h->s_defer, s_mainview = h->resume_on_caller ? h->s_defer : st;
   (void)hipStreamWaitEvent(h->s_defer, h->ev_fork2, 0);
   (void)hipStreamWaitEvent(s_resume, h->ev_col, 0);              // the resume chain reads the contact pass's results of its envs (a deferred env never got to the main dynamics' in-kernel wait)
-  (void)hipStreamWaitEvent(h->s_side, h->ev_fork2, 0);
+  if (!merged) (void)hipStreamWaitEvent(h->s_side, h->ev_fork2, 0);
   P.role = 3;
+  hipEvent_t resume_done = s_resume == st ? (hipEvent_t) nullptr : h->ev_join2;     // the chain on the third stream ends with ev_join2
   {
     // the resume chain and — same launch, workgroups of their own — the reset pass (:408, ~50 us of serial solver work) of the
-    // envs the main dynamics re-spawned; then the deferred envs' frames here and the re-spawned envs' first observations on the
-    // side stream (behind the contact chain's raster: off the critical path unless that chain is a long one)
+    // envs the main dynamics re-spawned; then, in one list launch, the deferred envs' frames and the re-spawned envs' first observations
     const int ga = std::min(lg_dyn, MCR_LIST_GRID / 2), gb = P.auto_reset ? lg_col : 0;
     McrParams Pr = P; Pr.role = 4; Pr.list_envs_per_block = 1;     // one re-spawned env per workgroup: they run side by side
-    LAUNCH_LDS(7, k_list_chain, ga + gb, 64, col::lds_bytes(N) + h->chain_lds_pad, s_resume, P, Pr, fuse_flags, ga);
-    (void)hipEventRecord(h->ev_chain, s_resume);
-    if (view_flags && !fuse_flags) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, s_resume, P);
-    if (draw) launch_view(h, 7, B, s_resume, P, 0);
-    if (P.auto_reset && draw) { (void)hipStreamWaitEvent(h->s_side, h->ev_chain, 0); launch_view(h, 4, B, h->s_side, Pr, 0); }
+    LAUNCH_LDS_STOP(7, k_list_chain, ga + gb, 64, col::lds_bytes(N) + h->chain_lds_pad, s_resume, STOP((!draw && !flags_list) ? resume_done : nullptr), P, Pr, fuse_flags, ga);
+    if (!merged && P.auto_reset && draw) (void)hipEventRecord(h->ev_chain, s_resume);
+    if (flags_list) hipExtLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, s_resume, nullptr, STOP(!draw ? resume_done : nullptr), 0, P);
+    if (merged) { McrParams Pv = P; Pv.role = P.auto_reset ? 5 : 3; launch_view(h, 7, B, s_resume, Pv, 0, STOP(resume_done)); }
+    else {
+      if (draw) launch_view(h, 7, B, s_resume, P, 0, STOP(resume_done));
+      if (P.auto_reset && draw) { (void)hipStreamWaitEvent(h->s_side, h->ev_chain, 0); launch_view(h, 4, B, h->s_side, Pr, 0, STOP(h->ev_join)); }
+    }
   }
   P.role = 1;
-  (void)hipEventRecord(h->ev_join, h->s_side);
+  RECORD_UNLESS_STOP(h->ev_join, h->s_side);
   // The bookkeeping of the main envs (:446-495; k_flags.h, one wavefront per car) needs the poses only.  It runs right
   // before the raster, and those ~16 us are what the list chains — forked off at the same moment — need to get their
   // wavefronts placed: a chain that starts beside a raster that already fills every CU runs 2-3x slower (measured).
   // (k_viewprep in front of it, in-stream: the side stream may be held by a long contact chain, and a further stream slows every queue)
+  hipEvent_t main_done = s_mainview == st ? (hipEvent_t) nullptr : h->ev_join2;
   if (P.viewprep_in_flags) hipLaunchKernelGGL(k_viewprep, dim3(dyn_blocks), dim3(64), 0, s_mainview, P);
-  if (view_flags) hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, s_mainview, P);
+  if (view_flags) hipExtLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, s_mainview, nullptr, STOP(!draw ? main_done : nullptr), 0, P);
   (void)hipStreamWaitEvent(s_mainview, h->ev_col, 0);              // the raster reads the tiles' recolour flags (long done)
   P.use_vorder = 1;
-  if (draw) launch_view(h, 2, B, s_mainview, P, 0);
+  if (draw) launch_view(h, 2, B, s_mainview, P, 0, STOP(main_done));
   P.use_vorder = 0;
-  // one join on the caller's stream instead of two (each wait is a barrier packet of a few microseconds at the very end of the
-  // step's critical path): the third stream picks the side stream's completion up first
-  (void)hipStreamWaitEvent(h->s_defer, h->ev_join, 0);
-  (void)hipEventRecord(h->ev_join2, h->s_defer);
+  // the join: the caller's stream waits for the other two (waiting for them one behind the other — one wait on the caller's
+  // stream — costs a second hop: 23 vs 18.5 us after the later of the two, tools/ubench/event_gap.hip)
+  if (!sev || (!draw && !view_flags)) (void)hipEventRecord(h->ev_join2, h->s_defer);
+  (void)hipStreamWaitEvent(st, h->ev_join, 0);
   (void)hipStreamWaitEvent(st, h->ev_join2, 0);
+#undef STOP
+#undef RECORD_UNLESS_STOP
 }
 
 // The kernels report conditions that make results wrong in mapped host memory (mcr_kernels.h: ST_*); read here without
@@ -463,7 +540,7 @@ static int check_status(mcr_env* h) {
     const uint32_t v = ((volatile uint32_t*)h->status_host)[i];
     if (v != h->status_seen[i]) {
       h->status_seen[i] = v;
-      if (i == ST_SPIN_GIVEUP) { h->concurrent_collide = false; h->verdict_fresh = false; }
+      if (i == ST_SPIN_GIVEUP) { h->concurrent_collide = false; h->soft_sync = false; h->verdict_fresh = false; }
       g_err = std::string("results of an earlier step are wrong: ") + what[i] + " (" + std::to_string(v) + " so far)";
       return MCR_ERR_STATE;
     }

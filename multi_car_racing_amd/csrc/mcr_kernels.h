@@ -37,6 +37,12 @@ struct McrParams {
   int32_t* collide_epoch;       // [B] k_collide pass 0 stores `epoch` here when it is through with the env (release); see cc_mode
   int32_t epoch;                // the handle's step counter (unique per step) ...
   const int32_t* epoch_ptr;     // ... or, when the step is replayed as a hipGraph (constant arguments), where a device-side counter holds it
+  int32_t* sync_words;          // [MCR_SYNC_WORDS * 16] step-phase words (one per 64-byte line), each holding the epoch of the last step that reached the
+                                // phase: how the step's three streams order their kernels when soft_sync is set (see mcr_post / mcr_await below)
+  int32_t soft_sync;            // 1: the streams of the three-chain step meet through sync_words (tiny kernels / kernel prologues that poll) instead
+                                // of events (marker and barrier packets that the command processor evaluates: 4-17 us each on the critical path)
+  int32_t await_tail;           // soft_sync, list raster at the tail of the caller's stream: its first workgroup ends by awaiting W_SIDE and W_MAIN — the
+                                // launch completes when the whole step has (a kernel of its own for that costs 5-7 us beside the main raster)
   int32_t cc_mode;              // 1: the main k_dynamics runs CONCURRENTLY with k_collide pass 0 (three-chain step): it finds the envs whose
                                 // car boxes overlap by itself (they are the contact chain's), and waits for collide_epoch[env] before it reads
                                 // what the collide pass produces for the step's bookkeeping (reward, tile count, wheel/tile bits)
@@ -71,7 +77,40 @@ struct McrParams {
   double h_ratio;
 };
 
+// status words (mapped host memory; non-zero = the results are no longer trustworthy, mcr_step returns MCR_ERR_STATE)
+enum { ST_SPIN_GIVEUP = 0,     // a kernel gave up waiting for another stream's kernels (three-chain step: the contact pass of an env, a phase word)
+       ST_VERDICT = 1,         // the contact pass disagreed with the one-step-ahead touch verdict
+       ST_CC_OVERFLOW = 2,     // more touching car<->car fixture pairs than the manifold store / the LDS pool holds: the excess was dropped
+       ST_EVENT_OVERFLOW = 3,  // more tile begin events in one env-step than the replay buffer holds
+       MCR_STATUS_WORDS = 8 };
 __device__ __forceinline__ int mcr_epoch(const McrParams& p) { return p.epoch_ptr ? *p.epoch_ptr : p.epoch; }
+// ---- soft_sync: ordering between the step's streams without command-processor packets (tools/ubench/event_gap.hip: a
+// hipEventRecord costs the next kernel of its stream 3 us; a hipStreamWaitEvent 3 us when its event completed long ago, 7.5-11 us
+// when it completes last, and 17 us when it completed a few microseconds before the packet's turn — the queue had been parked on it).
+// A phase word holds the epoch (the handle's step counter) of the last step that reached the phase.  It is POSTED either by a
+// one-thread kernel behind the kernels of the phase, in their stream, or by the first thread of the kernel that follows them in
+// their stream: both run after the end-of-kernel release of everything before them.  It is AWAITED by a one-wavefront kernel in
+// front of the dependent kernels, in their stream (the kernels behind it start with the usual acquire), or — k_list_chain — by a
+// kernel's prologue (poll, then one agent-scope acquire).  Waits are bounded and a give-up is reported like the contact
+// pass's (ST_SPIN_GIVEUP: mcr_step fails, the handle goes back to events).
+enum { W_BEGIN = 0,    // the caller's stream reached this step's main dynamics (everything it held before is complete)
+       W_COL = 1,      // the contact pass (k_collide pass 0, side stream) is complete
+       W_DYN = 2,      // the main dynamics is complete
+       W_SIDE = 3,     // the side stream's part of the step is complete
+       W_MAIN = 4,     // the third stream's part of the step is complete
+       MCR_SYNC_WORDS = 8 };
+__device__ __forceinline__ void mcr_post(const McrParams& p, int w) {
+  __hip_atomic_store(&p.sync_words[w * 16], mcr_epoch(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one lane polls; the caller adds the acquire if it reads the phase's data in the same kernel.  (epochs only grow: ">= 0" also
+// lets a waiter through that is late by a step, which cannot happen while every step awaits the one before)
+__device__ __forceinline__ bool mcr_await(const McrParams& p, int w) {
+  const int epoch = mcr_epoch(p), bound = (p.debug & 4096) ? (1 << 14) : (1 << 24);
+  int spin = 0;
+  for (; spin < bound && (int)(__hip_atomic_load(&p.sync_words[w * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0; ++spin) __builtin_amdgcn_s_sleep(8);
+  if (spin == bound) { atomicAdd(&p.counters[5], 1ull); atomicAdd(&p.status[ST_SPIN_GIVEUP], 1u); return false; }
+  return true;
+}
 #define MCR_VORDER_ENV_MASK 0xfffff
 #define MCR_VORDER_SLOT_SHIFT 20
 #define MCR_VORDER_P_SHIFT 21
@@ -165,11 +204,5 @@ __device__ __noinline__ void mcr_particle_step(uint32_t* pc, int k, bool skid, b
     pc[5 + k] = 2u | (grass ? 256u : 0u);                                    // skid_start = None
   }
 }
-// status words (mapped host memory; non-zero = the results are no longer trustworthy, mcr_step returns MCR_ERR_STATE)
-enum { ST_SPIN_GIVEUP = 0,     // the main dynamics gave up waiting for the contact pass of an env (three-chain step)
-       ST_VERDICT = 1,         // the contact pass disagreed with the one-step-ahead touch verdict
-       ST_CC_OVERFLOW = 2,     // more touching car<->car fixture pairs than the manifold store / the LDS pool holds: the excess was dropped
-       ST_EVENT_OVERFLOW = 3,  // more tile begin events in one env-step than the replay buffer holds
-       MCR_STATUS_WORDS = 8 };
 #define MCR_CC_MAX 24           // touching car<->car fixture pairs kept per env (warm start)
 #define MCR_CC_WORDS 20         // u32 words per stored manifold
