@@ -187,6 +187,13 @@ int mcr_debug_read_verdict_mismatches(mcr_env* h, uint64_t* out1);
 /* 1: the three-chain step runs the contact pass beside the main dynamics (mcr_create found that kernels of different streams
  * overlap in this process); 0: it runs first (single stream, profilers that serialise kernels, MCR_SEQUENTIAL_COLLIDE=1) */
 int mcr_concurrent_collide(const mcr_env* h);
+/* How the streams of the three-chain step are ordered (bit mask; 0 for a single-stream handle):
+ *   1  phase words in device memory, posted and awaited by kernels (no marker / barrier packets; needs overlapping kernels, like
+ *      the concurrent contact pass; MCR_SOFT_SYNC=0 turns it off) — otherwise events;
+ *   2  on the event path, events are completed by the launches they mark (hipExtLaunchKernelGGL) rather than recorded behind them
+ *      (MCR_STOP_EVENTS=0 turns it off).
+ * A wait that gave up (status word 0) puts the handle on the event path for the rest of its life. */
+int mcr_step_ordering(const mcr_env* h);
 /* number of touching car<->car fixture pairs (stored manifolds) per env after the last collide pass */
 int mcr_debug_read_contact_counts(mcr_env* h, int32_t* out /*[num_envs]*/);
 /* Conditions that make results wrong are reported by the kernels in mapped host memory and turned into MCR_ERR_STATE by the

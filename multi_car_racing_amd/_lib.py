@@ -57,6 +57,7 @@ SYMBOLS = {
     "mcr_debug_read_counters": (_i, [_vp, _vp]),
     "mcr_debug_read_verdict_mismatches": (_i, [_vp, _vp]),
     "mcr_concurrent_collide": (_i, [_vp]),
+    "mcr_step_ordering": (_i, [_vp]),
     "mcr_debug_overlap": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
     "mcr_status": (_i, [_vp, _vp, _i]),
     "mcr_debug_read_dynamics_stamps": (_i, [_vp, _vp, _i]),

@@ -8,6 +8,7 @@
 #include "k_collide.h"
 #include "k_dynamics.h"
 #include "k_flags.h"
+#include "k_viewprep.h"
 
 // the reset pass (:408) of the list's envs that were re-spawned in this step: collide pass 1 (clear the per-tile state,
 // re-detect), then the action-less dynamics step
@@ -85,4 +86,12 @@ __global__ __launch_bounds__(64) void k_flags_list(McrParams p) {
 __global__ void k_post(McrParams p, int w) { if (threadIdx.x == 0) mcr_post(p, w); }
 __global__ void k_await(McrParams p, int w0, int w1) {
   if (threadIdx.x == 0) { if (w0 >= 0) (void)mcr_await(p, w0); if (w1 >= 0) (void)mcr_await(p, w1); }
+}
+
+// The main envs' view records (k_viewprep.h, one lane per car: workgroups [0, vp_blocks)) and bookkeeping (k_flags.h, one wavefront
+// per car: the rest) in ONE launch: neither reads what the other writes, and one after the other they were 18 + 23 us in front of
+// the main raster.  Within k_flags' 64 VGPRs, so that its 8192 wavefronts still fit the chip in one round.
+__global__ __launch_bounds__(64, 8) void k_flags_viewprep(McrParams p, const int vp_blocks) {
+  if ((int)blockIdx.x < vp_blocks) viewprep_block(p, (int)blockIdx.x);
+  else flags_block(p, (int)blockIdx.x - vp_blocks);
 }

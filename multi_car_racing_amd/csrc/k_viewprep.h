@@ -134,11 +134,12 @@ __device__ __forceinline__ void viewprep_car(const McrParams& p, const int ci, c
 }
 
 // one lane per car of the main launch's envs (role 1 semantics: not the contact chain's, not the deferred, not the re-spawned ones)
-__global__ __launch_bounds__(64) void k_viewprep(McrParams p) {
-  const int g = blockIdx.x * 64 + threadIdx.x;
+__device__ __forceinline__ void viewprep_block(const McrParams& p, const int blk) {
+  const int g = blk * 64 + threadIdx.x;
   const int env = mcr_env_of_slot(p, g / p.G), agent = g % p.G;
   if (env >= p.env0 + p.nenv || agent >= p.N) return;
   const McrEnvState es = p.env[env];
   if (!es.active || es.just_reset) return;
   viewprep_car(p, env * p.N + agent, es.t);
 }
+__global__ __launch_bounds__(64) void k_viewprep(McrParams p) { viewprep_block(p, (int)blockIdx.x); }

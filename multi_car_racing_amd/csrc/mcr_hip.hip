@@ -71,6 +71,7 @@ struct mcr_env {
   int list_view_grid;         // workgroups of a list raster launch
   int chain_lds_pad;          // bytes of dynamic LDS the resume chain's workgroups ask for beyond what they use (see launch_step)
   bool merge_list_views = true;   // the deferred and the re-spawned envs' frames in one list launch at the tail of the resume chain
+  bool merge_flags_viewprep = true;   // soft_sync path: the main envs' view records and bookkeeping in one launch
   bool soft_sync = false;     // the step's streams meet through phase words in device memory (mcr_kernels.h: mcr_post / mcr_await) instead of events
   bool stop_events = true;    // events completed by the launches they mark (hipExtLaunchKernelGGL) instead of marker packets behind them
   bool resume_on_caller;      // three-chain step: the resume chain keeps the caller's stream, bookkeeping + main raster hop to the third stream
@@ -225,6 +226,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
         for (hipEvent_t* e : {&h->ev_fork, &h->ev_join, &h->ev_fork2, &h->ev_join2, &h->ev_col, &h->ev_chain}) (void)hipEventCreateWithFlags(e, evf);
         if (const char* g = getenv("MCR_STOP_EVENTS")) h->stop_events = atoi(g) != 0;
         h->soft_sync = kernels_overlap(h->s_defer, h->s_side);     // (a waiting kernel needs the kernels it waits for to run beside it)
+        if (const char* g = getenv("MCR_MERGE_FLAGS_VIEWPREP")) h->merge_flags_viewprep = atoi(g) != 0;
         if (const char* g = getenv("MCR_SOFT_SYNC")) h->soft_sync = h->soft_sync && atoi(g) != 0;
         if (const char* g = getenv("MCR_MERGE_LIST_VIEWS")) h->merge_list_views = atoi(g) != 0;
         // (beyond 4 cars per env the one-step-ahead touch verdict — a second pass over up to 28 car pairs — costs more than the
@@ -442,8 +444,11 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     }
     P.role = 1;
     hipLaunchKernelGGL(k_await, dim3(1), dim3(64), 0, h->s_defer, P, (int)W_DYN, cc ? (int)W_COL : -1);
-    if (P.viewprep_in_flags) hipLaunchKernelGGL(k_viewprep, dim3(dyn_blocks), dim3(64), 0, h->s_defer, P);
-    if (view_flags) hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, h->s_defer, P);
+    if (P.viewprep_in_flags && h->merge_flags_viewprep) hipLaunchKernelGGL(k_flags_viewprep, dim3(dyn_blocks + B * N), dim3(64), 0, h->s_defer, P, dyn_blocks);
+    else {
+      if (P.viewprep_in_flags) hipLaunchKernelGGL(k_viewprep, dim3(dyn_blocks), dim3(64), 0, h->s_defer, P);
+      if (view_flags) hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, h->s_defer, P);
+    }
     P.use_vorder = 1;
     if (draw) launch_view(h, 2, B, h->s_defer, P, 0);
     P.use_vorder = 0;
@@ -885,6 +890,10 @@ extern "C" int mcr_debug_read_counters(mcr_env* h, uint64_t* out4) {
   return MCR_OK;
 }
 extern "C" int mcr_concurrent_collide(const mcr_env* h) { return (h && h->split && h->concurrent_collide) ? 1 : 0; }
+extern "C" int mcr_step_ordering(const mcr_env* h) {
+  if (!h || !h->split) return 0;
+  return ((h->soft_sync && h->use_graph <= 0 && h->resume_on_caller && h->merge_list_views) ? 1 : 0) | (h->stop_events ? 2 : 0);
+}
 extern "C" int mcr_debug_read_verdict_mismatches(mcr_env* h, uint64_t* out) {
   if (!h || !out) return MCR_ERR_ARG;
   HIPCHK(hipDeviceSynchronize());

@@ -179,6 +179,28 @@ def test_benched_config_b4096_contacts_sample(torch_cuda, oracle):
     assert frozen == 0
 
 
+@pytest.mark.parametrize("knobs, ordering", [({}, 1), ({"MCR_SOFT_SYNC": "0"}, 2), ({"MCR_SOFT_SYNC": "0", "MCR_STOP_EVENTS": "0"}, 0),
+                                             ({"MCR_SOFT_SYNC": "0", "MCR_MERGE_LIST_VIEWS": "0"}, 2)])
+def test_every_stream_ordering_of_the_step_matches_the_oracle(torch_cuda, oracle, monkeypatch, knobs, ordering):
+    """The three-chain step orders its streams through phase words in device memory (default where kernels overlap) or through
+    events (profilers that serialise kernels, a wait that gave up, graph capture), with the deferred and re-spawned envs' frames in
+    one list launch or two: every variant is the same computation — rear-end collisions, TimeLimit resets and refills included."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    from multi_car_racing_amd.vec_env import VecMultiCarRacing
+    probe = VecMultiCarRacing(64, 2, seed=1, auto_reset=True, car_contacts=True, streams=2)
+    mode, overlap = probe.L.mcr_step_ordering(probe.h), probe.L.mcr_concurrent_collide(probe.h)
+    probe.close()
+    if ordering == 1 and not overlap:
+        pytest.skip("kernels of different streams do not overlap here: the phase-word path is off")
+    assert (mode & 1) == (ordering & 1) and (ordering == 1 or (mode & 2) == (ordering & 2)), (mode, ordering)
+    hot = _contact_envs(torch_cuda, 1024, 2, 33, 200, 90, True)
+    n_resets, n_contacts, frozen = _run_sampled(torch_cuda, oracle, B=1024, N=2, seed=33, steps=200, n_sample=48,
+                                                max_steps=90, state_every=30, car1_floors=True, prefer=hot, masked_reset_at=(77,))
+    assert n_resets >= 96 and n_contacts > 0, (n_resets, n_contacts)
+    assert frozen == 0
+
+
 def test_n8_b4096_properties_and_sampled_oracles(torch_cuda, oracle):
     """BASELINE configs[3]: num_agents=8, batch=4096 — dense car<->car rasterization.  Sampled oracles (state, reward,
     pixels of all 8 views) + size-independent properties + batch independence (env g in B=4096 == env g in B=4)."""

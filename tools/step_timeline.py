@@ -5,7 +5,7 @@ kt = pd.read_csv(sys.argv[1]).sort_values("Start_Timestamp").reset_index(drop=Tr
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 ns = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 def kname(s):
-    for k in ("k_collide", "k_dynamics", "k_viewprep", "k_view", "k_flags_list", "k_flags", "k_list_chain", "k_reset_list", "k_synth", "k_install", "copyBuffer", "fillBuffer"):
+    for k in ("k_collide", "k_dynamics", "k_flags_viewprep", "k_viewprep", "k_view", "k_post", "k_await", "k_flags_list", "k_flags", "k_list_chain", "k_reset_list", "k_synth", "k_install", "copyBuffer", "fillBuffer"):
         if k in s: return k
     return s[:30]
 kt["K"] = kt["Kernel_Name"].map(kname)

@@ -19,22 +19,24 @@ except Exception as e:
     b = {}
     lines.append(f"(bench_plain missing: {e})\n")
 
-KERNELS = ("k_collide", "k_dynamics", "k_viewprep", "k_view", "k_flags_list", "k_flags", "k_list_chain", "k_reset_list", "k_install", "k_touch", "k_step_begin", "fillBuffer", "copyBuffer")
+KERNELS = ("k_collide", "k_dynamics", "k_flags_viewprep", "k_viewprep", "k_view", "k_post", "k_await", "k_flags_list", "k_flags", "k_list_chain", "k_reset_list", "k_install", "k_touch", "k_step_begin", "fillBuffer", "copyBuffer")
 def kname(s):
     for k in KERNELS:
         if k in s: return k
     return s[:60]
 
-# launches of a step by queue, in launch order (mcr_hip.hip: launch_step, round 3):
-#   caller's queue : [collide, when the contact pass runs in front] dynamics (main envs) -> chain (resume) [-> bookkeeping] -> view
-#   side queue     : [collide, beside the dynamics] -> chain (contact envs) [-> bookkeeping] -> view -> reset pass (re-spawned envs) -> view
-#   third queue    : view records (k_viewprep, N <= 2) -> bookkeeping (main envs) -> view (main envs)
+# launches of a step by queue, in launch order (mcr_hip.hip: launch_step, round 3; soft_sync: the streams meet through phase words,
+# k_await / k_post are its one-thread kernels — on the event path, which counter-collecting runs take, they do not appear):
+#   caller's queue : [collide, when the contact pass runs in front] dynamics (main envs) -> chain (resume + reset pass of the re-spawned envs) [-> bookkeeping] -> view (both lists; ends with the step's join)
+#   side queue     : await(begin) -> [collide, beside the dynamics] -> chain (contact envs) [-> bookkeeping] -> view -> post(side done)
+#   third queue    : await(dynamics, collide) -> view records + bookkeeping (k_flags_viewprep, N <= 2; k_flags beyond) -> view (main envs) -> post(main done)
 CALLER = {"k_collide": ["collide (all envs)"], "k_dynamics": ["dynamics (main envs)"], "k_list_chain": ["chain (resume of deferred envs, caller's stream)"],
-          "k_flags_list": ["bookkeeping (deferred envs)"], "k_view": ["view (deferred envs, caller's stream)"]}
+          "k_flags_list": ["bookkeeping (deferred envs)"], "k_view": ["view (deferred + re-spawned envs, caller's stream; waits for the join)"], "k_await": ["join (caller's stream, steps without frames)"]}
 SIDE = {"k_collide": ["collide (all envs)"], "k_list_chain": ["chain (contact envs, side stream)"], "k_flags_list": ["bookkeeping (contact envs)"],
-        "k_reset_list": ["reset pass (re-spawned envs, side stream)"], "k_view": ["view (contact envs, side stream)", "view (re-spawned envs, side stream)"]}
+        "k_reset_list": ["reset pass (re-spawned envs, side stream)"], "k_view": ["view (contact envs, side stream)", "view (re-spawned envs, side stream)"],
+        "k_await": ["await: step begun (side stream; spins from the end of its last step)"], "k_post": ["post: side stream done"]}
 THIRD = {"k_viewprep": ["view records + car polygons (main envs, third stream)"], "k_flags": ["bookkeeping (main envs, third stream)"], "k_view": ["view (main envs)"]}
-STEP_KERNELS = ("k_collide", "k_dynamics", "k_viewprep", "k_view", "k_flags", "k_flags_list", "k_list_chain", "k_reset_list")
+STEP_KERNELS = ("k_collide", "k_dynamics", "k_flags_viewprep", "k_viewprep", "k_view", "k_post", "k_await", "k_flags", "k_flags_list", "k_list_chain", "k_reset_list")
 
 def label(df, order_col):
     """adds column Label for the launches of the last STEPS steps.  A step starts with its contact pass (the k_collide launch that
@@ -45,7 +47,7 @@ def label(df, order_col):
     df["K"] = df["Kernel_Name"].map(kname)
     df["Label"] = None
     dq = df[df.K == "k_dynamics"].Queue_Id.value_counts()
-    fq = df[df.K == "k_flags"].Queue_Id.value_counts()
+    fq = df[df.K.isin(["k_flags", "k_flags_viewprep"])].Queue_Id.value_counts()
     rq = df[df.K == "k_reset_list"].Queue_Id.value_counts()
     if dq.empty:
         return df
@@ -68,7 +70,7 @@ def label(df, order_col):
             key = (k, q); n = seen.get(key, 0); seen[key] = n + 1
             if q == main_q:
                 names = dict(CALLER)
-                if third_q is None: names.update({"k_viewprep": THIRD["k_viewprep"], "k_flags": THIRD["k_flags"], "k_view": THIRD["k_view"] + CALLER["k_view"]})
+                if third_q is None: names.update({"k_viewprep": THIRD["k_viewprep"], "k_flags": THIRD["k_flags"], "k_flags_viewprep": THIRD["k_flags_viewprep"], "k_view": THIRD["k_view"] + CALLER["k_view"]})
                 names = names.get(k, [])
             elif q == third_q: names = THIRD.get(k, [])
             else: names = SIDE.get(k, [])
