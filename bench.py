@@ -205,6 +205,7 @@ def main():
     tmask = 0 if args.no_kernel_timing else (255 if args.time_all_kernels else 4)
     FENCE = LOOKAHEAD // 4
     evs = [torch.cuda.Event(blocking=True) for _ in range(4)]       # the host sleeps at the look-ahead fence instead of spinning on a core the refill thread needs
+    cpu0 = time.process_time()                       # CPU seconds of every thread of this process (step loop, refill thread, track generators)
     t0 = time.perf_counter()
     for k in range(K):
         if tmask:
@@ -221,6 +222,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    host_cores = (time.process_time() - cpu0) / elapsed
     ms, nl = env.timing_read()
     env.timing(0)
     env.wait_refills()
@@ -273,6 +275,8 @@ def main():
             "roofline": roofline,
         }
         out["config"]["step_blocked_on_refill_s_rank0"] = env.env.blocked_s - blocked0
+        out["config"]["host_cores_busy_rank0"] = round(host_cores, 2)      # CPU time / wall time of the timed region: what one rank asks of the host
+        out["config"]["stream_ordering"] = {1: "phase words", 3: "phase words", 2: "events (stop events)", 0: "events"}.get(int(env.env.L.mcr_step_ordering(env.env.h)), "?") if args.streams != 1 else "single stream"
         if emu:
             out["config"]["emulated_host_share"] = emu
         if K < 200:

@@ -83,7 +83,8 @@ __global__ __launch_bounds__(64) void k_flags_list(McrParams p) {
 }
 
 // soft_sync's one-thread kernels (see mcr_post / mcr_await)
-__global__ void k_post(McrParams p, int w) { if (threadIdx.x == 0) mcr_post(p, w); }
+// (debug bit 13: the side stream's completion is never posted — what a stalled stream looks like to the step's join; tests)
+__global__ void k_post(McrParams p, int w) { if (threadIdx.x == 0 && !((p.debug & 8192) && w == W_SIDE)) mcr_post(p, w); }
 __global__ void k_await(McrParams p, int w0, int w1) {
   if (threadIdx.x == 0) { if (w0 >= 0) (void)mcr_await(p, w0); if (w1 >= 0) (void)mcr_await(p, w1); }
 }

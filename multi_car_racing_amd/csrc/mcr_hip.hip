@@ -69,8 +69,8 @@ struct mcr_env {
   bool fuse_flags;            // N <= 2: the list chains do their cars' bookkeeping themselves (one launch less per chain)
   bool split_views;           // list raster launches draw one view per workgroup
   int list_view_grid;         // workgroups of a list raster launch
-  int chain_lds_pad;          // bytes of dynamic LDS the resume chain's workgroups ask for beyond what they use (see launch_step)
   bool merge_list_views = true;   // the deferred and the re-spawned envs' frames in one list launch at the tail of the resume chain
+  hipStream_t probed_stream = (hipStream_t)-1;   // the caller's stream the phase-word ordering was last checked against (mcr_step)
   bool merge_flags_viewprep = true;   // soft_sync path: the main envs' view records and bookkeeping in one launch
   bool soft_sync = false;     // the step's streams meet through phase words in device memory (mcr_kernels.h: mcr_post / mcr_await) instead of events
   bool stop_events = true;    // events completed by the launches they mark (hipExtLaunchKernelGGL) instead of marker packets behind them
@@ -132,9 +132,6 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   if (const char* g = getenv("MCR_LIST_VIEW_GRID")) { const int v = atoi(g); if (v > 0) h->list_view_grid = v; }
   h->split_views = true;
   if (const char* g = getenv("MCR_SPLIT_VIEWS")) h->split_views = atoi(g) != 0;
-  h->chain_lds_pad = 0;
-  if (const char* g = getenv("MCR_CHAIN_LDS_PAD")) h->chain_lds_pad = atoi(g);
-  if (h->chain_lds_pad > 0 && hipFuncSetAttribute((const void*)k_list_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(col::lds_bytes(cfg->num_agents) + h->chain_lds_pad)) != hipSuccess) { (void)hipGetLastError(); h->chain_lds_pad = 0; }
   if (const char* g = getenv("MCR_RESUME_ON_CALLER")) h->resume_on_caller = atoi(g) != 0;
   if (const char* g = getenv("MCR_CHAIN_GRID")) { const int v = atoi(g); if (v > 0) h->chain_grid = v; }
   h->status_host = nullptr; h->step_count = 0; h->bp_fresh = false; memset(h->status_seen, 0, sizeof(h->status_seen));
@@ -222,7 +219,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
     int prio_lo = 0, prio_hi = 0; (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     if (hipStreamCreateWithPriority(&h->s_side, hipStreamNonBlocking, prio_hi) == hipSuccess) {
       if (hipStreamCreateWithPriority(&h->s_defer, hipStreamNonBlocking, prio_hi) == hipSuccess) {
-        const unsigned evf = hipEventDisableTiming | ((getenv("MCR_EVENT_DEVICE_SCOPE") && atoi(getenv("MCR_EVENT_DEVICE_SCOPE"))) ? hipEventReleaseToDevice : 0u);
+        const unsigned evf = hipEventDisableTiming;     // (hipEventReleaseToDevice changes nothing measurable: tools/ubench/event_gap.hip)
         for (hipEvent_t* e : {&h->ev_fork, &h->ev_join, &h->ev_fork2, &h->ev_join2, &h->ev_col, &h->ev_chain}) (void)hipEventCreateWithFlags(e, evf);
         if (const char* g = getenv("MCR_STOP_EVENTS")) h->stop_events = atoi(g) != 0;
         h->soft_sync = kernels_overlap(h->s_defer, h->s_side);     // (a waiting kernel needs the kernels it waits for to run beside it)
@@ -438,7 +435,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     {
       const int ga = std::min(lg_dyn, MCR_LIST_GRID / 2), gb = P.auto_reset ? lg_col : 0;
       McrParams Pr = P; Pr.role = 4; Pr.list_envs_per_block = 1;
-      LAUNCH_LDS(7, k_list_chain, ga + gb, 64, col::lds_bytes(N) + h->chain_lds_pad, st, P, Pr, fuse_flags, ga);
+      LAUNCH_LDS(7, k_list_chain, ga + gb, 64, col::lds_bytes(N), st, P, Pr, fuse_flags, ga);
       if (flags_list) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, st, P);
       if (draw) { McrParams Pv = P; Pv.role = P.auto_reset ? 5 : 3; Pv.await_tail = 1; launch_view(h, 7, B, st, Pv, 0); }     // ... and the step's join
     }
@@ -503,7 +500,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     // envs the main dynamics re-spawned; then, in one list launch, the deferred envs' frames and the re-spawned envs' first observations
     const int ga = std::min(lg_dyn, MCR_LIST_GRID / 2), gb = P.auto_reset ? lg_col : 0;
     McrParams Pr = P; Pr.role = 4; Pr.list_envs_per_block = 1;     // one re-spawned env per workgroup: they run side by side
-    LAUNCH_LDS_STOP(7, k_list_chain, ga + gb, 64, col::lds_bytes(N) + h->chain_lds_pad, s_resume, STOP((!draw && !flags_list) ? resume_done : nullptr), P, Pr, fuse_flags, ga);
+    LAUNCH_LDS_STOP(7, k_list_chain, ga + gb, 64, col::lds_bytes(N), s_resume, STOP((!draw && !flags_list) ? resume_done : nullptr), P, Pr, fuse_flags, ga);
     if (!merged && P.auto_reset && draw) (void)hipEventRecord(h->ev_chain, s_resume);
     if (flags_list) hipExtLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, s_resume, nullptr, STOP(!draw ? resume_done : nullptr), 0, P);
     if (merged) { McrParams Pv = P; Pv.role = P.auto_reset ? 5 : 3; launch_view(h, 7, B, s_resume, Pv, 0, STOP(resume_done)); }
@@ -538,7 +535,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
 // synchronising, like the install counters — a condition raised by a step that is still running shows up in a later call.
 static int check_status(mcr_env* h) {
   static const char* what[MCR_STATUS_WORDS] = {
-      "the main dynamics gave up waiting for the contact pass (three-chain step); the handle now runs the contact pass in front",
+      "a kernel gave up waiting for the kernels of another stream (three-chain step: the contact pass of an env, a phase word); the handle now runs the contact pass in front and orders its streams with events",
       "the contact pass disagreed with the one-step-ahead touch verdict", "more touching car<->car fixture pairs than the manifold store holds",
       "more tile begin events in one env-step than the replay buffer holds", "", "", "", ""};
   for (int i = 0; i < MCR_STATUS_WORDS; ++i) {
@@ -585,6 +582,17 @@ extern "C" int mcr_step(mcr_env* h, const float* d_actions, uint8_t* d_obs, doub
   if (cc_active(h) && !h->verdict_fresh) {   // after reset() / reset_envs() / a state restore / a step without actions: which envs hold a touching car<->car pair?
     McrParams Pt = P; Pt.role = 0; Pt.part = h->P.part + (size_t)h->step_parity * P.B;
     hipLaunchKernelGGL(k_touch, dim3(P.B), dim3(64), 0, st, Pt);
+  }
+  if (h->split && h->soft_sync && st != h->probed_stream && h->use_graph <= 0) {
+    // Phase words need the caller's stream and the two internal ones on hardware queues of their own: a waiting kernel at the head of
+    // a shared queue would hold back the very kernel it waits for (HIP multiplexes streams of one priority over a few queues; the
+    // internal streams are high-priority ones, so an ordinary caller's stream never shares theirs — checked once per stream, ~1 ms).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    if (cap == hipStreamCaptureStatusNone) {
+      h->probed_stream = st;
+      if (!(kernels_overlap(h->s_side, st) && kernels_overlap(h->s_defer, st))) h->soft_sync = false;
+    }
   }
   h->verdict_fresh = vf != 0;             // this step's bookkeeping evaluates the next step's
   if (h->use_graph > 0 && !h->timing) {

@@ -49,7 +49,7 @@ class VecMultiCarRacing:
     def __init__(self, num_envs, num_agents=2, device=None, seed=0, env_offset=0, direction="CCW",
                  use_random_direction=True, backwards_flag=True, h_ratio=0.25, use_ego_color=False,
                  obs=True, auto_reset=True, max_episode_steps=1000, car_contacts=True,
-                 gen_threads=None, async_refill=True, streams=None, refill_lag=8, world_size=1, graph=None,
+                 gen_threads=None, async_refill=True, streams=None, refill_lag=64, world_size=1, graph=None,
                  skid_particles=False):
         if not torch.cuda.is_available():
             raise _lib.McrError("VecMultiCarRacing needs a HIP device: the step path has no CPU fallback")
@@ -70,7 +70,10 @@ class VecMultiCarRacing:
         # A re-spawned env consumes its staged episode; the refill thread generates + stages the next one.  An env could
         # only FREEZE (k_dynamics: inactive, zero outputs until the episode arrives) if it finished a whole episode before
         # that refill landed, so step() waits for any refill batch queued more than `refill_lag` steps ago — fewer steps
-        # than any episode can last — and the freeze path stays a safety net (debug_counters()[3] counts its env-steps).
+        # than any episode can last (a car needs a few hundred steps to leave the playfield from the track; a TimeLimit
+        # shorter than the lag shortens it) — and the freeze path stays a safety net (debug_counters()[3] counts its
+        # env-steps).  (8 steps until round 3: at 0.28 ms per step that is 2 ms for generate + stage + a blocking event
+        # on a 2-core host share, and step() sat in wait_refills() 80 % of the time with the cores 2/3 busy.)
         self.refill_lag = max(1, min(int(refill_lag), int(max_episode_steps) - 1)) if int(max_episode_steps) > 0 else max(1, int(refill_lag))
         self._step_idx = 0
         self.blocked_s = 0.0          # wall time step() spent waiting for the refill thread (host behind the device)

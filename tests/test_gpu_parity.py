@@ -688,3 +688,35 @@ def test_step_graph_replay_is_bit_identical(torch_cuda):
     for key in s1:
         assert np.array_equal(s1[key], s2[key]), key
     a1.close(); a2.close()
+
+
+def test_status_word_reports_a_stalled_stream(torch_cuda, lib):
+    """The streams of the three-chain step meet through phase words that kernels post and await.  A stream that never
+    posts (debug bit 13 withholds the side stream's "done") must not hang the step or pass unnoticed: the join's wait is bounded,
+    the give-up is reported by the next mcr_step, and the handle orders its streams with events from then on."""
+    torch = torch_cuda
+    env = _make(128, 2, 6, contacts=True, streams=2)
+    if not (env.L.mcr_step_ordering(env.h) & 1):
+        env.close(); pytest.skip("kernels of different streams do not overlap here: the step already uses events")
+    env.reset()
+    a = torch.zeros((128, 2, 3), device="cuda"); a[..., 1] = 0.5
+    for _ in range(3):
+        env.step(a)
+    torch.cuda.synchronize()
+    assert env.L.mcr_step_ordering(env.h) & 1                # (the per-stream check of the first step passed)
+    lib.check(env.L.mcr_debug_set(env.h, 4096 | 8192))     # short spin bound; the side stream's completion is never posted
+    env.step(a); torch.cuda.synchronize()
+    with pytest.raises(lib.McrError, match="gave up waiting"):
+        env.step(a)
+    lib.check(env.L.mcr_debug_set(env.h, 0))
+    assert not (env.L.mcr_step_ordering(env.h) & 1)
+    st = np.zeros(8, np.uint32)
+    lib.check(env.L.mcr_status(env.h, lib.ptr(st), 8))
+    assert st[0] >= 1
+    for _ in range(5):                                      # the handle keeps working on the event path
+        env.step(a)
+    torch.cuda.synchronize()
+    seen = st.copy()
+    lib.check(env.L.mcr_status(env.h, lib.ptr(st), 8))
+    assert np.array_equal(st, seen), "further give-ups after the fallback"
+    env.close()

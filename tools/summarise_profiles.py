@@ -34,8 +34,10 @@ CALLER = {"k_collide": ["collide (all envs)"], "k_dynamics": ["dynamics (main en
           "k_flags_list": ["bookkeeping (deferred envs)"], "k_view": ["view (deferred + re-spawned envs, caller's stream; waits for the join)"], "k_await": ["join (caller's stream, steps without frames)"]}
 SIDE = {"k_collide": ["collide (all envs)"], "k_list_chain": ["chain (contact envs, side stream)"], "k_flags_list": ["bookkeeping (contact envs)"],
         "k_reset_list": ["reset pass (re-spawned envs, side stream)"], "k_view": ["view (contact envs, side stream)", "view (re-spawned envs, side stream)"],
-        "k_await": ["await: step begun (side stream; spins from the end of its last step)"], "k_post": ["post: side stream done"]}
-THIRD = {"k_viewprep": ["view records + car polygons (main envs, third stream)"], "k_flags": ["bookkeeping (main envs, third stream)"], "k_view": ["view (main envs)"]}
+        "k_await": ["await: step begun (side stream; spins from the end of its last step)"] * 2, "k_post": ["post: side stream done"]}
+AWAIT3 = "await: dynamics + contact pass done (third stream; spins through the dynamics)"
+THIRD = {"k_viewprep": ["view records + car polygons (main envs, third stream)"], "k_flags": ["bookkeeping (main envs, third stream)"], "k_view": ["view (main envs)"],
+         "k_flags_viewprep": ["view records + bookkeeping (main envs, third stream)"], "k_await": [AWAIT3, AWAIT3], "k_post": ["post: third stream done"]}
 STEP_KERNELS = ("k_collide", "k_dynamics", "k_flags_viewprep", "k_viewprep", "k_view", "k_post", "k_await", "k_flags", "k_flags_list", "k_list_chain", "k_reset_list")
 
 def label(df, order_col):
@@ -79,8 +81,8 @@ def label(df, order_col):
 
 st = pd.read_csv(f"{src}/stats/s_kernel_stats.csv")
 st["Kernel"] = st["Name"].map(kname)
-lines.append("## `--kernel-trace --stats` (kernel_stats.csv, whole process incl. pre-roll; every launch of a kernel pooled)\n")
-lines.append(st[["Kernel", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"]].head(9).to_markdown(index=False) + "\n")
+lines.append("## `--kernel-trace --stats` (kernel_stats.csv, whole process incl. pre-roll; every launch of a kernel pooled; k_await = the one-wavefront kernels that WAIT for another stream's phase word — their duration is waiting time, not work)\n")
+lines.append(st[["Kernel", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"]].head(11).to_markdown(index=False) + "\n")
 kt = label(pd.read_csv(f"{src}/stats/s_kernel_trace.csv"), "Start_Timestamp")
 kt["us"] = (kt["End_Timestamp"] - kt["Start_Timestamp"]) / 1e3
 g = kt[kt.Label.notna()].groupby("Label").us.agg(["count", "mean", "median", "min", "max"]).round(1)
@@ -115,7 +117,7 @@ sq = sq[sq.Label.notna()]
 # counter is a SAMPLE of the launches: mean per sampled launch x launches of that kernel per step)
 per_launch = sq.pivot_table(index="K", columns="Counter_Name", values="Counter_Value", aggfunc="mean")
 launches_per_step = kt[kt.Label.notna()].groupby("K").size() / STEPS
-tot = per_launch.mul(launches_per_step, axis=0)
+tot = per_launch.mul(launches_per_step, axis=0).dropna(how="all")
 lines.append("\n## SQ counters per step, all launches of a kernel pooled (mean over the timed region)\n")
 lines.append(tot.round(0).to_markdown() + "\n")
 if "k_view" in tot.index:
