@@ -218,6 +218,8 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
     // masked stream costs ~10 us more: 0.81 ms per step.)
     int prio_lo = 0, prio_hi = 0; (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     if (hipStreamCreateWithPriority(&h->s_side, hipStreamNonBlocking, prio_hi) == hipSuccess) {
+      // (the priority of the third stream — it carries the main raster, whose backlog of workgroups competes with the list raster at the
+      // tail of the caller's stream for every LDS slot that frees up — makes no difference: high / normal / low 14.73 / 14.72 / 14.72 M)
       if (hipStreamCreateWithPriority(&h->s_defer, hipStreamNonBlocking, prio_hi) == hipSuccess) {
         const unsigned evf = hipEventDisableTiming;     // (hipEventReleaseToDevice changes nothing measurable: tools/ubench/event_gap.hip)
         for (hipEvent_t* e : {&h->ev_fork, &h->ev_join, &h->ev_fork2, &h->ev_join2, &h->ev_col, &h->ev_chain}) (void)hipEventCreateWithFlags(e, evf);
