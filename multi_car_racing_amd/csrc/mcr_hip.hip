@@ -72,6 +72,7 @@ struct mcr_env {
   bool merge_list_views = true;   // the deferred and the re-spawned envs' frames in one list launch at the tail of the resume chain
   hipStream_t probed_stream = (hipStream_t)-1;   // the caller's stream the phase-word ordering was last checked against (mcr_step)
   bool merge_flags_viewprep = true;   // soft_sync path: the main envs' view records and bookkeeping in one launch
+  bool soft_token = false;    // this handle is its device's one phase-word handle (mcr_create)
   bool soft_sync = false;     // the step's streams meet through phase words in device memory (mcr_kernels.h: mcr_post / mcr_await) instead of events
   bool stop_events = true;    // events completed by the launches they mark (hipExtLaunchKernelGGL) instead of marker packets behind them
   bool resume_on_caller;      // three-chain step: the resume chain keeps the caller's stream, bookkeeping + main raster hop to the third stream
@@ -86,6 +87,9 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // the machine beside it (one such wavefront per SIMD leaves half the register file and nearly all LDS free; two on every SIMD
 // could starve a contact pass dispatched second).  After a reported give-up the handle stays with the contact pass in front.
 static bool cc_active(const mcr_env* h) { return h->split && h->concurrent_collide; }
+
+#include <atomic>
+static std::atomic<int> g_soft_handles[64];     // live handles per device that order their streams with phase words (at most one: mcr_create)
 
 // Do kernels of two streams really run side by side in this process?  Under a counter-collecting profiler, a debugger or
 // AMD_SERIALIZE_KERNEL they do not — and the cc_mode step (the main dynamics waits inside the kernel for words the
@@ -227,6 +231,12 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
         h->soft_sync = kernels_overlap(h->s_defer, h->s_side);     // (a waiting kernel needs the kernels it waits for to run beside it)
         if (const char* g = getenv("MCR_MERGE_FLAGS_VIEWPREP")) h->merge_flags_viewprep = atoi(g) != 0;
         if (const char* g = getenv("MCR_SOFT_SYNC")) h->soft_sync = h->soft_sync && atoi(g) != 0;
+        // One handle per device and process at a time: the side stream's wait for "begin" is enqueued BEFORE the kernel that posts it.
+        // With the streams of two handles multiplexed over the same hardware queues and their steps interleaved on one caller's stream,
+        // handle A's waiting kernel can sit in front of the post handle B's join waits for, which in turn sits in front of A's dynamics:
+        // a cycle that only the wait bound would break.  Further handles order their streams with events (every wait there is for work
+        // enqueued earlier).
+        if (h->soft_sync) { if (g_soft_handles[cfg->device & 63].fetch_add(1) == 0) h->soft_token = true; else { g_soft_handles[cfg->device & 63].fetch_sub(1); h->soft_sync = false; } }
         if (const char* g = getenv("MCR_MERGE_LIST_VIEWS")) h->merge_list_views = atoi(g) != 0;
         // (beyond 4 cars per env the one-step-ahead touch verdict — a second pass over up to 28 car pairs — costs more than the
         // contact pass gains by running beside the dynamics: measured at N = 8, round 2: 3.66 vs 4.28 M env-steps/s.  Round 3 tried a
@@ -247,6 +257,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
 
 extern "C" int mcr_destroy(mcr_env* h) {
   if (!h) return MCR_ERR_ARG;
+  if (h->soft_token) g_soft_handles[h->cfg.device & 63].fetch_sub(1);
   (void)hipSetDevice(h->cfg.device);
   (void)hipDeviceSynchronize();
   for (auto& g : h->sg) if (g.valid) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); g.valid = false; }

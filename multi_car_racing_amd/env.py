@@ -15,6 +15,7 @@ from . import _lib, seeding
 
 STATE_W = STATE_H = 96
 VIDEO_W, VIDEO_H = 600, 400          # multi_car_racing.py:45-46
+WINDOW_W, WINDOW_H = 1000, 800       # multi_car_racing.py:47-48
 FPS = 50
 
 
@@ -163,8 +164,15 @@ class MultiCarRacing:
             st = self._torch.cuda.current_stream(self._dev)
             _lib.check(self.L.mcr_render(self._h, 0, VIDEO_W, VIDEO_H, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(st.cuda_stream)), "mcr_render")
             return out.cpu().numpy()
-        raise NotImplementedError("mode='human' opens one window per agent in the reference; there is no display path here — "
-                                  "use 'rgb_array' (600x400 frames) or 'state_pixels'")
+        # 'human' (:577-583, 595-597): the reference draws the WINDOW_W x WINDOW_H viewport into one window per agent, flips it and
+        # returns the windows' `isopen` flags.  There is no display here: the same frames are drawn off-screen and kept in
+        # `self.human_frames` (uint8 [N, WINDOW_H, WINDOW_W, 3], device) for whoever wants to show them; every "window" is open.
+        if not self._was_reset:
+            return np.array([None] * self.num_agents, dtype=object)
+        self.human_frames = self._torch.empty((self.num_agents, WINDOW_H, WINDOW_W, 3), dtype=self._torch.uint8, device=self._dev)
+        st = self._torch.cuda.current_stream(self._dev)
+        _lib.check(self.L.mcr_render(self._h, 0, WINDOW_W, WINDOW_H, ctypes.c_void_p(self.human_frames.data_ptr()), ctypes.c_void_p(st.cuda_stream)), "mcr_render")
+        return np.ones(self.num_agents, dtype=bool)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -187,7 +187,9 @@ def test_every_stream_ordering_of_the_step_matches_the_oracle(torch_cuda, oracle
     one list launch or two: every variant is the same computation — rear-end collisions, TimeLimit resets and refills included."""
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
+    import gc
     from multi_car_racing_amd.vec_env import VecMultiCarRacing
+    gc.collect()                                             # (one phase-word handle per device at a time: no stale ones from earlier tests)
     probe = VecMultiCarRacing(64, 2, seed=1, auto_reset=True, car_contacts=True, streams=2)
     mode, overlap = probe.L.mcr_step_ordering(probe.h), probe.L.mcr_concurrent_collide(probe.h)
     probe.close()

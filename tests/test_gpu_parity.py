@@ -450,6 +450,12 @@ def test_facade_matches_reference_surface(torch_cuda, oracle):
     frame = env.render("rgb_array")                                # (N, VIDEO_H, VIDEO_W, 3) like :518 stacks them
     want, amb = o.render_size(600, 400)
     assert frame.shape == (2, 400, 600, 3) and frame.dtype == np.uint8 and ((frame != want).any(-1) & (amb == 0)).sum() == 0
+    # 'human' (:577-583, 595-597): the 1000x800 window contents, drawn off-screen here; the call returns the windows' isopen flags
+    isopen = env.render("human")
+    assert isopen.shape == (2,) and isopen.dtype == bool and isopen.all()
+    want, amb = o.render_size(1000, 800)
+    got = env.human_frames.cpu().numpy()
+    assert got.shape == (2, 800, 1000, 3) and ((got != want).any(-1) & (amb == 0)).sum() == 0
     env.close()
     e2 = M.MultiCarRacing(num_agents=1, verbose=0)
     with pytest.raises(AttributeError):
@@ -720,3 +726,28 @@ def test_status_word_reports_a_stalled_stream(torch_cuda, lib):
     lib.check(env.L.mcr_status(env.h, lib.ptr(st), 8))
     assert np.array_equal(st, seen), "further give-ups after the fallback"
     env.close()
+
+
+def test_second_handle_on_a_device_orders_its_streams_with_events(torch_cuda, lib):
+    """One phase-word handle per device and process (mcr_hip.hip: a waiting kernel of one handle could otherwise sit in front of a
+    kernel another handle's step waits for); two handles stepped alternately on one stream compute the same thing."""
+    import gc
+    torch = torch_cuda
+    gc.collect()
+    a_env = _make(256, 2, 9, contacts=True, streams=2)
+    b_env = _make(256, 2, 9, contacts=True, streams=2)
+    if a_env.L.mcr_concurrent_collide(a_env.h):
+        assert a_env.L.mcr_step_ordering(a_env.h) & 1 and not (b_env.L.mcr_step_ordering(b_env.h) & 1)
+    oa, ob = a_env.reset().clone(), b_env.reset().clone()
+    assert torch.equal(oa, ob)
+    g = torch.Generator(device="cuda"); g.manual_seed(4)
+    for k in range(60):
+        a = torch.rand((256, 2, 3), device="cuda", generator=g); a[..., 0] = a[..., 0] * 2 - 1
+        o1, r1, d1, _ = a_env.step(a)
+        o2, r2, d2, _ = b_env.step(a)
+        assert torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(o1, o2), k
+    a_env.close()
+    c_env = _make(64, 2, 9, contacts=True, streams=2)        # the token is free again
+    if c_env.L.mcr_concurrent_collide(c_env.h):
+        assert c_env.L.mcr_step_ordering(c_env.h) & 1
+    c_env.close(); b_env.close()
