@@ -91,7 +91,7 @@ __device__ __forceinline__ int mcr_epoch(const McrParams& p) { return p.epoch_pt
 // one-thread kernel behind the kernels of the phase, in their stream, or by the first thread of the kernel that follows them in
 // their stream: both run after the end-of-kernel release of everything before them.  It is AWAITED by a one-wavefront kernel in
 // front of the dependent kernels, in their stream (the kernels behind it start with the usual acquire), or — k_list_chain — by a
-// kernel's prologue (poll, then one agent-scope acquire).  Waits are bounded and a give-up is reported like the contact
+// kernel's prologue (poll, then one agent-scope acquire).  Waits are bounded (about a minute) and a give-up is reported like the contact
 // pass's (ST_SPIN_GIVEUP: mcr_step fails, the handle goes back to events).
 enum { W_BEGIN = 0,    // the caller's stream reached this step's main dynamics (everything it held before is complete)
        W_COL = 1,      // the contact pass (k_collide pass 0, side stream) is complete
@@ -104,11 +104,16 @@ __device__ __forceinline__ void mcr_post(const McrParams& p, int w) {
 }
 // one lane polls; the caller adds the acquire if it reads the phase's data in the same kernel.  (epochs only grow: ">= 0" also
 // lets a waiter through that is late by a step, which cannot happen while every step awaits the one before)
+// The bound: 2^15 polls 0.2 us apart, then 2^24 more 3.4 us apart — about a minute.  The wait for *begin* is the one that depends on
+// the caller: whatever the caller's stream still holds in front of the step (a long inference kernel, an event wait) is waited out
+// here, and that must not be mistaken for a stalled stream.  debug bit 12 shortens it to a few milliseconds (tests).
 __device__ __forceinline__ bool mcr_await(const McrParams& p, int w) {
-  const int epoch = mcr_epoch(p), bound = (p.debug & 4096) ? (1 << 14) : (1 << 24);
+  const int epoch = mcr_epoch(p), fast = (p.debug & 4096) ? (1 << 14) : (1 << 15), slow = (p.debug & 4096) ? 0 : (1 << 24);
   int spin = 0;
-  for (; spin < bound && (int)(__hip_atomic_load(&p.sync_words[w * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0; ++spin) __builtin_amdgcn_s_sleep(8);
-  if (spin == bound) { atomicAdd(&p.counters[5], 1ull); atomicAdd(&p.status[ST_SPIN_GIVEUP], 1u); return false; }
+  for (; spin < fast && (int)(__hip_atomic_load(&p.sync_words[w * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0; ++spin) __builtin_amdgcn_s_sleep(8);
+  if (spin < fast) return true;
+  for (spin = 0; spin < slow && (int)(__hip_atomic_load(&p.sync_words[w * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0; ++spin) __builtin_amdgcn_s_sleep(127);
+  if (spin == slow) { atomicAdd(&p.counters[5], 1ull); atomicAdd(&p.status[ST_SPIN_GIVEUP], 1u); return false; }
   return true;
 }
 #define MCR_VORDER_ENV_MASK 0xfffff

@@ -751,3 +751,41 @@ def test_second_handle_on_a_device_orders_its_streams_with_events(torch_cuda, li
     if c_env.L.mcr_concurrent_collide(c_env.h):
         assert c_env.L.mcr_step_ordering(c_env.h) & 1
     c_env.close(); b_env.close()
+
+
+def test_a_busy_caller_stream_is_waited_out_not_reported(torch_cuda, lib):
+    """The side stream's wait for the step's begin also waits out whatever the caller's stream holds in front of the step.  Several
+    seconds of the caller's own kernels there (longer than the contact pass's 3 s bound) are not a stalled stream: no give-up, no
+    error, same results as a handle that was not kept waiting."""
+    import time
+    torch = torch_cuda
+    env = _make(128, 2, 12, contacts=True, streams=2)
+    ref = _make(128, 2, 12, contacts=True, streams=1)
+    if not (env.L.mcr_step_ordering(env.h) & 1):
+        env.close(); ref.close(); pytest.skip("the step uses events here")
+    env.reset(); ref.reset()
+    a = torch.zeros((128, 2, 3), device="cuda"); a[..., 1] = 0.4; a[:, 1, 0] = 0.3
+    for _ in range(3):
+        env.step(a); ref.step(a)
+    torch.cuda.synchronize()
+    x = torch.randn((6144, 6144), dtype=torch.float64, device="cuda")
+    y = x @ x; torch.cuda.synchronize()                      # (library start-up)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        y = x @ x
+    torch.cuda.synchronize(); one = (time.perf_counter() - t0) / 5
+    n = max(1, min(4000, int(5.0 / max(one, 1e-4))))           # ~5 s of f64 GEMMs in front of the step, on the caller's stream
+    t0 = time.perf_counter()
+    for _ in range(n):
+        y = x @ x
+    _, r1, d1, _ = env.step(a)
+    torch.cuda.synchronize()
+    held = time.perf_counter() - t0
+    _, r2, d2, _ = ref.step(a)
+    assert torch.equal(r1, r2) and torch.equal(d1, d2)
+    st = np.zeros(8, np.uint32)
+    lib.check(env.L.mcr_status(env.h, lib.ptr(st), 8))
+    assert st[0] == 0, f"a wait gave up after the caller's stream was busy for {held:.1f} s"
+    assert held > 3.6, f"the caller's stream was only busy for {held:.1f} s: the test did not exercise the long wait"
+    env.step(a); torch.cuda.synchronize()                    # no error pending
+    env.close(); ref.close()
