@@ -13,6 +13,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -111,7 +112,7 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0, help="W > 1: ONE GPU, but the host side of a W-rank job on this node: the process is pinned to 1/W of the "
                     "cores the cgroup allows and its track generator takes the threads VecMultiCarRacing gives a rank of a W-rank job; reports "
                     "env-steps/s, the time step() was blocked on the refill thread and the env-steps frozen waiting for the host")
-    ap.add_argument("--graph", type=int, default=0, help="1: mcr_step replays a hipGraph of the step (bypassed while kernels are timed; measured gain 0.4 %); 0 (default): plain launches")
+    ap.add_argument("--graph", type=int, default=0, help="1: mcr_step replays a hipGraph of the step (bypassed while kernels are timed; measured gain 0.4 %%); 0 (default): plain launches")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -121,10 +122,30 @@ def main():
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks\n")
         sys.exit(2)
 
+    emu_share = None
+    if args.emulate_world > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        # the host share of ONE rank of a W-rank job on this node: the ranks split the cores the cgroup allows (vec_env.py).  Pinned
+        # BEFORE the HIP runtime starts, so that its own threads (signal handling) live on the share as well, like everything the rank runs.
+        from multi_car_racing_amd._lib import effective_cpus      # (no HIP call in there: min(affinity, cgroup CPU quota))
+        allowed = sorted(os.sched_getaffinity(0)); total = effective_cpus()
+        emu_share = (total, max(1, total // args.emulate_world))
+        os.sched_setaffinity(0, set(allowed[:emu_share[1]]))
     import numpy as np
     import torch
     import torch.distributed as dist
     from multi_car_racing_amd.sharded import ShardedVecEnv, reduce_metrics
+
+    def thread_cpu():
+        """CPU seconds (user + system) of every thread of this process by name: who on the host side is busy"""
+        out, tck = {}, os.sysconf("SC_CLK_TCK")
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                name = open(f"/proc/self/task/{tid}/comm").read().strip()
+                f = open(f"/proc/self/task/{tid}/stat").read().rsplit(")", 1)[1].split()
+                out[(tid, name)] = (int(f[11]) + int(f[12])) / tck
+            except OSError:
+                pass
+        return out
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -142,10 +163,7 @@ def main():
     extra = {}
     if args.emulate_world > 1 and world == 1:
         # the host share of ONE rank of a W-rank job on this node: the ranks split the cores the cgroup allows (vec_env.py)
-        from multi_car_racing_amd._lib import effective_cpus
-        allowed = sorted(os.sched_getaffinity(0)); total = effective_cpus()
-        share = max(1, total // args.emulate_world)
-        os.sched_setaffinity(0, set(allowed[:share]))             # threads created from here on inherit it (generator pool, refill worker)
+        total, share = emu_share
         extra["gen_threads"] = max(1, total // args.emulate_world)     # what VecMultiCarRacing gives a rank of a W-rank job
         emu = {"world": args.emulate_world, "cores_allowed_to_the_job": total, "cores_this_rank": share, "gen_threads": extra["gen_threads"]}
     env = ShardedVecEnv(B * world, N, seed=0, rank=rank, world_size=world, device=dev, obs=bool(args.obs),
@@ -205,6 +223,7 @@ def main():
     tmask = 0 if args.no_kernel_timing else (255 if args.time_all_kernels else 4)
     FENCE = LOOKAHEAD // 4
     evs = [torch.cuda.Event(blocking=True) for _ in range(4)]       # the host sleeps at the look-ahead fence instead of spinning on a core the refill thread needs
+    thr0 = thread_cpu()
     cpu0 = time.process_time()                       # CPU seconds of every thread of this process (step loop, refill thread, track generators)
     t0 = time.perf_counter()
     for k in range(K):
@@ -214,7 +233,8 @@ def main():
         if k % FENCE == FENCE - 1:
             j = (k // FENCE) % 4
             if k >= LOOKAHEAD:
-                evs[j].synchronize()
+                while not evs[j].query():           # (hipEventSynchronize spins on this runtime even for a blocking event: 0.8 of a core
+                    time.sleep(1e-4)                #  that the track generator needs when a rank has two of them — query + sleep: 0.02)
             evs[j].record()
     torch.cuda.synchronize()
     env.wait_refills()
@@ -223,6 +243,11 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     host_cores = (time.process_time() - cpu0) / elapsed
+    thr1 = thread_cpu()
+    me = str(threading.get_native_id())
+    busy = sorted(((v - thr0.get(key, 0.0)) / elapsed, key) for key, v in thr1.items())[::-1][:6]
+    # (threads that have exited by now — the track generator's, started per batch — are in host_cores_busy but not listed here)
+    host_threads = [{"thread": ("step loop" if key[0] == me else key[1]) + ":" + key[0], "cores": round(v, 2)} for v, key in busy if v >= 0.01]
     ms, nl = env.timing_read()
     env.timing(0)
     env.wait_refills()
@@ -275,6 +300,7 @@ def main():
             "roofline": roofline,
         }
         out["config"]["step_blocked_on_refill_s_rank0"] = env.env.blocked_s - blocked0
+        out["config"]["host_threads_busy_rank0"] = host_threads               # by thread name (python = the step loop and the refill thread)
         out["config"]["host_cores_busy_rank0"] = round(host_cores, 2)      # CPU time / wall time of the timed region: what one rank asks of the host
         out["config"]["stream_ordering"] = {1: "phase words", 3: "phase words", 2: "events (stop events)", 0: "events"}.get(int(env.env.L.mcr_step_ordering(env.env.h)), "?") if args.streams != 1 else "single stream"
         if emu:

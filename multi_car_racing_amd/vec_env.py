@@ -157,13 +157,19 @@ class VecMultiCarRacing:
     def _refill(self, ids):
         rows = self._generate(ids)
         self._stage(ids, rows, self._copy_stream)
-        # the bounce buffer may be overwritten as soon as the copies are done.  A BLOCKING event: hipStreamSynchronize spins, and a
-        # refill thread that spins takes a core from the track generator — with the ranks of a node sharing few cores
+        # the bounce buffer may be overwritten as soon as the copies are done.  Polled with a sleep in between: hipStreamSynchronize
+        # spins, and so does hipEventSynchronize on a "blocking" event (measured: 0.8 of a core in bench.py's look-ahead fence); a
+        # thread that spins takes a core from the track generator — with the ranks of a node sharing few cores
         # (bench.py --emulate-world) that is what the host side runs out of first
         self._copy_done.record(self._copy_stream)
-        self._copy_done.synchronize()
+        while not self._copy_done.query():          # (not .synchronize(): see above — it spins on this runtime, blocking event or not)
+            time.sleep(5e-5)
 
     def _worker_main(self):
+        try:                                                   # name the thread for top / bench.py's per-thread CPU report (PR_SET_NAME)
+            ctypes.CDLL(None).prctl(15, b"mcr-refill", 0, 0, 0)
+        except Exception:
+            pass
         torch.cuda.set_device(self.device)
         while True:
             ids = self._q.get()
