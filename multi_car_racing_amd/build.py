@@ -5,14 +5,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "_lib", "libmcr_hip.so")
 # translation units and their extra flags (mcr_view.hip explains why the raster is built without the SLP vectoriser)
-SOURCES = [("mcr_hip.hip", []), ("mcr_view.hip", ["-fno-slp-vectorize"]), ("mcr_host.cpp", [])]
+# mcr_hip.hip: the SLP vectoriser's packed f32 forms pay in k_dynamics' velocity sweeps (without it: 135 instead of 118 us), but with the
+# default profitability threshold a seventh of the loop is register shuffling for their operands; sweep on the GPU (dynamics / step):
+# threshold 0: 118.2 us / 14.70 M, 4: 114.6 / 14.91, 5: 112.6 / 15.03, 8: 115.7 / 14.95, 12: 114.1 / 15.04, 16: 122.2 / 14.73, off: 135.3 / 14.15
+SOURCES = [("mcr_hip.hip", ["-mllvm", "-slp-threshold=5"]), ("mcr_view.hip", ["-fno-slp-vectorize"]), ("mcr_host.cpp", [])]
 
 
 def deps():
     """every file the library is built from: all of csrc/ plus the public header"""
     import glob
     out = [f for pat in ("*.h", "*.hip", "*.cpp", "*.inc") for f in glob.glob(os.path.join(CSRC, pat))]
-    return out + [os.path.join(HERE, "..", "include", "mcr.h")]
+    return out + [os.path.join(HERE, "..", "include", "mcr.h"), os.path.abspath(__file__)]      # (this file: the per-file flags)
 
 # -ffp-contract=off: host (x86-64) and gfx950 must round identically (DESIGN.md, numerics)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value"]
