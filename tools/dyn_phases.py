@@ -4,12 +4,14 @@ import sys, os, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multi_car_racing_amd.vec_env import VecMultiCarRacing
 from multi_car_racing_amd import _lib
-B, N = 4096, 2
+B, N = 4096, int(os.environ.get("N", "2"))
 env = VecMultiCarRacing(B, N, seed=0, auto_reset=True, streams=2)
 env.reset()
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 pool = torch.rand((64, B, N, 3), device="cuda", generator=g); pool[..., 0] = pool[..., 0] * 2 - 1
-nb = (B * 2 + 63) // 64
+G = 1
+while G < N: G *= 2
+nb = (B * G + 63) // 64
 ns = (B + 1) // 2                      # side stream: 2 envs per wavefront
 buf = np.zeros((nb + 2 * ns) * 8, np.uint64)
 _lib.check(env.L.mcr_debug_set(env.h, 256))
