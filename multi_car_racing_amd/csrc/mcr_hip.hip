@@ -72,6 +72,7 @@ struct mcr_env {
   bool merge_list_views = true;   // the deferred and the re-spawned envs' frames in one list launch at the tail of the resume chain
   hipStream_t probed_stream = (hipStream_t)-1;   // the caller's stream the phase-word ordering was last checked against (mcr_step)
   bool merge_flags_viewprep = true;   // soft_sync path: the main envs' view records and bookkeeping in one launch
+  int defer_after = MCR_DEFER_AFTER;   // position sweeps the main dynamics grants an env before it defers it (MCR_DEFER_AFTER in the environment: measurements)
   bool soft_token = false;    // this handle is its device's one phase-word handle (mcr_create)
   bool soft_sync = false;     // the step's streams meet through phase words in device memory (mcr_kernels.h: mcr_post / mcr_await) instead of events
   bool stop_events = true;    // events completed by the launches they mark (hipExtLaunchKernelGGL) instead of marker packets behind them
@@ -227,6 +228,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
       if (hipStreamCreateWithPriority(&h->s_defer, hipStreamNonBlocking, prio_hi) == hipSuccess) {
         const unsigned evf = hipEventDisableTiming;     // (hipEventReleaseToDevice changes nothing measurable: tools/ubench/event_gap.hip)
         for (hipEvent_t* e : {&h->ev_fork, &h->ev_join, &h->ev_fork2, &h->ev_join2, &h->ev_col, &h->ev_chain}) (void)hipEventCreateWithFlags(e, evf);
+        if (const char* g = getenv("MCR_DEFER_AFTER")) { const int v = atoi(g); if (v >= 1 && v < 60) h->defer_after = v; }
         if (const char* g = getenv("MCR_STOP_EVENTS")) h->stop_events = atoi(g) != 0;
         h->soft_sync = kernels_overlap(h->s_defer, h->s_side);     // (a waiting kernel needs the kernels it waits for to run beside it)
         if (const char* g = getenv("MCR_MERGE_FLAGS_VIEWPREP")) h->merge_flags_viewprep = atoi(g) != 0;
@@ -353,11 +355,11 @@ static void launch_reset(mcr_env* h, McrParams P, hipStream_t st) {
 // step(): collide -> dynamics [-> auto-reset pass] -> view on the caller's stream `st`.
 // With num_streams == 2 the step forks into three chains that meet again at the end (grids are sized for the worst
 // case, surplus workgroups exit on their first load):
-//   st      : collide(all) -+-> dynamics(main envs, 2 position sweeps) -+-> reset pass -> view(main envs) -+-> flags
+//   st      : collide(all) -+-> dynamics(main envs, 3 position sweeps) -+-> reset pass -> view(main envs) -+-> flags
 //   s_side  :               +-> dynamics(contact envs) -> their reset pass -> view(contact envs) ---------+
 //   s_defer :                                                          +-> dynamics(resume deferred envs) -> their reset pass -> view(them) --+
 // Contact envs: a wavefront holding a touching car<->car pair takes 2-4x as long as the others.  Deferred envs: the
-// few whose position loop is still iterating after 2 sweeps (a slow marginal crawl that would hold the whole main
+// few whose position loop is still iterating after 3 sweeps (a slow marginal crawl that would hold the whole main
 // launch for up to 60).  s_defer's dynamics starts while the GPU is nearly idle (the reset pass), so it finds free
 // SIMDs at once.  An env of either list that ended its episode in this step (rare) takes its reset pass inside its own
 // chain (two launches that exit at once in every other step; round 1 ran them as a "late" pass on the caller's stream).
@@ -397,14 +399,14 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     return;
   }
   // Three chains that meet again at the end (k_list_chain.h: a list chain is one fused launch + its raster):
-  //   st      : -+-> dynamics(main envs, 2 position sweeps) ---------+-> bookkeeping(main envs) -> raster(main envs) ------+
+  //   st      : -+-> dynamics(main envs, 3 position sweeps) ---------+-> bookkeeping(main envs) -> raster(main envs) ------+
   //   s_side  :  +-> collide(all) -> chain(contact envs) -> raster --+-> reset pass(re-spawned envs) -> their raster ------+
   //   s_defer :                                                      +-> chain(resume the deferred envs) -> their raster --+
   // Contact envs: a wavefront holding a touching car<->car pair takes 2-4x as long as the others.  Deferred envs: the
-  // few whose position loop is still iterating after 2 sweeps (a slow marginal crawl that would hold the whole main
+  // few whose position loop is still iterating after 3 sweeps (a slow marginal crawl that would hold the whole main
   // launch for up to 60).  Re-spawned envs (auto-reset, ~B/1000 per step): their reset pass would hold the raster of
   // everybody else (they are not in the main raster's list, see k_dynamics).
-  P.defer_after = MCR_DEFER_AFTER; P.respawn_list = P.auto_reset ? 1 : 0; P.list_envs_per_block = MCR_SIDE_ENVS_PER_WAVE;
+  P.defer_after = h->defer_after; P.respawn_list = P.auto_reset ? 1 : 0; P.list_envs_per_block = MCR_SIDE_ENVS_PER_WAVE;
   // The contact pass runs on the side stream BESIDE the main dynamics (cc_mode, mcr_kernels.h): nothing the solver needs
   // comes from it (Car.step reads the wheels' tile bits of the PREVIOUS pass; which envs are the contact chain's follows
   // from the entry poses), only the step's bookkeeping at the end of the dynamics kernel does, and that waits for

@@ -153,7 +153,7 @@ __device__ __forceinline__ int mcr_env_of_slot(const McrParams& p, int s, bool m
 // holds car<->car contacts): MCR_SIDE_ENVS_PER_WAVE envs per wavefront, so that the wavefront's LDS pool of contact
 // constraints (DYN_VC_POOL = MCR_SIDE_ENVS_PER_WAVE * MCR_CC_MAX) can never overflow, however the envs are packed.
 #define MCR_SIDE_ENVS_PER_WAVE 2
-#define MCR_DEFER_AFTER 2          // position sweeps the main dynamics launch grants an env before deferring it (99.86 % need 1)
+#define MCR_DEFER_AFTER 3          // position sweeps the main dynamics launch grants an env before deferring it (99.86 % need 1; 1 / 2 / 3 / 4 / 6 sweeps: 14.99 / 15.01 / 15.10 / 15.10 / 15.09 M env-steps/s)
 __device__ __forceinline__ int mcr_dyn_slot(const McrParams& p, int blk) {
   const int grp = (int)threadIdx.x / p.G;
   if (p.role >= 2) return grp < p.list_envs_per_block ? blk * p.list_envs_per_block + grp : -1;
