@@ -66,6 +66,7 @@ struct mcr_env {
   int simd_count;             // SIMDs of the device (4 per CU)
   int32_t* dev_step_ctr;      // device-side step counter (the epoch of a replayed step graph)
   bool viewprep_in_flags;     // three-chain step: k_viewprep (side stream, beside the bookkeeping) produces the main envs' view records / car polygons
+  bool fuse_side = false, fuse_resume = false;   // the same on the phase-word path, per chain
   bool fuse_flags;            // N <= 2: the list chains do their cars' bookkeeping themselves (one launch less per chain)
   bool split_views;           // list raster launches draw one view per workgroup
   int list_view_grid;         // workgroups of a list raster launch
@@ -132,7 +133,9 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   h->viewprep_in_flags = cfg->num_agents <= 2;     // beyond two cars per env the bookkeeping + raster chain is the step's critical path: the epilogue stays in the dynamics (N = 4: 0.539 vs 0.561 ms)
   if (const char* g = getenv("MCR_VIEWPREP_IN_FLAGS")) h->viewprep_in_flags = atoi(g) != 0;
   h->fuse_flags = true;
-  if (const char* g = getenv("MCR_FUSE_FLAGS")) h->fuse_flags = atoi(g) != 0;
+  if (const char* g = getenv("MCR_FUSE_FLAGS")) h->fuse_flags = h->fuse_side = h->fuse_resume = atoi(g) != 0;
+  if (const char* g = getenv("MCR_FUSE_SIDE")) h->fuse_side = atoi(g) != 0;
+  if (const char* g = getenv("MCR_FUSE_RESUME")) h->fuse_resume = atoi(g) != 0;
   h->list_view_grid = cfg->num_agents <= 2 ? MCR_LIST_GRID : 8 * MCR_LIST_GRID;
   if (const char* g = getenv("MCR_LIST_VIEW_GRID")) { const int v = atoi(g); if (v > 0) h->list_view_grid = v; }
   h->split_views = true;
@@ -431,16 +434,15 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     // (kernel trace, round 3: the resume chain starts 2 us after the dynamics instead of 11, the next step's dynamics @@ us after
     // the step's last kernel instead of 20)
     P.soft_sync = 1;
-    const int fuse_flags = (view_flags && N <= 2 && h->fuse_flags) ? 1 : 0;
+    const int fuse_side = (view_flags && N <= 2 && h->fuse_side) ? 1 : 0, fuse_resume = (view_flags && N <= 2 && h->fuse_resume) ? 1 : 0;
     const int lg_flags = std::min(B * N, (N <= 2 ? 4 : 32) * MCR_LIST_GRID);
-    const bool flags_list = view_flags && !fuse_flags;
     if (!cc) LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), st, P, 0);
     hipLaunchKernelGGL(k_await, dim3(1), dim3(64), 0, h->s_side, P, (int)W_BEGIN, -1);
     if (cc) LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), h->s_side, P, 0);     // (W_COL: posted by the chain that follows)
     P.split = 0;
     P.role = 2;
-    LAUNCH_LDS(5, k_list_chain, lg_dyn, 64, col::lds_bytes(N), h->s_side, P, P, fuse_flags, lg_dyn);
-    if (flags_list) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, h->s_side, P);
+    LAUNCH_LDS(5, k_list_chain, lg_dyn, 64, col::lds_bytes(N), h->s_side, P, P, fuse_side, lg_dyn);
+    if (view_flags && !fuse_side) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, h->s_side, P);
     if (draw) launch_view(h, 6, B, h->s_side, P, 0);
     hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, h->s_side, P, (int)W_SIDE);
     P.role = 1;
@@ -450,8 +452,8 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     {
       const int ga = std::min(lg_dyn, MCR_LIST_GRID / 2), gb = P.auto_reset ? lg_col : 0;
       McrParams Pr = P; Pr.role = 4; Pr.list_envs_per_block = 1;
-      LAUNCH_LDS(7, k_list_chain, ga + gb, 64, col::lds_bytes(N), st, P, Pr, fuse_flags, ga);
-      if (flags_list) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, st, P);
+      LAUNCH_LDS(7, k_list_chain, ga + gb, 64, col::lds_bytes(N), st, P, Pr, fuse_resume, ga);
+      if (view_flags && !fuse_resume) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, st, P);
       if (draw) { McrParams Pv = P; Pv.role = P.auto_reset ? 5 : 3; Pv.await_tail = 1; launch_view(h, 7, B, st, Pv, 0); }     // ... and the step's join
     }
     P.role = 1;
