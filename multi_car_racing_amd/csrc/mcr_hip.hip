@@ -130,7 +130,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   // surplus workgroups exit on their first load.
   h->chain_grid = 4 * MCR_LIST_GRID;
   h->resume_on_caller = true;
-  h->viewprep_in_flags = cfg->num_agents <= 2;     // beyond two cars per env the bookkeeping + raster chain is the step's critical path: the epilogue stays in the dynamics (N = 4: 0.539 vs 0.561 ms)
+  h->viewprep_in_flags = cfg->num_agents <= 3;     // beyond three cars per env the bookkeeping + raster chain is the step's critical path: the epilogue stays in the dynamics (round 3, phase-word path: N = 3 13.4 -> 13.7 M with it, N = 4 10.8 -> 10.6, N = 8 no difference)
   if (const char* g = getenv("MCR_VIEWPREP_IN_FLAGS")) h->viewprep_in_flags = atoi(g) != 0;
   h->fuse_flags = true;
   if (const char* g = getenv("MCR_FUSE_FLAGS")) h->fuse_flags = h->fuse_side = h->fuse_resume = atoi(g) != 0;
