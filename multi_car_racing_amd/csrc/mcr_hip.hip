@@ -84,7 +84,7 @@ struct mcr_env {
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // Does the three-chain step run the contact pass BESIDE the main dynamics?  Only where kernels of different streams overlap
-// (probed at create), up to 4 cars per env (measured), and only for batches whose main dynamics launch puts at most one of its
+// (probed at create), up to 7 cars per env (measured), and only for batches whose main dynamics launch puts at most one of its
 // 256-VGPR wavefronts on a SIMD: that launch waits INSIDE the kernel for words of the contact pass, which must be able to get onto
 // the machine beside it (one such wavefront per SIMD leaves half the register file and nearly all LDS free; two on every SIMD
 // could starve a contact pass dispatched second).  After a reported give-up the handle stays with the contact pass in front.
@@ -243,13 +243,16 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
         // enqueued earlier).
         if (h->soft_sync) { if (g_soft_handles[cfg->device & 63].fetch_add(1) == 0) h->soft_token = true; else { g_soft_handles[cfg->device & 63].fetch_sub(1); h->soft_sync = false; } }
         if (const char* g = getenv("MCR_MERGE_LIST_VIEWS")) h->merge_list_views = atoi(g) != 0;
-        // (beyond 4 cars per env the one-step-ahead touch verdict — a second pass over up to 28 car pairs — costs more than the
+        // (at 8 cars per env the one-step-ahead touch verdict — a second pass over up to 28 car pairs — costs more than the
         // contact pass gains by running beside the dynamics: measured at N = 8, round 2: 3.66 vs 4.28 M env-steps/s.  Round 3 tried a
         // CONSERVATIVE verdict there instead — bounding discs + car boxes, no narrowphase, the contact chain taking every env it
         // marks: with ~340 of 4096 envs in contact and as many near misses per step the side stream's chain, bookkeeping and raster
         // grow faster than the 110 us of k_collide that leave the critical path: 1.40 vs 0.975 ms per step.  What bounds N = 8 is the
         // contact chain itself — 585 us for its slowest wavefront, a sequential Gauss-Seidel over the contacts between the joint sweeps)
-        h->concurrent_collide = N <= 4 && !getenv("MCR_SEQUENTIAL_COLLIDE") && (B * G + 63) / 64 <= h->simd_count && kernels_overlap(h->s_defer, h->s_side);
+        // (round 3, phase-word path, contact pass beside / in front of the dynamics: N = 5 8.99 / 8.50 M env-steps/s, N = 6 7.87 / 7.49,
+        // N = 7 7.16 / 6.80, N = 8 4.90 / 5.47 — up to seven cars per env it runs beside)
+        const int cc_max_agents = getenv("MCR_CC_MAX_AGENTS") ? atoi(getenv("MCR_CC_MAX_AGENTS")) : 7;
+        h->concurrent_collide = N <= cc_max_agents && !getenv("MCR_SEQUENTIAL_COLLIDE") && (B * G + 63) / 64 <= h->simd_count && kernels_overlap(h->s_defer, h->s_side);
         h->split = true;
       } else (void)hipStreamDestroy(h->s_side);
     }

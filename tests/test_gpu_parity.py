@@ -303,7 +303,7 @@ def test_full_size_properties_and_batch_independence(torch_cuda, oracle):
     big.close(); small.close()
 
 
-@pytest.mark.parametrize("B,N", [(1024, 2), (512, 3), (256, 4)])
+@pytest.mark.parametrize("B,N", [(1024, 2), (512, 3), (256, 4), (256, 6)])
 def test_side_stream_is_bit_identical_to_single_stream(torch_cuda, B, N):
     """The three-chain step only changes WHERE an env's chain runs (list chains for the contact, deferred and re-spawned
     envs, their bookkeeping in list launches; the main envs' view records in the bookkeeping launch for N <= 3, in the dynamics'
