@@ -74,6 +74,7 @@ struct mcr_env {
   hipStream_t probed_stream = (hipStream_t)-1;   // the caller's stream the phase-word ordering was last checked against (mcr_step)
   bool merge_flags_viewprep = true;   // soft_sync path: the main envs' view records and bookkeeping in one launch
   int defer_after = MCR_DEFER_AFTER;   // position sweeps the main dynamics grants an env before it defers it (MCR_DEFER_AFTER in the environment: measurements)
+  bool flags_on_caller = true;   // phase-word path, no view records in the bookkeeping launch (N > 3): the main envs' bookkeeping runs on the caller's stream
   bool soft_token = false;    // this handle is its device's one phase-word handle (mcr_create)
   bool soft_sync = false;     // the step's streams meet through phase words in device memory (mcr_kernels.h: mcr_post / mcr_await) instead of events
   bool stop_events = true;    // events completed by the launches they mark (hipExtLaunchKernelGGL) instead of marker packets behind them
@@ -232,6 +233,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
         const unsigned evf = hipEventDisableTiming;     // (hipEventReleaseToDevice changes nothing measurable: tools/ubench/event_gap.hip)
         for (hipEvent_t* e : {&h->ev_fork, &h->ev_join, &h->ev_fork2, &h->ev_join2, &h->ev_col, &h->ev_chain}) (void)hipEventCreateWithFlags(e, evf);
         if (const char* g = getenv("MCR_DEFER_AFTER")) { const int v = atoi(g); if (v >= 1 && v < 60) h->defer_after = v; }
+        if (const char* g = getenv("MCR_FLAGS_ON_CALLER")) h->flags_on_caller = atoi(g) != 0;
         if (const char* g = getenv("MCR_STOP_EVENTS")) h->stop_events = atoi(g) != 0;
         h->soft_sync = kernels_overlap(h->s_defer, h->s_side);     // (a waiting kernel needs the kernels it waits for to run beside it)
         if (const char* g = getenv("MCR_MERGE_FLAGS_VIEWPREP")) h->merge_flags_viewprep = atoi(g) != 0;
@@ -450,6 +452,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, h->s_side, P, (int)W_SIDE);
     P.role = 1;
     P.viewprep_in_flags = (view_flags && draw && h->viewprep_in_flags) ? 1 : 0;
+    const bool flags_on_caller = view_flags && draw && !P.viewprep_in_flags && h->flags_on_caller;
     LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 0);
     P.role = 3;
     {
@@ -457,6 +460,9 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
       McrParams Pr = P; Pr.role = 4; Pr.list_envs_per_block = 1;
       LAUNCH_LDS(7, k_list_chain, ga + gb, 64, col::lds_bytes(N), st, P, Pr, fuse_resume, ga);
       if (view_flags && !fuse_resume) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, st, P);
+      // Beyond three cars per env the third stream's chain (bookkeeping of B*N cars, then B*N views) is the longer one and the caller's
+      // has slack: the main envs' bookkeeping — which the raster does not depend on — moves here, between the resume chain and its raster
+      if (flags_on_caller) { McrParams Pm = P; Pm.role = 1; hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, st, Pm); }
       if (draw) { McrParams Pv = P; Pv.role = P.auto_reset ? 5 : 3; Pv.await_tail = 1; launch_view(h, 7, B, st, Pv, 0); }     // ... and the step's join
     }
     P.role = 1;
@@ -464,7 +470,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     if (P.viewprep_in_flags && h->merge_flags_viewprep) hipLaunchKernelGGL(k_flags_viewprep, dim3(dyn_blocks + B * N), dim3(64), 0, h->s_defer, P, dyn_blocks);
     else {
       if (P.viewprep_in_flags) hipLaunchKernelGGL(k_viewprep, dim3(dyn_blocks), dim3(64), 0, h->s_defer, P);
-      if (view_flags) hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, h->s_defer, P);
+      if (view_flags && !flags_on_caller) hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, h->s_defer, P);
     }
     P.use_vorder = 1;
     if (draw) launch_view(h, 2, B, h->s_defer, P, 0);
