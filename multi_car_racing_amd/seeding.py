@@ -1,5 +1,8 @@
 """gym 0.17.2 `gym.utils.seeding.np_random` restated ([3P-recalled]): the env stream is a numpy
-RandomState seeded with the little-endian uint32 words of the first 8 bytes of sha512(str(seed))."""
+RandomState seeded with the little-endian uint32 words of the first 8 bytes of sha512(str(seed)).
+(gym is MIT-licensed, (c) 2016 OpenAI; this file restates the published behaviour of three of its helper functions —
+`np_random`, `hash_seed`, `_bigint_from_bytes` / `_int_list_from_bigint` — so that `env.seed(s)` draws the same tracks as the
+reference; it is not a copy of gym's source and the reference repository does not contain that file.)"""
 import hashlib
 import os
 import struct
