@@ -360,17 +360,12 @@ static void launch_reset(mcr_env* h, McrParams P, hipStream_t st) {
   if (P.obs) launch_view(h, 2, B, st, P, 1);
 }
 
-// step(): collide -> dynamics [-> auto-reset pass] -> view on the caller's stream `st`.
-// With num_streams == 2 the step forks into three chains that meet again at the end (grids are sized for the worst
-// case, surplus workgroups exit on their first load):
-//   st      : collide(all) -+-> dynamics(main envs, 3 position sweeps) -+-> reset pass -> view(main envs) -+-> flags
-//   s_side  :               +-> dynamics(contact envs) -> their reset pass -> view(contact envs) ---------+
-//   s_defer :                                                          +-> dynamics(resume deferred envs) -> their reset pass -> view(them) --+
-// Contact envs: a wavefront holding a touching car<->car pair takes 2-4x as long as the others.  Deferred envs: the
-// few whose position loop is still iterating after 3 sweeps (a slow marginal crawl that would hold the whole main
-// launch for up to 60).  s_defer's dynamics starts while the GPU is nearly idle (the reset pass), so it finds free
-// SIMDs at once.  An env of either list that ended its episode in this step (rare) takes its reset pass inside its own
-// chain (two launches that exit at once in every other step; round 1 ran them as a "late" pass on the caller's stream).
+// step(): collide -> dynamics [-> auto-reset pass] -> view on the caller's stream `st`; with num_streams == 2 the step forks
+// into three chains that meet again at the end (see the diagram inside; grids are sized for the worst case, surplus workgroups
+// exit on their first load).  Contact envs: a wavefront holding a touching car<->car pair takes 2-4x as long as the others.
+// Deferred envs: the few whose position loop is still iterating after 3 sweeps (a slow marginal crawl that would hold the whole
+// main launch for up to 60).  An env of either list that ended its episode in this step (rare) takes its reset pass inside its
+// own chain.
 static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags) {
   const int B = P.B, N = P.N;
   const int dyn_blocks = (B * P.G + 63) / 64;
@@ -407,9 +402,10 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     return;
   }
   // Three chains that meet again at the end (k_list_chain.h: a list chain is one fused launch + its raster):
-  //   st      : -+-> dynamics(main envs, 3 position sweeps) ---------+-> bookkeeping(main envs) -> raster(main envs) ------+
-  //   s_side  :  +-> collide(all) -> chain(contact envs) -> raster --+-> reset pass(re-spawned envs) -> their raster ------+
-  //   s_defer :                                                      +-> chain(resume the deferred envs) -> their raster --+
+  //   st      : -+-> dynamics(main envs, 3 position sweeps) -+-> chain(resume the deferred envs || reset pass of the re-spawned envs) -> their raster -+
+  //   s_side  :  +-> collide(all) -> chain(contact envs) -> their raster ---------------------------------------------------------------------------+
+  //   s_defer :                                              +-> view records, bookkeeping(main envs) -> raster(main envs) -------------------------+
+  // ordered by phase words that kernels post and await (the first branch below) or by events (the second).
   // Contact envs: a wavefront holding a touching car<->car pair takes 2-4x as long as the others.  Deferred envs: the
   // few whose position loop is still iterating after 3 sweeps (a slow marginal crawl that would hold the whole main
   // launch for up to 60).  Re-spawned envs (auto-reset, ~B/1000 per step): their reset pass would hold the raster of
@@ -436,8 +432,9 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     //   s_side  : await(BEGIN) -> [collide -> post(COL)] -> chain(contact envs) -> raster -> post(SIDE)
     //   st      : [posts BEGIN] dynamics(main envs) -> [posts DYN, awaits COL] chain(resume + re-spawned envs) -> raster -> await(SIDE, MAIN)
     //   s_defer : await(DYN, COL) -> view records -> bookkeeping(main envs) -> raster(main envs) -> post(MAIN)
-    // (kernel trace, round 3: the resume chain starts 2 us after the dynamics instead of 11, the next step's dynamics @@ us after
-    // the step's last kernel instead of 20)
+    // (kernel trace, round 3: the resume chain starts 3 us after the dynamics instead of 11-21, the next step's dynamics 0-1 us after
+    // the step's last kernel instead of 20-32; the chains' bookkeeping: list launches behind the chains; N > 3: the main envs'
+    // bookkeeping on the caller's stream)
     P.soft_sync = 1;
     const int fuse_side = (view_flags && N <= 2 && h->fuse_side) ? 1 : 0, fuse_resume = (view_flags && N <= 2 && h->fuse_resume) ? 1 : 0;
     const int lg_flags = std::min(B * N, (N <= 2 ? 4 : 32) * MCR_LIST_GRID);
