@@ -8,18 +8,27 @@
 #include <algorithm>
 __global__ void k_spin(long long ticks) { const long long t0 = wall_clock64(); while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8); }
 __global__ void k_a(long long* out, long long ticks) { const long long t0 = wall_clock64(); while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(2); if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = wall_clock64(); }
+__global__ void k_a_store(long long* out, long long ticks, unsigned* word, unsigned val) { const long long t0 = wall_clock64(); while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(2); if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = wall_clock64(); __hip_atomic_store(word, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); } }
+__global__ void k_postw(unsigned* word, unsigned val) { __hip_atomic_store(word, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__global__ void k_awaitw(unsigned* word, unsigned val) { for (int i = 0; i < (1 << 22) && __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != val; ++i) __builtin_amdgcn_s_sleep(8); }
 __global__ void k_b(long long* out) { if (threadIdx.x == 0 && blockIdx.x == 0) out[1] = wall_clock64(); }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 int main() {
   hipStream_t s1, s2, s3; CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s3, hipStreamNonBlocking));
   long long* d; CK(hipMalloc(&d, 64)); long long hst[2];
+  unsigned* sig = nullptr; const bool have_sig = hipExtMallocWithFlags((void**)&sig, 64, hipMallocSignalMemory) == hipSuccess;
+  unsigned* dw = nullptr; CK(hipMalloc(&dw, 64)); unsigned token = 0;
+  if (!have_sig) { (void)hipGetLastError(); printf("(no signal memory: the stream memory op cases are skipped)\n"); }
   const char* names[] = {"same stream, nothing between", "same stream: record(ev) between", "same stream: record(ev) + wait(done event of s2) between",
                          "hop: s1 A, record; s2 wait, B", "hop: s1 A with stopEvent (hipExtLaunchKernelGGL); s2 wait, B", "same stream: 2 waits on done events between",
                          "same stream: 3 records between", "hop, ReleaseToDevice events", "two hops: s1 A,record; s2 wait,record; s3 wait,B",
                          "same stream: A with stopEvent, then B", "join of two: s1 A; s2 A'; s3 waits both, B (gap after the later)",
                          "same stream: wait on s2's event, complete long before A ends but not at enqueue", "same stream: two such waits (s2, s3)",
-                         "same stream: two such waits + record", "same stream: wait on s2's kernel ending 5 us BEFORE A ends", "same stream: wait on s2's kernel ending 5 us AFTER A ends (gap after it)"};
-  for (int variant = 0; variant < 16; ++variant) {
+                         "same stream: two such waits + record", "same stream: wait on s2's kernel ending 5 us BEFORE A ends", "same stream: wait on s2's kernel ending 5 us AFTER A ends (gap after it)",
+                         "hop by stream memory ops: s1 A, hipStreamWriteValue32; s2 hipStreamWaitValue32, B", "hop by kernels: s1 A, post kernel; s2 await kernel, B",
+                         "hop: A's last thread stores the word; s2 hipStreamWaitValue32, B", "same stream: hipStreamWaitValue32 on a word set long ago between A and B",
+                         "hop: s1 A, hipStreamWriteValue32; s2 await kernel (spinning since before A), B"};
+  for (int variant = 0; variant < 21; ++variant) {
     std::vector<double> gaps;
     for (int rep = 0; rep < 40; ++rep) {
       const unsigned fl = hipEventDisableTiming | (variant == 7 ? hipEventReleaseToDevice : 0u);
@@ -47,12 +56,26 @@ int main() {
                  hipLaunchKernelGGL(k_a, dim3(256), dim3(64), 0, s1, d, a_ticks); CK(hipStreamWaitEvent(s1, e2, 0)); CK(hipStreamWaitEvent(s1, e3, 0)); if (variant == 13) CK(hipEventRecord(e1, s1)); hipLaunchKernelGGL(k_b, dim3(256), dim3(64), 0, s1, d); break;
         case 14: hipExtLaunchKernelGGL(k_a, dim3(64), dim3(64), 0, s2, nullptr, e2, 0, d + 2, a_ticks - 500); hipLaunchKernelGGL(k_a, dim3(256), dim3(64), 0, s1, d, a_ticks); CK(hipStreamWaitEvent(s1, e2, 0)); hipLaunchKernelGGL(k_b, dim3(256), dim3(64), 0, s1, d); break;
         case 15: hipExtLaunchKernelGGL(k_a, dim3(64), dim3(64), 0, s2, nullptr, e2, 0, d, a_ticks); hipLaunchKernelGGL(k_a, dim3(256), dim3(64), 0, s1, d + 2, a_ticks - 500); CK(hipStreamWaitEvent(s1, e2, 0)); hipLaunchKernelGGL(k_b, dim3(256), dim3(64), 0, s1, d); break;
+        case 16: case 18: case 19: case 20:
+          if (!have_sig) break;
+          ++token;
+          if (variant == 19) { CK(hipStreamWriteValue32(s2, sig, token, 0)); CK(hipStreamSynchronize(s2)); hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s1, 1000LL); }
+          if (variant == 20) hipLaunchKernelGGL(k_awaitw, dim3(1), dim3(64), 0, s2, sig, token);
+          if (variant == 18) hipLaunchKernelGGL(k_a_store, dim3(256), dim3(64), 0, s1, d, a_ticks, sig, token);
+          else hipLaunchKernelGGL(k_a, dim3(256), dim3(64), 0, s1, d, a_ticks);
+          if (variant == 16 || variant == 20) CK(hipStreamWriteValue32(s1, sig, token, 0));
+          if (variant == 19) { CK(hipStreamWaitValue32(s1, sig, token, hipStreamWaitValueEq, 0xffffffffu)); hipLaunchKernelGGL(k_b, dim3(256), dim3(64), 0, s1, d); }
+          else { if (variant != 20) CK(hipStreamWaitValue32(s2, sig, token, hipStreamWaitValueEq, 0xffffffffu)); hipLaunchKernelGGL(k_b, dim3(256), dim3(64), 0, s2, d); }
+          break;
+        case 17: ++token; hipLaunchKernelGGL(k_awaitw, dim3(1), dim3(64), 0, s2, dw, token); hipLaunchKernelGGL(k_a, dim3(256), dim3(64), 0, s1, d, a_ticks); hipLaunchKernelGGL(k_postw, dim3(1), dim3(1), 0, s1, dw, token);
+                 hipLaunchKernelGGL(k_b, dim3(256), dim3(64), 0, s2, d); break;
       }
       CK(hipDeviceSynchronize());
       CK(hipMemcpy(hst, d, 16, hipMemcpyDeviceToHost));
-      if (rep >= 5) gaps.push_back((hst[1] - hst[0]) / 100.0);
+      if (rep >= 5 && (have_sig || !(variant == 16 || variant >= 18))) gaps.push_back((hst[1] - hst[0]) / 100.0);
       CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1)); CK(hipEventDestroy(e2)); CK(hipEventDestroy(e3));
     }
+    if (gaps.empty()) continue;
     std::sort(gaps.begin(), gaps.end());
     printf("%-75s gap median %6.2f us  min %6.2f  p90 %6.2f\n", names[variant], gaps[gaps.size() / 2], gaps[0], gaps[gaps.size() * 9 / 10]);
   }
