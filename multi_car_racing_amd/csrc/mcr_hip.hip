@@ -449,7 +449,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, h->s_side, P, (int)W_SIDE);
     P.role = 1;
     P.viewprep_in_flags = (view_flags && draw && h->viewprep_in_flags) ? 1 : 0;
-    const bool flags_on_caller = view_flags && draw && !P.viewprep_in_flags && h->flags_on_caller;
+    const bool flags_on_caller = view_flags && draw && !P.viewprep_in_flags && h->flags_on_caller && N <= 7;   // (N = 8: the contact chain is the critical one; no gain, and the raster would share the machine with the bookkeeping)
     LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 0);
     P.role = 3;
     {
