@@ -12,6 +12,10 @@
 #include <vector>
 #include <thread>
 #include <atomic>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
+#include <sys/prctl.h>
 #include <string>
 
 // ============================================================================ MT19937 (numpy layout)
@@ -446,6 +450,59 @@ extern "C" int mcr_episode_generate(uint32_t* mt_track, int num_agents, int cw, 
   return MCR_OK;
 }
 
+// Helper threads of mcr_episodes_generate, kept between calls: a batch is a handful of tracks (the refill thread asks for the
+// ~4 episodes that ended in a step, every step) at 0.07 ms each, and starting a thread costs about as much as generating one —
+// with threads started per call the second generator thread of a 2-core host share did a third of the work instead of half.
+// One job at a time (a second caller that finds the pool busy generates on its own thread).
+namespace {
+struct GenPool {
+  std::mutex m, run_m;
+  std::condition_variable cv_work, cv_done;
+  std::vector<std::thread> threads;
+  const std::function<void()>* job = nullptr;
+  uint64_t seq = 0;
+  int want = 0, started = 0, finished = 0;
+  bool stop = false;
+  void worker() {
+    (void)prctl(PR_SET_NAME, "mcr-gen", 0, 0, 0);
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> lk(m);
+    for (;;) {
+      cv_work.wait(lk, [&] { return stop || (seq != seen && job && started < want); });
+      if (stop) return;
+      seen = seq;
+      ++started;
+      const std::function<void()>* fn = job;
+      lk.unlock();
+      (*fn)();
+      lk.lock();
+      if (++finished == want) cv_done.notify_all();
+    }
+  }
+  // runs fn on the caller and on `helpers` pool threads; returns when all of them are through
+  void run(int helpers, const std::function<void()>& fn) {
+    std::unique_lock<std::mutex> one(run_m, std::try_to_lock);
+    if (helpers <= 0 || !one.owns_lock()) { fn(); return; }
+    {
+      std::lock_guard<std::mutex> lk(m);
+      while ((int)threads.size() < helpers) threads.emplace_back([this] { worker(); });
+      job = &fn; ++seq; want = helpers; started = finished = 0;
+    }
+    cv_work.notify_all();
+    fn();
+    std::unique_lock<std::mutex> lk(m);
+    cv_done.wait(lk, [&] { return finished == want; });
+    job = nullptr;
+  }
+  ~GenPool() {
+    { std::lock_guard<std::mutex> lk(m); stop = true; }
+    cv_work.notify_all();
+    for (auto& t : threads) if (t.joinable()) t.join();
+  }
+};
+GenPool& gen_pool() { static GenPool* p = new GenPool(); return *p; }   // (never destroyed: its threads may outlive main() in an embedding process)
+}  // namespace
+
 extern "C" int mcr_episodes_generate(uint32_t* mt_track, uint32_t* mt_global, int n, int num_agents, int direction_mode,
                                      void* blobs_out, int32_t* info_out, int num_threads) {
   if (!mt_track || !mt_global || !blobs_out || n < 0) return MCR_ERR_ARG;
@@ -468,10 +525,8 @@ extern "C" int mcr_episodes_generate(uint32_t* mt_track, uint32_t* mt_global, in
       if (info_out) { int32_t* o = info_out + (size_t)i * 12; for (int k = 0; k < 4; ++k) o[k] = info[k]; for (int k = 0; k < 8; ++k) o[4 + k] = k < num_agents ? order[k] : -1; }
     }
   };
-  std::vector<std::thread> pool;
-  for (int t = 1; t < num_threads; ++t) pool.emplace_back(work);
-  work();
-  for (auto& th : pool) th.join();
+  const std::function<void()> job = work;
+  gen_pool().run(num_threads - 1, job);
   return err.load();
 }
 
