@@ -13,24 +13,30 @@ __device__ __forceinline__ bool mcr_touch_verdict(const McrParams& p, const int 
   const int lane = threadIdx.x & 63, N = p.N, BN = p.BN;
   if (!p.car_contacts || N < 2) return false;
   const McrShapes& S = *p.shapes;
+  const int npairs = N * (N - 1) / 2;
+  // lane L < npairs <-> car pair (a, b), a < b, in the order (0,1) (0,2) .. (0,N-1) (1,2) ..
+  int pa = 0, pb = 1;
+  { int r = lane; for (pa = 0; pa < N - 1; ++pa) { const int cnt = N - 1 - pa; if (r < cnt) break; r -= cnt; } pb = pa + 1 + r; }
+  const bool is_pair = lane < npairs;
   {
     // coarse exit before any fixture is transformed: a car lies inside the discs of radius S.pad[0] around its hull's
     // centre of mass and S.pad[1] around each wheel's; two cars whose discs stay 0.2 apart (polygon radii and box slack
-    // are 0.02 and 0.05) cannot have overlapping car boxes, let alone touch.  Lane = car * 8 + body (bodies 0..4).
+    // are 0.02 and 0.05) cannot have overlapping car boxes, let alone touch.  Lane = car * 8 + body (bodies 0..4) holds a
+    // centre; lane = car pair tests its nine disc pairs (hull-hull, hull_a-wheel_b x4, wheel_a-hull_b x4).
     const int cc_ = lane >> 3, body = lane & 7;
     float bx = 0.0f, by = 0.0f;
     const bool have = cc_ < N && body < 5;
     if (have) { bx = p.carf[(CF_CX + body) * BN + env * N + cc_]; by = p.carf[(CF_CY + body) * BN + env * N + cc_]; }
     bool close = false;
-    for (int a = 0; a < N - 1; ++a)
-      for (int b = a + 1; b < N; ++b)
-        for (int k = 0; k < 9; ++k) {                           // hull-hull, hull_a-wheel_b x4, wheel_a-hull_b x4
-          const int ba = k < 5 ? 0 : k - 4, bb = k < 5 ? k : 0;
-          const float ax = __shfl(bx, a * 8 + ba), ay = __shfl(by, a * 8 + ba), ox = __shfl(bx, b * 8 + bb), oy = __shfl(by, b * 8 + bb);
-          const float r = (ba == 0 ? S.pad[0] : S.pad[1]) + (bb == 0 ? S.pad[0] : S.pad[1]) + 0.2f;
-          close = close || ((ax - ox) * (ax - ox) + (ay - oy) * (ay - oy) <= r * r);
-        }
-    if (!close) return false;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int ba = k < 5 ? 0 : k - 4, bb = k < 5 ? k : 0;
+      const int la = is_pair ? pa * 8 + ba : 0, lb = is_pair ? pb * 8 + bb : 0;
+      const float ax = __shfl(bx, la), ay = __shfl(by, la), ox = __shfl(bx, lb), oy = __shfl(by, lb);
+      const float r = (ba == 0 ? S.pad[0] : S.pad[1]) + (bb == 0 ? S.pad[0] : S.pad[1]) + 0.2f;
+      close = close || (is_pair && (ax - ox) * (ax - ox) + (ay - oy) * (ay - oy) <= r * r);
+    }
+    if (!__any(close)) return false;
   }
   const int c = lane >> 3, fi = lane & 7;
   float4 fxf = make_float4(0.0f, 0.0f, 0.0f, 1.0f), fbox = make_float4(MCR_MAXFLT, MCR_MAXFLT, -MCR_MAXFLT, -MCR_MAXFLT);
@@ -55,44 +61,36 @@ __device__ __forceinline__ bool mcr_touch_verdict(const McrParams& p, const int 
     hix = mcr_max(hix, __shfl_xor(hix, o)); hiy = mcr_max(hiy, __shfl_xor(hiy, o));
   }
   const float cb0 = lox - 0.05f, cb1 = loy - 0.05f, cb2 = hix + 0.05f, cb3 = hiy + 0.05f;     // the car's box, on all 8 lanes of the car
-  // cheap exit, as in k_collide: no pair of car boxes overlaps -> no fixture pair can touch
-  bool any_pair = false;
-  uint32_t amask = 0u;                                            // bit a: car a's box overlaps the box of some car b > a
-  for (int a = 0; a < N - 1; ++a)
-    for (int b = a + 1; b < N; ++b) {
-      const float a0 = __shfl(cb0, a * 8), a1 = __shfl(cb1, a * 8), a2 = __shfl(cb2, a * 8), a3 = __shfl(cb3, a * 8);
-      const float b0 = __shfl(cb0, b * 8), b1 = __shfl(cb1, b * 8), b2 = __shfl(cb2, b * 8), b3 = __shfl(cb3, b * 8);
-      if (!(a0 > b2 || a2 < b0 || a1 > b3 || a3 < b1)) { any_pair = true; amask |= 1u << a; }
-    }
-  if (!any_pair) return false;
-  int total = 0;
-  for (int a = 0; a < N - 1; ++a) total += 64 * (N - 1 - a);
-  for (int r0 = 0, a_of = 0, a_end = 64 * (N - 1); r0 < total; r0 += 64) {
-    while (r0 >= a_end) { ++a_of; a_end += 64 * (N - 1 - a_of); }          // the chunk's car a (k_collide.h: same skip)
-    if (!((amask >> a_of) & 1u)) continue;
-    const int idx = r0 + lane;
-    bool valid = idx < total;
-    int a = 0, fa = 0, b = 1, fb = 0;
-    if (valid) {
-      int r = idx;
-      for (a = 0; a < N - 1; ++a) { const int cnt = 64 * (N - 1 - a); if (r < cnt) break; r -= cnt; }
-      const int per_fa = (N - 1 - a) * 8;
-      fa = r / per_fa; const int r2 = r - fa * per_fa;
-      b = a + 1 + (r2 >> 3); fb = r2 & 7;
-      if (fa >= 4 && fb >= 4) valid = false;                            // wheel vs wheel: filtered
-    }
-    const int ia = valid ? a * 8 + fa : 0, ib = valid ? b * 8 + fb : 0;
+  // cheap exit, as in k_collide: no pair of car boxes overlaps -> no fixture pair can touch (lane = car pair)
+  unsigned long long pmask;
+  {
+    const int la = is_pair ? pa * 8 : 0, lb = is_pair ? pb * 8 : 0;
+    const float a0 = __shfl(cb0, la), a1 = __shfl(cb1, la), a2 = __shfl(cb2, la), a3 = __shfl(cb3, la);
+    const float b0 = __shfl(cb0, lb), b1 = __shfl(cb1, lb), b2 = __shfl(cb2, lb), b3 = __shfl(cb3, lb);
+    pmask = __ballot(is_pair && !(a0 > b2 || a2 < b0 || a1 > b3 || a3 < b1));
+  }
+  // the fixture pairs of the car pairs whose boxes overlap, 8 x 8 at a time (lane = fixture of a * 8 + fixture of b).  "Does any
+  // pair touch" does not depend on the order the pairs are looked at: k_collide, which also has to ORDER its manifolds, walks the
+  // pairs differently and must arrive at the same answer (it counts the envs where it does not).
+  while (pmask) {
+    const int q = (int)__builtin_ctzll(pmask); pmask &= pmask - 1ull;
+    int a = 0, r = q;
+    for (a = 0; a < N - 1; ++a) { const int cnt = N - 1 - a; if (r < cnt) break; r -= cnt; }
+    const int b = a + 1 + r;
+    const int fa = lane >> 3, fb = lane & 7;
+    const bool valid = !(fa >= 4 && fb >= 4);                              // wheel vs wheel: filtered
+    const int ia = a * 8 + fa, ib = b * 8 + fb;
     const float4 A = make_float4(__shfl(fbox.x, ia), __shfl(fbox.y, ia), __shfl(fbox.z, ia), __shfl(fbox.w, ia));
     const float4 Bb = make_float4(__shfl(fbox.x, ib), __shfl(fbox.y, ib), __shfl(fbox.z, ib), __shfl(fbox.w, ib));
     const float4 ta = make_float4(__shfl(fxf.x, ia), __shfl(fxf.y, ia), __shfl(fxf.z, ia), __shfl(fxf.w, ia));
     const float4 tb = make_float4(__shfl(fxf.x, ib), __shfl(fxf.y, ib), __shfl(fxf.z, ib), __shfl(fxf.w, ib));
     bool hit = false;
     if (valid && !(A.x > Bb.z || A.z < Bb.x || A.y > Bb.w || A.w < Bb.y)) {
-      const McrPoly& pa = fa < 4 ? S.hull[fa] : S.wheel; const McrPoly& pb = fb < 4 ? S.hull[fb] : S.wheel;
+      const McrPoly& pa_ = fa < 4 ? S.hull[fa] : S.wheel; const McrPoly& pb_ = fb < 4 ? S.hull[fb] : S.wheel;
       Xf xa, xb;
       xa.p = v2(ta.x, ta.y); xa.q.s = ta.z; xa.q.c = ta.w; xb.p = v2(tb.x, tb.y); xb.q.s = tb.z; xb.q.c = tb.w;
       cc::Manifold M; M.n = 0; M.type = 0; M.pl[0] = M.pl[1] = v2(0.0f, 0.0f); M.id[0] = M.id[1] = 0; M.localNormal = M.localPoint = v2(0.0f, 0.0f);
-      cc::collide_polygons(M, pa, xa, pb, xb);
+      cc::collide_polygons(M, pa_, xa, pb_, xb);
       hit = M.n > 0;
     }
     if (__any(hit)) return true;
