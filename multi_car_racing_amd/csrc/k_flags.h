@@ -14,19 +14,20 @@
 #include "k_raster_common.h"
 #include "k_touch.h"
 
-__device__ __forceinline__ void flags_block(const McrParams& p, const int blk) {
-  const int lane = threadIdx.x;
+// (env_of_list >= 0: the env was looked up by the caller — the list rasters' bookkeeping workgroups, k_view.h — and blk is the agent)
+__device__ __forceinline__ void flags_block(const McrParams& p, const int blk, const int env_of_list = -1) {
+  const int lane = threadIdx.x & 63;
   const int N = p.N, BN = p.BN;
   // roles as in the other step kernels: 0 every env, 1 the main launch's envs, 2 / 3 the contact / deferred lists
-  const int env = mcr_env_of_slot(p, blk / N);
+  const int env = env_of_list >= 0 ? env_of_list : mcr_env_of_slot(p, blk / N);
   if (env >= p.env0 + p.nenv) return;
-  const int ci = env * N + blk % N;
+  const int ci = env * N + (env_of_list >= 0 ? blk : blk % N);
   const McrEnvState es = p.env[env];
   // The wavefront of an env's first car also settles the env's touch verdict for the NEXT step (k_touch.h): the poses this
   // step ended with are the ones the next contact pass sees.  Main launch: the main dynamics has written 0 for every env
   // whose hulls are far apart (nearly all) and 2 where the exact test is needed; list launches: always the exact test.
   // The mark is requested here and looked at when the scan below is done (its latency is off the wavefront's chain).
-  const bool vwave = p.part_next != nullptr && blk % N == 0;
+  const bool vwave = p.part_next != nullptr && (env_of_list >= 0 ? blk : blk % N) == 0;
   uint32_t vmark = 0;
   if (vwave) vmark = p.role == 1 ? (uint32_t)p.part_next[env] : 2u;
   auto settle_verdict = [&]() {
@@ -145,4 +146,6 @@ __device__ __forceinline__ void flags_block(const McrParams& p, const int blk) {
 
 // one wavefront per car (the list launches of roles >= 2 call flags_block from k_list_chain.h)
 // 8192 wavefronts = one round on 1024 SIMDs at 8 wavefronts each: the kernel must stay within 64 VGPRs
+#ifndef MCR_DEVICE_FUNCTIONS_ONLY
 __global__ __launch_bounds__(64, 8) void k_flags(McrParams p) { flags_block(p, (int)blockIdx.x); }
+#endif

@@ -100,9 +100,11 @@ __device__ __forceinline__ bool mcr_touch_verdict(const McrParams& p, const int 
 
 // all envs at once: what mcr_step launches first when the verdicts may be stale (after reset(), reset_envs(), a state
 // restore, a step without actions)
+#ifndef MCR_DEVICE_FUNCTIONS_ONLY
 __global__ __launch_bounds__(64) void k_touch(McrParams p) {
   const int env = p.env0 + (int)blockIdx.x;
   if (env >= p.env0 + p.nenv) return;
   const bool v = p.env[env].active ? mcr_touch_verdict(p, env) : false;
   if (threadIdx.x == 0) p.part[env] = v ? 1 : 0;
 }
+#endif

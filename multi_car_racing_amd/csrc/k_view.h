@@ -105,13 +105,22 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
   //   role >= 2 (side streams): the envs of the contact / deferred lists;  use_vorder (step path): the order k_dynamics
   //   recorded, heavy (zoomed-out) envs first;  role 1: not the envs the side streams draw;  only_just_reset: reset().
   if (PERSIST) __builtin_amdgcn_s_setprio(3);                               // a few envs beside the main launch that fills every CU: they go first
+  const int vgrid = (int)gridDim.x - (PERSIST ? p.flags_blocks : 0);        // workgroups that draw; the rest: the list's bookkeeping
+  if (PERSIST && (int)blockIdx.x >= vgrid) {
+    // the bookkeeping of the list's cars (k_flags.h: backward / on-grass flags, the env's touch verdict for the next step), one wavefront
+    // per car.  Contact list for the contact chain's raster, deferred list otherwise (the re-spawned envs' cars take none in this step).
+    const int32_t* __restrict__ L = p.role == 2 ? p.clist : p.dlist;
+    const int ncars = L[0] * N, per_round = p.flags_blocks * (VIEW_THREADS / 64);
+    for (int c = ((int)blockIdx.x - vgrid) * (VIEW_THREADS / 64) + (int)(threadIdx.x >> 6); c < ncars; c += per_round) flags_block(p, c % N, L[1 + c / N]);
+    return;
+  }
   int my_env = -1, my_slot = 0, my_P = -1, my_agent = 0;
   // List launches with `split_views`: a work slot is ONE VIEW (list entry s / N, agent s % N) instead of an env with its N views —
   // the few envs of a list are the tail of a chain on the step's critical path, and their views side by side take half the time
   // of one after the other (what an env's views share is fetched once per view then).
   const bool split_views = PERSIST && p.split_views != 0;
   {
-    const int s = (int)blockIdx.x + (PERSIST ? lane * (int)gridDim.x : 0);
+    const int s = (int)blockIdx.x + (PERSIST ? lane * vgrid : 0);
     int e = -1;
     bool ojr = only_just_reset != 0;
     if (p.role == 5) {

@@ -75,6 +75,7 @@ struct mcr_env {
   bool merge_flags_viewprep = true;   // soft_sync path: the main envs' view records and bookkeeping in one launch
   int defer_after = MCR_DEFER_AFTER;   // position sweeps the main dynamics grants an env before it defers it (MCR_DEFER_AFTER in the environment: measurements)
   bool flags_on_caller = true;   // phase-word path, no view records in the bookkeeping launch (N > 3): the main envs' bookkeeping runs on the caller's stream
+  bool flags_in_view = true;  // phase-word path: the list chains' bookkeeping runs in workgroups of the chains' raster launches (McrParams::flags_blocks)
   bool soft_token = false;    // this handle is its device's one phase-word handle (mcr_create)
   bool soft_sync = false;     // the step's streams meet through phase words in device memory (mcr_kernels.h: mcr_post / mcr_await) instead of events
   bool stop_events = true;    // events completed by the launches they mark (hipExtLaunchKernelGGL) instead of marker packets behind them
@@ -234,6 +235,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
         for (hipEvent_t* e : {&h->ev_fork, &h->ev_join, &h->ev_fork2, &h->ev_join2, &h->ev_col, &h->ev_chain}) (void)hipEventCreateWithFlags(e, evf);
         if (const char* g = getenv("MCR_DEFER_AFTER")) { const int v = atoi(g); if (v >= 1 && v < 60) h->defer_after = v; }
         if (const char* g = getenv("MCR_FLAGS_ON_CALLER")) h->flags_on_caller = atoi(g) != 0;
+        if (const char* g = getenv("MCR_FLAGS_IN_VIEW")) h->flags_in_view = atoi(g) != 0;
         if (const char* g = getenv("MCR_STOP_EVENTS")) h->stop_events = atoi(g) != 0;
         h->soft_sync = kernels_overlap(h->s_defer, h->s_side);     // (a waiting kernel needs the kernels it waits for to run beside it)
         if (const char* g = getenv("MCR_MERGE_FLAGS_VIEWPREP")) h->merge_flags_viewprep = atoi(g) != 0;
@@ -344,7 +346,7 @@ static void launch_view(mcr_env* h, int kid, int slots, hipStream_t st, const Mc
   if (tm) { tl.id = kid; tl.a = get_event(h); tl.b = get_event(h); (void)hipEventRecord(tl.a, st); }
   // (list launches: with more than two cars per env the contact list is long — N = 8: ~340 envs x 8 views per step — and 128
   // workgroups would draw ~20 views each, one after the other, at the end of the side stream's chain)
-  if (P.role >= 2) { McrParams Q = P; Q.split_views = h->split_views ? 1 : 0; mcr_view_launch(2, list_grid(slots * (Q.split_views ? P.N : 1), h->list_view_grid), st, Q, h->view_stamps, only_just_reset, stop); }
+  if (P.role >= 2) { McrParams Q = P; Q.split_views = h->split_views ? 1 : 0; mcr_view_launch(2, list_grid(slots * (Q.split_views ? P.N : 1), h->list_view_grid) + Q.flags_blocks, st, Q, h->view_stamps, only_just_reset, stop); }
   else mcr_view_launch((P.debug & 32) ? 1 : 0, slots, st, P, h->view_stamps, only_just_reset, stop);
   if (tm) { (void)hipEventRecord(tl.b, st); h->pending.push_back(tl); }
 }
@@ -444,8 +446,13 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     P.split = 0;
     P.role = 2;
     LAUNCH_LDS(5, k_list_chain, lg_dyn, 64, col::lds_bytes(N), h->s_side, P, P, fuse_side, lg_dyn);
-    if (view_flags && !fuse_side) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, h->s_side, P);
-    if (draw) launch_view(h, 6, B, h->s_side, P, 0);
+    // (the chains' bookkeeping: workgroups of its own inside the chain's raster launch when there is one, a list launch otherwise)
+    // (beyond four cars per env the lists hold thousands of cars — ~315 contact envs x 8 at N = 8 — and a few 256-thread workgroups
+    // would take them in many rounds at the end of the contact chain, the critical path there; measured N = 2 15.37 -> 15.65 M
+    // env-steps/s, N = 4 11.00 -> 11.07, N = 8 5.47 -> 5.44)
+    const int fiv = (view_flags && draw && h->flags_in_view && N <= 4) ? (N <= 2 ? 8 : 64) : 0;
+    if (view_flags && !fuse_side && !fiv) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, h->s_side, P);
+    if (draw) { McrParams Pv = P; Pv.flags_blocks = fuse_side ? 0 : fiv; launch_view(h, 6, B, h->s_side, Pv, 0); }
     hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, h->s_side, P, (int)W_SIDE);
     P.role = 1;
     P.viewprep_in_flags = (view_flags && draw && h->viewprep_in_flags) ? 1 : 0;
@@ -456,11 +463,11 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
       const int ga = std::min(lg_dyn, MCR_LIST_GRID / 2), gb = P.auto_reset ? lg_col : 0;
       McrParams Pr = P; Pr.role = 4; Pr.list_envs_per_block = 1;
       LAUNCH_LDS(7, k_list_chain, ga + gb, 64, col::lds_bytes(N), st, P, Pr, fuse_resume, ga);
-      if (view_flags && !fuse_resume) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, st, P);
+      if (view_flags && !fuse_resume && !fiv) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, st, P);
       // Beyond three cars per env the third stream's chain (bookkeeping of B*N cars, then B*N views) is the longer one and the caller's
       // has slack: the main envs' bookkeeping — which the raster does not depend on — moves here, between the resume chain and its raster
       if (flags_on_caller) { McrParams Pm = P; Pm.role = 1; hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, st, Pm); }
-      if (draw) { McrParams Pv = P; Pv.role = P.auto_reset ? 5 : 3; Pv.await_tail = 1; launch_view(h, 7, B, st, Pv, 0); }     // ... and the step's join
+      if (draw) { McrParams Pv = P; Pv.role = P.auto_reset ? 5 : 3; Pv.await_tail = 1; Pv.flags_blocks = fuse_resume ? 0 : fiv; launch_view(h, 7, B, st, Pv, 0); }     // ... and the step's join
     }
     P.role = 1;
     hipLaunchKernelGGL(k_await, dim3(1), dim3(64), 0, h->s_defer, P, (int)W_DYN, cc ? (int)W_COL : -1);

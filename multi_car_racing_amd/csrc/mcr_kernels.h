@@ -41,6 +41,8 @@ struct McrParams {
                                 // phase: how the step's three streams order their kernels when soft_sync is set (see mcr_post / mcr_await below)
   int32_t soft_sync;            // 1: the streams of the three-chain step meet through sync_words (tiny kernels / kernel prologues that poll) instead
                                 // of events (marker and barrier packets that the command processor evaluates: 4-17 us each on the critical path)
+  int32_t flags_blocks;         // list raster launches: the last `flags_blocks` workgroups of the grid do the bookkeeping (k_flags.h) of the list's cars, a
+                                // wavefront per car, beside the workgroups that draw them — a launch of its own for them sat between a chain and its raster
   int32_t await_tail;           // soft_sync, list raster at the tail of the caller's stream: its first workgroup ends by awaiting W_SIDE and W_MAIN — the
                                 // launch completes when the whole step has (a kernel of its own for that costs 5-7 us beside the main raster)
   int32_t cc_mode;              // 1: the main k_dynamics runs CONCURRENTLY with k_collide pass 0 (three-chain step): it finds the envs whose

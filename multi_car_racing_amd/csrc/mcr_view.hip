@@ -5,6 +5,8 @@
 // kernels keep the default (k_dynamics is 7 us FASTER with the packed forms: fewer instructions on a single wavefront
 // per SIMD).  build.py carries the per-file flags.
 #include "mcr_kernels.h"
+#define MCR_DEVICE_FUNCTIONS_ONLY          // k_flags.h / k_touch.h: the device functions, not the kernels (they live in mcr_hip.hip)
+#include "k_flags.h"
 #include "k_view.h"
 #include <hip/hip_ext.h>
 
