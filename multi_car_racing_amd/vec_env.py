@@ -315,6 +315,13 @@ class VecMultiCarRacing:
         _lib.check(self.L.mcr_debug_read_verdict_mismatches(self.h, _lib.ptr(out)), "mcr_debug_read_verdict_mismatches")
         return int(out[0])
 
+    def status_words(self):
+        """cumulative status words of include/mcr.h `mcr_status`: [0] in-kernel waits given up, [1] touch-verdict mismatches,
+        [2] car<->car manifold overflows, [3] begin-event queue overflows (all 0 in a healthy rollout; does not synchronise)"""
+        out = np.zeros(8, np.uint32)
+        _lib.check(self.L.mcr_status(self.h, _lib.ptr(out), 8), "mcr_status")
+        return out
+
     def rollout_stats(self, reset=False):
         """(episodes finished, sum of their returns over all agents) accumulated on the device; synchronises."""
         out = np.zeros(2)
