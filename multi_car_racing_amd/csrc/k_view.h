@@ -1,29 +1,29 @@
 // k_view.h — one 256-thread workgroup per env, drawing its N agent views one after the other: the 96x96 ego-frame
 // software rasteriser that replaces pyglet/OpenGL (multi_car_racing.py:511-604, 613-674; gym Car.draw).  What the views
 // of an env share — episode slot header, tile flags, the road quads in L1/L2 — is fetched once per workgroup.
-// (The backward/on-grass bookkeeping of :446-495 that round 1 computed in here is k_flags.h now.)
+// (The backward/on-grass bookkeeping of :446-495 is k_flags.h.)
 //
-// Round-2 design: a SPAN rasteriser.  Round 1 tested every polygon of a bin list against every pixel of its 8x16 bin
-// (64 k pixel tests per view for ~4 k covered pixels) and was issue-bound on three pipes at once (SALU list walking,
-// VALU edge functions, broadcast LDS reads; profiles/r02_ubench_issue_rates.txt).  Here the work is proportional to what
-// is actually drawn:
-//   1. candidates, in rounds of 248 (one thread each): the road_poly quads (read once, coalesced) and the view's
-//      "special" polygons — car polygons k_dynamics prepared, gauges, flag, the light grass squares the viewport can
-//      see.  A thread transforms its polygon, culls it exactly (does its bbox hold a pixel centre?) and, if it survives,
-//      builds a 48-byte record in its own slot: the polygon is scanned along its LONGER bounding-box axis (rows or
-//      columns), so a scan line crosses it in a short span; per edge the span bound is affine in the line coordinate,
-//      bound(v) = s*v + c, stored once as a lower and once as an upper bound (+-1e30 when the edge is of the other
-//      kind), so a span end is a max / min of four FMAs — no per-pixel edge tests at all.  No compaction, no atomics:
-//      a culled slot simply has zero lines.  The next round's HBM data is requested before this round's spans are drawn;
-//   2. tasks: a block-wide prefix sum over the slots' line counts lays out (record, line) tasks, 64 per wavefront,
+// A SPAN rasteriser (round 2), laid out in round 4 for FOUR workgroups per CU (<= 40,960 B of LDS, <= 128 VGPRs):
+//   1. candidates, in rounds of 168 slots (one thread each; one round is the rule): the road_poly quads of the blocks the
+//      viewport can see (read once, coalesced) and the view's "special" polygons — the Car.draw polygons of the cars it can
+//      see, the light grass squares, the playfield quad when the view leaves it, the part of a gauge that is taller than the
+//      HUD bar.  A thread transforms its polygon, culls it exactly (does its bbox hold a pixel centre?) and, if it
+//      survives, builds a 32-byte record in its own slot: the polygon is scanned along its LONGER bounding-box axis (rows
+//      or columns), so a scan line crosses it in a short span; per edge the span bound is affine in the line coordinate,
+//      bound(v) = s*v + c, and a bit of the record's meta word says whether the edge bounds the span from below or from
+//      above — a span end is a max / min of four FMAs, no per-pixel edge tests.  No compaction, no atomics: a culled slot
+//      has zero lines.  The next round's (or view's) HBM data is requested before this round's spans are drawn;
+//   2. tasks: a prefix sum over the slots' line counts lays out (record, group of 4 lines) tasks, 64 lines per wavefront trip
 //      whatever the polygon sizes are;
-//   4. fill: each lane computes its line's span [lo, hi] and writes the polygon's draw key over it with LDS ds_max_u32 —
-//      "highest draw key wins" is the painter's order of the reference (playfield, grass squares, road_poly in creation
-//      order, cars, HUD), and the palette index rides in the key's low bits;
-//   5. resolve: key buffer -> palette -> packed RGB, 4 pixels = 12 bytes per lane, contiguous dwordx3 stores with the
-//      vertical flip of :602 folded into the address.
-// The playfield base colour and the HUD bar are part of the key-buffer clear; the score label (:665-666) is stamped by
-// one wavefront with the top key.  52 KB of LDS per workgroup -> 3 workgroups per CU (LDS is granted in 2 KB steps).
+//   3. fill: each lane computes its line's span [lo, hi] and writes rank << 24 | RGB over it with LDS ds_max_u32 — "highest
+//      rank wins" is the painter's order of the reference (playfield, grass squares, road_poly in creation order, cars,
+//      gauges) and the winner's colour needs no lookup;
+//   4. resolve: 4 key words -> 3 byte permutes -> 12 bytes per lane as one streaming dwordx3 store, the vertical flip of
+//      :602 folded into the address.
+// The key buffer holds the 84 SCENE rows only (32,592 B).  The 12 rows below them are the HUD (window y < 100: the black
+// quad of :638-642 overdraws whatever the scene put there): the fourth wavefront, which has no candidate slots, composes
+// them analytically — bar, the 7 gauges in draw order, score label (:665-666), backwards flag — and stores them straight
+// into the frame while the other three set their candidates up (hud_rows below).
 // Sampling rule: pixel centres; a centre belongs to a convex polygon iff it lies inside every edge (closed).  Span
 // ends are computed by division instead of evaluating the edge function at the centre; the two agree except for
 // centres within ~1e-5 px of an edge — inside the 0.02 px band in which the oracle declares a pixel ambiguous.
@@ -33,63 +33,137 @@
 namespace view {
 
 constexpr int KS = 97;                 // key-buffer row stride in words: odd, so that a column of pixels walks all LDS banks
-constexpr int RC = 248;                // candidate slots (= record slots) per round
-constexpr int TASK4_CAP = 592;         // task entries per chunk; an entry covers 4 consecutive scan lines of one record
+constexpr int ROWS = 84;               // scene rows of the key buffer: GL rows 12 .. 95 (row 0 of the buffer = GL row 12)
+constexpr int HUD_ROWS = 12;           // GL rows 0 .. 11 = array rows 84 .. 95: hud_rows()
+constexpr int RC = 168;                // candidate slots (= record slots) per round: wavefronts 0, 1 and the first 40 lanes of wavefront 2
+constexpr int TASK4_CAP = 320;         // task entries per chunk; an entry covers 4 consecutive scan lines of one record
+constexpr int KEYW4 = ROWS * KS / 4;   // the key buffer in 16-byte units
+static_assert(ROWS * KS % 4 == 0, "the key buffer is cleared in 16-byte units");
 constexpr float BIG = 1e30f;
 constexpr int NBLK = MCR_QUAD_CAP / MCR_QBLK;   // road_poly culling blocks per track
+constexpr float CAR_RADIUS = 4.5f;     // world units around the middle of the hull's 8-gon that hold every Car.draw polygon: the farthest
+                                       // hull corner is 3.46 away, the farthest wheel corner 3.07 (+ a unit for a joint stretched by a crash)
 // A pixel of the key buffer is rank << 24 | RGB: "highest rank wins" (ds_max_u32) is the painter's order of the reference
 // and the winner's colour needs no lookup.  Ranks: the playfield quad, the light grass squares, then the candidates in
-// slot order (road_poly entries in creation order, cars, gauges, flag: RANK_SLOT0 + slot), the score label on top.
+// slot order (road_poly entries in creation order, cars, tall gauges: RANK_SLOT0 + slot).
 // A view that needs several rounds of candidates flattens what is drawn so far to RANK_FLAT before each further round.
-enum { RANK_BASE = 0, RANK_PLAYFIELD = 1, RANK_GRASS = 2, RANK_FLAT = 3, RANK_SLOT0 = 4, RANK_LABEL = 255 };
-// record key field: palette index [0,5) | rank [5,13) | HUD polygon, not clipped to the scene rows [13]
-__device__ __forceinline__ uint32_t mk_key(int rank, int pal) { return ((uint32_t)rank << 5) | (uint32_t)pal; }
-#define REC_HUD (1u << 13)
-// record meta word: key field [0,16) | row-scan [16] | chained second half in the next slot [17] | first line [18,25) | lines [25,32)
-#define REC_ROW (1u << 16)
-#define REC_CHAIN (1u << 17)
+enum { RANK_BASE = 0, RANK_PLAYFIELD = 1, RANK_GRASS = 2, RANK_FLAT = 3, RANK_SLOT0 = 4 };
+// record meta word: edge i bounds the span from below [i] (else from above), i < 4 | row-scan [4] | chained second half in the
+// next slot [5] | first line [6,13) | lines [13,20)
+#define REC_ROW (1u << 4)
+#define REC_CHAIN (1u << 5)
+#define REC_L0_SHIFT 6
+#define REC_NL_SHIFT 13
 
 // One edge (ax,ay)->(bx,by) of a polygon with orientation sign sg: inside <=> A x + B y + C >= 0.  With u the
 // coordinate along the span and v the line coordinate the edge bounds u from below (Au > 0) or above (Au < 0) by
-// s v + c; an edge parallel to the spans (Au == 0) bounds nothing (the polygon's line range already accounts for it).
-__device__ __forceinline__ void span_edge(float ax, float ay, float bx, float by, float sg, bool row, float& s, float& cl, float& ch) {
+// s v + c; an edge parallel to the spans (Au == 0) bounds nothing (the polygon's line range already accounts for it):
+// it is stored as the lower bound -BIG.  Returns 1 for a lower bound.
+__device__ __forceinline__ uint32_t span_edge(float ax, float ay, float bx, float by, float sg, bool row, float& s, float& c) {
   const float ex = bx - ax, ey = by - ay;
   const float A = -sg * ey, B = sg * ex, C = -(A * ax + B * ay);
   const float Au = row ? A : B, Av = row ? B : A;
   const float r = __builtin_amdgcn_rcpf(Au);
-  const float c = -C * r;
   s = Au != 0.0f ? -Av * r : 0.0f;
-  cl = Au > 0.0f ? c : -BIG;
-  ch = Au < 0.0f ? c : BIG;
+  c = Au != 0.0f ? -C * r : -BIG;
+  return Au < 0.0f ? 0u : 1u;
 }
-// Span record of four consecutive edges v0->v1->v2->v3->v4 of a convex polygon in pixel space that survived the cull with
-// pixel-centre ranges [i0,i1] x [j0,j1] (a quad: v4 = v0; an 8-gon takes two records in adjacent slots, the halves 0..4 and
-// 4..7,0, written by two threads that share the polygon's orientation, scan axis and line range).  `area`: the polygon's
-// signed area x 2.  Returns the scan-axis / line-range bits of the meta word (0: degenerate, nothing to draw).
-__device__ __forceinline__ uint32_t setup_half(const float* x5, const float* y5, float area, int i0, int i1, int j0, int j1,
-                                               float4 (*rdat)[3], int slot) {
+// Span record of four consecutive edges v0->v1->v2->v3->(cx,cy) of a convex polygon in key-buffer space that survived the cull
+// with pixel-centre ranges [i0,i1] x [j0,j1] (a quad: the closing vertex is v0; an 8-gon takes two records in adjacent slots, the
+// halves 0..4 and 4..7,0, written by two threads that share the polygon's orientation, scan axis and line range).  `area`: the
+// polygon's signed area x 2.  Returns the meta word without the chain bit (0: degenerate, nothing to draw).
+__device__ __forceinline__ uint32_t setup_half(const float* px, const float* py, float cx, float cy, float area, int i0, int i1, int j0, int j1,
+                                               float4 (*rdat)[2], int slot) {
   uint32_t meta = 0u;
   if (area != 0.0f) {
     const float sg = area > 0.0f ? 1.0f : -1.0f;
     const bool row = (j1 - j0) >= (i1 - i0);                       // scan along the longer axis: many short spans
     const int l0 = row ? j0 : i0, nl = (row ? j1 : i1) - l0 + 1;
-    float4 S4, L4, H4;
-    span_edge(x5[0], y5[0], x5[1], y5[1], sg, row, S4.x, L4.x, H4.x); span_edge(x5[1], y5[1], x5[2], y5[2], sg, row, S4.y, L4.y, H4.y);
-    span_edge(x5[2], y5[2], x5[3], y5[3], sg, row, S4.z, L4.z, H4.z); span_edge(x5[3], y5[3], x5[4], y5[4], sg, row, S4.w, L4.w, H4.w);
-    rdat[slot][0] = S4; rdat[slot][1] = L4; rdat[slot][2] = H4;
-    meta = (row ? REC_ROW : 0u) | ((uint32_t)l0 << 18) | ((uint32_t)nl << 25);
+    float4 S4, C4;
+    const uint32_t k0 = span_edge(px[0], py[0], px[1], py[1], sg, row, S4.x, C4.x), k1 = span_edge(px[1], py[1], px[2], py[2], sg, row, S4.y, C4.y);
+    const uint32_t k2 = span_edge(px[2], py[2], px[3], py[3], sg, row, S4.z, C4.z), k3 = span_edge(px[3], py[3], cx, cy, sg, row, S4.w, C4.w);
+    rdat[slot][0] = S4; rdat[slot][1] = C4;
+    meta = k0 | (k1 << 1) | (k2 << 2) | (k3 << 3) | (row ? REC_ROW : 0u) | ((uint32_t)l0 << REC_L0_SHIFT) | ((uint32_t)nl << REC_NL_SHIFT);
   }
   return meta;
+}
+// the other lane of an even / odd lane pair (the two halves of an 8-gon sit in such a pair)
+__device__ __forceinline__ float pair_swap(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true)); }
+
+// The backwards flag (:669-674): the triangle (900,30) (925,70) (950,30) in window units = (86.4,3.6) (88.8,8.4) (91.2,3.6) px covers the
+// pixel centres x 87..90 of GL row 4, 87..89 of row 5, 88..89 of row 6 and 88 of row 7; no centre lies within 0.13 px of an edge.
+// As byte masks of the 4-pixel groups 21 (x 84..87) and 22 (x 88..91) for GL row 4 + r4 (tests/test_oracle_pinning.py derives them from the vertices):
+__device__ __forceinline__ uint32_t hud_flag_mask(int cg, int r4) {
+  const uint32_t g21 = r4 < 2 ? 0xff000000u : 0u, g22 = r4 == 0 ? 0x00ffffffu : r4 <= 2 ? 0x0000ffffu : 0x000000ffu;
+  return cg == 21 ? g21 : cg == 22 ? g22 : 0u;
+}
+
+// The 12 HUD rows of a view (render_indicators, :634-674), composed by ONE wavefront and stored straight into the frame (array rows
+// 84..95): black bar, the 7 gauge rectangles of the view record in draw order (a later one overwrites an earlier one), the score label,
+// the backwards flag.  Lanes 0..47: the 4-pixel group lane % 24 of GL rows 2k + lane / 24, k = 0..5.  A pixel is a colour CLASS in a byte
+// (0 black, 1 white, 2 blue, 3 purple, 4 green, 5 red) until three byte permutes turn the four classes of a lane into R, G and B planes.
+__device__ __forceinline__ void hud_rows(const float* __restrict__ vr, const uint8_t* __restrict__ glyphs, uint32_t* __restrict__ frame, const int lane, const bool flag_on) {
+  // score label (:665-666): the glyph cells that 16 x 4 pixel centres (x 1..16, GL rows 4..7: they cover its window box) see, as one bit per lane
+  const int value = UNI(__float_as_int(vr[VP_SCORE]));
+  const unsigned long long lmask = __ballot(label_on(value, ((float)(1 + (lane & 15)) + 0.5f) * (1000.0f / 96.0f), ((float)(4 + (lane >> 4)) + 0.5f) * (800.0f / 96.0f), glyphs));
+  if (lane >= 48) return;
+  const int cg = lane >= 24 ? lane - 24 : lane, rsel = lane >= 24 ? 1 : 0;
+  // x part of the gauges: which of my 4 pixel centres lie in [x0, x1]
+  uint32_t xm[7]; float gy0[7], gy1[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const float x0 = vr[VP_IND + i * 4], x1 = vr[VP_IND + i * 4 + 1];
+    gy0[i] = vr[VP_IND + i * 4 + 2]; gy1[i] = vr[VP_IND + i * 4 + 3];
+    uint32_t m = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float cx = (float)(4 * cg + j) + 0.5f; if (x0 <= cx && cx <= x1) m |= 0xffu << (8 * j); }
+    xm[i] = m;
+  }
+  // label bits of my group: bit (row - 4) * 16 + (x - 1) of lmask, x = 4 cg + j; x = 0 and x > 16 are outside the sampled window
+  const uint32_t lvalid = cg == 0 ? 0xeu : cg < 4 ? 0xfu : cg == 4 ? 0x1u : 0u;
+#pragma unroll
+  for (int k = 0; k < HUD_ROWS / 2; ++k) {
+    const int row = 2 * k + rsel;
+    const float cy = (float)row + 0.5f;
+    uint32_t win = 0u;                                                       // black bar (:638-642)
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {                                            // vertical_ind x 5, horiz_ind x 2 (:643-663)
+      const uint32_t cls = i == 0 ? 0x01010101u : i <= 2 ? 0x02020202u : i <= 4 ? 0x03030303u : i == 5 ? 0x04040404u : 0x05050505u;
+      const uint32_t m = (gy0[i] <= cy && cy <= gy1[i]) ? xm[i] : 0u;
+      win = (win & ~m) | (cls & m);
+    }
+    if (k == 2 || k == 3) {                                                  // GL rows 4..7: label, then flag
+      const int r4 = row - 4;
+      uint32_t nib = cg == 0 ? ((uint32_t)(lmask >> (r4 * 16)) << 1) : (uint32_t)(lmask >> (r4 * 16 + 4 * min(cg, 4) - 1));
+      nib &= lvalid;
+      const uint32_t lm = ((nib * 0x00204081u) & 0x01010101u) * 0xffu;
+      win = (win & ~lm) | (0x01010101u & lm);
+      if (flag_on) {
+        const uint32_t fm = hud_flag_mask(cg, r4);
+        win = (win & ~fm) | (0x02020202u & fm);
+      }
+    }
+    // classes -> planes (table byte = the class's channel value: R 0 255 0 51 0 255, G 0 255 0 0 255 0, B 0 255 255 255 0 0) -> packed RGB
+    const uint32_t R4 = __builtin_amdgcn_perm(0x0000ff00u, 0x3300ff00u, win), G4 = __builtin_amdgcn_perm(0x000000ffu, 0x0000ff00u, win), B4 = __builtin_amdgcn_perm(0u, 0xffffff00u, win);
+    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+    u32x3 wv;
+    wv.x = __builtin_amdgcn_perm(B4, __builtin_amdgcn_perm(G4, R4, 0x01000400u), 0x03040100u);      // R0 G0 B0 R1
+    wv.y = __builtin_amdgcn_perm(B4, __builtin_amdgcn_perm(G4, R4, 0x06020005u), 0x03020500u);      // G1 B1 R2 G2
+    wv.z = __builtin_amdgcn_perm(B4, __builtin_amdgcn_perm(G4, R4, 0x00070300u), 0x07020106u);      // B2 R3 G3 B3
+    __builtin_nontemporal_store(wv, (u32x3*)(frame + (size_t)((95 - row) * 24 + cg) * 3));
+  }
 }
 
 }  // namespace view
 
 // per-phase clock accumulators of thread 0 (the PHASES instantiation, launched when debug bit 32 is set): [view][16] u64,
-// summed over the rounds of the view.  A separate instantiation: the accumulators cost 22 VGPRs the kernel does not have.
+// summed over the rounds of the view.  A separate instantiation: the accumulators cost registers the kernel does not have.
 #define PHASE_ACC(i) do { if constexpr (PHASES) { const unsigned long long now_ = __builtin_readcyclecounter(); pacc[i] += now_ - tprev; tprev = now_; } } while (0)
 
+// Main launches are built for 4 workgroups per CU (16 wavefronts: 128 VGPRs, 40,960 B of LDS); the list launches (a handful of
+// workgroups that walk a list) have registers of their own.
 template <bool PHASES, bool PERSIST>
-__global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned long long* __restrict__ stamps, const int only_just_reset) {
+__global__ __launch_bounds__(VIEW_THREADS, PERSIST ? 3 : 4) void k_view(McrParams p, unsigned long long* __restrict__ stamps, const int only_just_reset) {
   using namespace view;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -159,33 +233,43 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
   int env, P, a_lo;
   const uint8_t* __restrict__ slot;
   { const int k = UNI(__builtin_ctzll(todo)); todo &= todo - 1; env = __builtin_amdgcn_readlane(my_env, k); slot = slot_of(k); a_lo = __builtin_amdgcn_readlane(my_agent, k); }
-  // what a candidate needs from HBM, requested one round ahead
-  struct Raw { float4 a, b, c, d; uint32_t m; };     // quad: a = v0 v1, b = v2 v3, m = meta | car polygon: a..d = 8 vertices, m = vertex count
-  Raw nxt; nxt.a = nxt.b = nxt.c = nxt.d = make_float4(0.0f, 0.0f, 0.0f, 0.0f); nxt.m = 0u;
+  // what a candidate needs from HBM, requested one round ahead: a quad's 4 vertices + meta word, or 4 vertices of a Car.draw polygon +
+  // its vertex count (the 8-gon's two slots fetch vertices 0..3 and 4..7)
+  struct Raw { float4 a, b; uint32_t m; };
+  Raw nxt; nxt.a = nxt.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f); nxt.m = 0u;
   P = (!PERSIST && my_P >= 0) ? my_P : ((const McrSlotHeader*)slot)->P;
   const int dbg = p.debug;
   unsigned long long pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = PHASES ? __builtin_readcyclecounter() : 0ull;
 
-  __shared__ __attribute__((aligned(16))) uint32_t keyb[96 * KS];           // draw key per pixel, GL rows (0 = bottom)
-  __shared__ __attribute__((aligned(16))) float4 rdat[RC][3];               // per record: slopes, lower consts, upper consts of 4 edges
+  __shared__ __attribute__((aligned(16))) uint32_t keyb[ROWS * KS];         // draw key per scene pixel, GL rows from 12 up (row 0 = GL row 12)
+  __shared__ __attribute__((aligned(16))) float4 rdat[RC][2];               // per record: slopes and constants of 4 edges
   __shared__ uint32_t rmeta[RC];
+  __shared__ uint32_t rkey[RC];                                             // rank << 24 | RGB
   __shared__ uint16_t tasks4[TASK4_CAP];                                    // record slot << 5 | group of 4 lines
-  __shared__ uint32_t tfl[MCR_TILE_CAP / 2];                                // the env's tile flags (bit 8 / 24: recoloured)
-  __shared__ uint32_t palc[32];
+  __shared__ unsigned long long trec[(MCR_TILE_CAP / 128) * 2];             // "tile was touched" (:102-104) bit masks: [tile / 128][tile & 1], bit (tile >> 1) & 63
+  __shared__ uint32_t palc[24];
   __shared__ float vrec[2][MCR_VIEWP_FLOATS];                               // view record of the view being drawn / the next one
   __shared__ float glo[20], ghi[20];
   __shared__ uint8_t glyphs[80];
   __shared__ int wsum[4];
   __shared__ uint8_t vblk[2][NBLK];                                         // visible blocks of the view being drawn / the next one
-  __shared__ int nvb[2];
+  __shared__ uint8_t vcar[2][MCR_MAX_AGENTS];                               // visible cars
+  __shared__ int nvb[2], nvc[2];
   static_assert(MCR_TILE_CAP / 2 == VIEW_THREADS, "one tile-flag word per thread");
+  static_assert(view::PAL_COUNT <= 24, "palette copy");
   // Wavefront 3 lists, per view, the road_poly blocks (runs of MCR_QBLK consecutive entries; boxes from the track
   // generator) the scene rectangle (obs x 0..96, y 12..96) can see: only their entries become candidates.  Separating-
   // axis test both ways — the box in pixel space against the rectangle, the rectangle in world space against the box —
-  // with a pixel of slack.
-  auto list_blocks = [&](const uint8_t* __restrict__ sl, int vw, int buf) {
+  // with a pixel of slack.  Lanes 48 .. 48 + N list the cars whose polygons can reach the scene rectangle.
+  auto list_blocks = [&](const uint8_t* __restrict__ sl, int e, int vw, int buf, const int lane) {
     float4 bbox = make_float4(1.0f, 1.0f, -1.0f, -1.0f);
     if (lane < NBLK) bbox = ((const float4*)(sl + MCR_OFF_QBLK))[lane];
+    const int cc = lane - NBLK;
+    float ax = 0.0f, ay = 0.0f;
+    if (cc >= 0 && cc < N) {                                                // the middle of two opposite vertices of the hull's 8-gon (Car.draw polygon 10)
+      const float* __restrict__ cp = p.carpoly + (size_t)(e * N + cc) * MCR_CARPOLY_FLOATS + 10 * 16;
+      ax = 0.5f * (cp[0] + cp[8]); ay = 0.5f * (cp[1] + cp[9]);
+    }
     const float* __restrict__ vp = p.viewp + (size_t)vw * MCR_VIEWP_FLOATS;
     const float c0 = vp[VP_CAM + 0], c1 = vp[VP_CAM + 1], c2 = vp[VP_CAM + 2], c3 = vp[VP_CAM + 3], c4 = vp[VP_CAM + 4], c5 = vp[VP_CAM + 5];
     const float v0 = vp[VP_INV + 0], v1 = vp[VP_INV + 1], v2 = vp[VP_INV + 2], v3 = vp[VP_INV + 3], v4 = vp[VP_INV + 4], v5 = vp[VP_INV + 5];
@@ -202,51 +286,70 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
     const float mx = fabsf(v0) + fabsf(v1) + 0.05f, my = fabsf(v3) + fabsf(v4) + 0.05f;
     const bool vis = bbox.x <= bbox.z && pxh >= -1.0f && pxl <= 97.0f && pyh >= 11.0f && pyl <= 97.0f &&
                      bbox.z >= wxl - mx && bbox.x <= wxh + mx && bbox.w >= wyl - my && bbox.y <= wyh + my;
-    const unsigned long long mask = __ballot(vis);
+    const float cpx = __builtin_fmaf(c0, ax, __builtin_fmaf(c1, ay, c4)), cpy = __builtin_fmaf(c2, ax, __builtin_fmaf(c3, ay, c5));
+    const float rx = CAR_RADIUS * (fabsf(c0) + fabsf(c1)) + 1.0f, ry = CAR_RADIUS * (fabsf(c2) + fabsf(c3)) + 1.0f;
+    const bool cvis = cc >= 0 && cc < N && cpx >= -rx && cpx <= 96.0f + rx && cpy >= 12.0f - ry && cpy <= 96.0f + ry;
+    const unsigned long long mask = __ballot(vis), cmask = __ballot(cvis);
     if (vis) vblk[buf][__popcll(mask & ((1ull << lane) - 1ull))] = (uint8_t)lane;
-    if (lane == 0) nvb[buf] = __popcll(mask);
+    if (cvis) vcar[buf][__popcll(cmask & ((1ull << lane) - 1ull))] = (uint8_t)cc;
+    if (lane == 0) { nvb[buf] = __popcll(mask); nvc[buf] = __popcll(cmask); }
+  };
+  // the env's "tile was touched" flags (tile_flags bit 8: recoloured, :102-104), one bit per tile: thread t holds tiles 2t and 2t + 1
+  auto pack_tile_flags = [&](uint32_t tf) {
+    const unsigned long long me = __ballot((tf & 0x100u) != 0u), mo = __ballot((tf & 0x1000000u) != 0u);
+    if (lane == 0) { trec[wave * 2] = me; trec[wave * 2 + 1] = mo; }
   };
 
   // ---- once per workgroup: palette, glyphs, grass lattice; the first env's tile flags, view record, block list
-  if (tid < 32) palc[tid] = PALETTE_RGB[tid];
+  if (tid < 24) palc[tid] = PALETTE_RGB[tid];
   if (tid >= 128 && tid < 128 + 77) glyphs[tid - 128] = ((const uint8_t*)LABEL_GLYPHS)[tid - 128];
-  tfl[tid] = ((const uint32_t*)(p.tile_flags + (size_t)env * MCR_TILE_CAP))[tid];
+  pack_tile_flags(((const uint32_t*)(p.tile_flags + (size_t)env * MCR_TILE_CAP))[tid]);
   if (tid >= 64 && tid < 64 + MCR_VIEWP_FLOATS) vrec[0][tid - 64] = p.viewp[(size_t)(env * N + a_lo) * MCR_VIEWP_FLOATS + (tid - 64)];
-  if (wave == 3) list_blocks(slot, env * N + a_lo, 0);
+  if (wave == 3) list_blocks(slot, env, env * N + a_lo, 0, lane);
   // grass lattice as the reference builds it (:620-627): f32(k*x) and f32(k*x + k) for x = -20, -18, .., 18
   if (tid >= 224 && tid < 244) { const double k = MCR_PLAYFIELD / 20.0, x = 2.0 * (double)(tid - 224 - 10); glo[tid - 224] = (float)(k * x + 0); ghi[tid - 224] = (float)(k * x + k); }
-  const float kx = 96.0f / 1000.0f, ky = 96.0f / 800.0f;
-  // candidate c of a view (env e, episode slot sl with pe road_poly entries) whose visible blocks are
-  // vblk[buf][0 .. pv / QBLK): road_poly entry or special; `sb`: first candidate index of the view's specials (they sit
-  // at the END of the last round, see below)
+  // Candidates of a view (env e, episode slot sl with pe road_poly entries, visible blocks vblk[buf][0 .. pv / QBLK), visible
+  // cars vcar[buf][0 .. cs / 14)): [0, pv) the road_poly entries of the visible blocks; from `sb` on the specials: 14 slots per
+  // visible car (its 12 Car.draw polygons, world vertices from k_dynamics; the 8-gon hull polygon takes slots 10 + 11, slot 13
+  // is a pad that keeps pairs aligned), the 5 vertical gauges when one of them is taller than the HUD bar, the playfield quad
+  // (only when the view leaves it), the G light grass squares the viewport can see.
   auto quad_of = [&](int c, int buf) -> int { return (int)vblk[buf][c / MCR_QBLK] * MCR_QBLK + (c & (MCR_QBLK - 1)); };
-  auto fetch_raw = [&](int c, int pv, int sb, int buf, const uint8_t* __restrict__ sl, int pe, int e) -> Raw {
-    Raw r; r.a = r.b = r.c = r.d = make_float4(0.0f, 0.0f, 0.0f, 0.0f); r.m = 0u;
+  auto fetch_raw = [&](int c, int pv, int sb, int cs, int buf, const uint8_t* __restrict__ sl, int pe, int e) -> Raw {
+    Raw r; r.a = r.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f); r.m = 0u;
     if (c < pv) {
       const int q = quad_of(c, buf);
       if (q < pe) { r.a = ((const float4*)(sl + MCR_OFF_QA))[q]; r.b = ((const float4*)(sl + MCR_OFF_QB))[q]; r.m = ((const uint32_t*)(sl + MCR_OFF_QMETA))[q]; }
-    } else if (c >= sb && c - sb < 14 * N) {
-      const int cc = (c - sb) / 14, sl14 = (c - sb) - cc * 14;
-      const int j = sl14 < 11 ? sl14 : sl14 - 1;                            // slot 11 sets up the second half of polygon 10 (the 8-gon): same data; slot 13 is a pad
+    } else if (c >= sb && c - sb < cs) {
+      const int vc = (c - sb) / 14, sl14 = (c - sb) - vc * 14;
       if (sl14 != 13) {
-        const float* __restrict__ cp = p.carpoly + (size_t)(e * N + cc) * MCR_CARPOLY_FLOATS;
-        const float4* cv = (const float4*)(cp + j * 16);
-        r.a = cv[0]; r.b = cv[1]; r.c = cv[2]; r.d = cv[3];
+        const int j = sl14 < 11 ? sl14 : sl14 - 1;                          // slot 11 sets up the second half of polygon 10 (the 8-gon): its vertices 4..7
+        const float* __restrict__ cp = p.carpoly + (size_t)(e * N + (int)vcar[buf][vc]) * MCR_CARPOLY_FLOATS;
+        const float4* cv = (const float4*)(cp + j * 16) + (sl14 == 11 ? 2 : 0);
+        r.a = cv[0]; r.b = cv[1];
         r.m = (uint32_t)__float_as_int(cp[MCR_CARPOLY_NOFF + j]);
       }
     }
     return r;
   };
-
-  // slot layout of a view's specials (see the candidate phase): spread over the wavefronts when the view fits one round
-  auto spread_layout = [&](int pv, int f, int g) -> bool { return N <= 4 && pv <= 128 - 14 * N && g <= 56 && f - 14 * N <= 64; };
-  auto special_of = [&](int c, bool spread, int sb, int f, int g) -> int {   // candidate c -> index among the view's specials, or -1
-    if (!spread) return (c >= sb && c - sb < f + g) ? c - sb : -1;
-    const int nh = f - 14 * N;                                              // gauges, flag [, playfield]
-    if (c >= sb && c < 128) return c - sb;
-    if (c >= 192 - nh && c < 192) return 14 * N + c - (192 - nh);
-    if (c >= 248 - g && c < 248) return f + c - (248 - g);
-    return -1;
+  // The slot layout of a view.  When the road quads and the cars fit the first two wavefronts and the rest the 40 slots of the
+  // third (the rule once the camera has zoomed in) the cars END at slot 128 and gauges / playfield / grass start there — every
+  // wavefront then runs one or two kinds of candidate, not all of them one after the other; otherwise the specials are contiguous
+  // at the end of the last round (they land on the wavefronts the quads leave idle).
+  struct Layout { int pv, cs, tg, f, g, nround, sb; };
+  auto layout_of = [&](int buf) -> Layout {
+    const float* __restrict__ v = vrec[buf];
+    Layout L;
+    L.pv = UNI(nvb[buf]) * MCR_QBLK;
+    L.cs = (dbg & 4) ? 0 : UNI(nvc[buf]) * 14;
+    L.tg = UNI(__float_as_int(v[VP_HUDTOP])) > UNI(__float_as_int(13.0f)) ? 5 : 0;      // (positive floats order like their bit patterns)
+    L.f = L.cs + L.tg + (UNI(__float_as_int(v[VP_GRASS + 4])) ? 0 : 1);                 // + the playfield quad
+    L.g = UNI(__float_as_int(v[VP_GRASS + 1])) * UNI(__float_as_int(v[VP_GRASS + 3]));
+    const int nspec = (L.f + L.g + 1) & ~1;                                 // even: the 8-gon's slot pair never straddles two rounds
+    L.nround = (L.pv + nspec + RC - 1) / RC;
+    const bool spread = L.pv + L.cs <= 128 && L.f - L.cs + L.g <= RC - 128;
+    L.sb = spread ? 128 - L.cs : L.nround * RC - nspec;
+    if (spread) L.nround = 1;
+    return L;
   };
   int vs = 0;                                                               // views this workgroup has drawn
 #pragma nounroll
@@ -267,50 +370,44 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
     const bool nv_ok = !last || has_next;
     const int env_v = last ? env_n : env, vw_v = last ? env_n * N + a_lo_n : vw + 1;
     const uint8_t* __restrict__ slot_v = last ? slot_n : slot;
+    // the view's own copy of the thread index: what the phases derive from it (key-buffer addresses of clear and resolve, frame offsets,
+    // the HUD's column masks) is computed where it is used instead of being hoisted out of the view loop and kept in 20 VGPRs across it
+    int tl = tid; asm volatile("" : "+v"(tl));
+    const int ll = tl & 63;
     PHASE_ACC(0);
     __syncthreads();                                                        // this view's record and block list are in LDS; the previous view's resolve is through with the key buffer
     PHASE_ACC(1);
-    if (!PERSIST && vs == 0 && tid == 0 && my_P >= 0) p.vorder[blockIdx.x] = -1;   // every wavefront has read the entry: free it for the step after next
-    // the next view's record, block list and (new env) tile flags / entry count travel while this one is drawn
-    if (nv_ok && tid >= 64 && tid < 64 + MCR_VIEWP_FLOATS) vrec[buf ^ 1][tid - 64] = p.viewp[(size_t)vw_v * MCR_VIEWP_FLOATS + (tid - 64)];
-    if (nv_ok && wave == 3) list_blocks(slot_v, vw_v, buf ^ 1);
-    if (last && has_next) { tfl_n = ((const uint32_t*)(p.tile_flags + (size_t)env_n * MCR_TILE_CAP))[tid]; P_nv = ((const McrSlotHeader*)slot_n)->P; }
-    const float m00 = vr[VP_CAM + 0], m01 = vr[VP_CAM + 1], m10 = vr[VP_CAM + 2], m11 = vr[VP_CAM + 3], ctx = vr[VP_CAM + 4], cty = vr[VP_CAM + 5];
-    const uint32_t old_flags = __float_as_uint(vr[VP_OLDFLAGS]);
+    if (!PERSIST && vs == 0 && tl == 0 && my_P >= 0) p.vorder[blockIdx.x] = -1;   // every wavefront has read the entry: free it for the step after next
+    // the next view's record and (new env) tile flags / entry count travel while this one is drawn
+    if (nv_ok && tl >= 64 && tl < 64 + MCR_VIEWP_FLOATS) vrec[buf ^ 1][tl - 64] = p.viewp[(size_t)vw_v * MCR_VIEWP_FLOATS + (tl - 64)];
+    if (last && has_next) { tfl_n = ((const uint32_t*)(p.tile_flags + (size_t)env_n * MCR_TILE_CAP))[tl]; P_nv = ((const McrSlotHeader*)slot_n)->P; }
+    // camera, shifted so that key-buffer row 0 is GL row 12
+    const float m00 = vr[VP_CAM + 0], m01 = vr[VP_CAM + 1], m10 = vr[VP_CAM + 2], m11 = vr[VP_CAM + 3], ctx = vr[VP_CAM + 4], cty = vr[VP_CAM + 5] - (float)HUD_ROWS;
     // grass squares the viewport can see / "is the whole viewport inside the playfield" (k_dynamics, from the inverse camera)
-    const int mu0 = UNI(__float_as_int(vr[VP_GRASS + 0])), nu = UNI(__float_as_int(vr[VP_GRASS + 1])), mv0 = UNI(__float_as_int(vr[VP_GRASS + 2])), nv = UNI(__float_as_int(vr[VP_GRASS + 3]));
+    const int mu0 = UNI(__float_as_int(vr[VP_GRASS + 0])), nu = UNI(__float_as_int(vr[VP_GRASS + 1])), mv0 = UNI(__float_as_int(vr[VP_GRASS + 2]));
     const bool inside_field = UNI(__float_as_int(vr[VP_GRASS + 4])) != 0;
-    // key-buffer clear: HUD bar (window y < 100 = obs rows 0..11, :655-656) and the scene's base colour
+    // key-buffer clear: the scene's base colour
     {
-      const uint32_t kbar = 0u, kbase = inside_field ? ((uint32_t)RANK_PLAYFIELD << 24) | palc[PAL_GRASS0] : 0u;   // black bar / black beyond the playfield
+      const uint32_t kbase = inside_field ? ((uint32_t)RANK_PLAYFIELD << 24) | palc[PAL_GRASS0] : 0u;   // black beyond the playfield
       uint4* k4 = (uint4*)keyb;
-      for (int i = tid; i < 96 * KS / 4; i += VIEW_THREADS) {
-        const uint32_t k = i < 12 * KS / 4 ? kbar : kbase;                  // 12 * 97 = 1164 words = 291 uint4: the split is aligned
-        k4[i] = make_uint4(k, k, k, k);
-      }
+      for (int i = tl; i < KEYW4; i += VIEW_THREADS) k4[i] = make_uint4(kbase, kbase, kbase, kbase);
     }
-    // Candidates of a view: [0, P) the road_poly quads and, right-aligned to the end of the last round (so that they
-    // land on the wavefront the quads leave idle), the specials: 14 slots per car (its 12 Car.draw polygons, world
-    // vertices from k_dynamics; the 8-gon hull polygon takes slots 10+11), 7 gauges, the flag, the playfield quad (only
-    // when the view leaves it), the G light grass squares the viewport can see.
-    const int Pv = UNI(nvb[buf]) * MCR_QBLK;                                // road_poly candidates: the entries of the visible blocks
-    const int G = nu * nv;
-    const int F = 14 * N + 8 + (inside_field ? 0 : 1);
-    const int nspec = (F + G + 1) & ~1;                                     // even: the 8-gon's slot pair never straddles two rounds
-    const int nround = (Pv + nspec + RC - 1) / RC;
-    // A view that fits one round with room to spare (the rule once the camera has zoomed in) SPREADS its specials over
-    // the wavefronts instead: cars end at slot 128 (wavefront 1), gauges / flag / playfield at 192 (wavefront 2), grass at
-    // 248 (wavefront 3) — every wavefront then runs one kind of candidate, not all of them one after the other.
-    const bool spread = spread_layout(Pv, F, G);
-    const int SB = spread ? 128 - 14 * N : nround * RC - nspec;             // first slot of the cars (= of the specials when they are contiguous)
-    if (vs == 0 && tid < RC) nxt = fetch_raw(tid, Pv, SB, buf, slot, P, env);   // later views: requested while the previous one was drawn
+    if (wave == 3) {
+      // ---- the wavefront without candidate slots: the next view's block / car lists, then this view's HUD rows straight into the frame,
+      // while the other three set the first round's candidates up
+      if (nv_ok) list_blocks(slot_v, env_v, vw_v, buf ^ 1, ll);
+      if (!(dbg & 8)) hud_rows(vr, glyphs, (uint32_t*)(p.obs + (size_t)vw * (96 * 96 * 3)), ll, (__float_as_uint(vr[VP_OLDFLAGS]) & 1u) != 0u && p.backwards_flag != 0);
+    }
+    const Layout L = layout_of(buf);
+    const int Pv = L.pv, CS = L.cs, TG = L.tg, F = L.f, G = L.g, nround = L.nround, SB = L.sb;
+    if (vs == 0 && tl < RC) nxt = fetch_raw(tl, Pv, SB, CS, buf, slot, P, env);   // later views: requested while the previous one was drawn
 #pragma nounroll
     for (int rd = 0; rd < nround; ++rd) {
-      const int c = rd * RC + tid;
+      const int c = rd * RC + tl;
       const Raw cur = nxt;
       if (rd > 0) {                                                         // what the earlier rounds drew keeps its colour, below everything to come (but above the grass)
         uint4* k4 = (uint4*)keyb;
-        for (int i = tid; i < 96 * KS / 4; i += VIEW_THREADS) {
+        for (int i = tl; i < KEYW4; i += VIEW_THREADS) {
           uint4 k = k4[i];
           k.x = k.x > (((uint32_t)RANK_FLAT << 24) | 0xffffffu) ? (k.x & 0xffffffu) | ((uint32_t)RANK_FLAT << 24) : k.x;
           k.y = k.y > (((uint32_t)RANK_FLAT << 24) | 0xffffffu) ? (k.y & 0xffffffu) | ((uint32_t)RANK_FLAT << 24) : k.y;
@@ -319,183 +416,163 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
           k4[i] = k;
         }
       }
-      const bool mine = tid < RC;
-      uint32_t my_meta = 0u;                                                // a culled slot has no lines
-      // Every candidate, whatever its kind, is "4 (or 8) vertices in world or pixel space + a key": a short kind-specific head
-      // produces them, ONE common tail transforms, culls and sets the span record up — a wavefront that holds several kinds
-      // of candidates (road quads and cars; gauges; grass) runs the tail once, not once per kind.
-      float wx[8], wy[8];
-      uint32_t key = 0u; int cminY = 12, nn = 0;                            // nn: 0 nothing; 4 / 8 vertices in world space; -4: 4 vertices in pixel space
-      bool half2 = false;                                                   // this slot sets up the SECOND half (edges 4..7) of an 8-gon
-      const int q = (mine && c < Pv) ? quad_of(c, buf) : P;
-      if (q < P) {
-        // ---- road_poly entry
-        const uint32_t meta = cur.m;
-        const uint32_t tile1 = (meta >> 8) & 0x3ffu;
-        if (!(dbg & 18)) {
-          wx[0] = cur.a.x; wy[0] = cur.a.y; wx[1] = cur.a.z; wy[1] = cur.a.w; wx[2] = cur.b.x; wy[2] = cur.b.y; wx[3] = cur.b.z; wy[3] = cur.b.w;
-          uint32_t col = meta & 0xffu;
-          if (tile1 && ((tfl[(tile1 - 1) >> 1] >> (((tile1 - 1) & 1u) * 16u)) & 0x100u)) col = MCR_COL_ROAD0;     // touched tile -> ROAD_COLOR (:102-104)
-          const uint32_t pal = col == MCR_COL_ROAD0 ? PAL_ROAD0 : col == MCR_COL_ROAD1 ? PAL_ROAD1 : col == MCR_COL_ROAD2 ? PAL_ROAD2 : col == MCR_COL_KERB_WHITE ? PAL_WHITE : PAL_RED255;
-          key = mk_key(RANK_SLOT0 + tid, pal); nn = 4;
-        }
-      } else if (const int sidx = mine ? special_of(c, spread, SB, F, G) : -1; sidx >= 0) {
-        // ---- specials
-        if (sidx < 14 * N) {                                                // Car.draw polygon
-          const int cc = sidx / 14, sl = sidx - cc * 14;
-          const int j = sl < 11 ? sl : sl - 1;
-          const int n = (int)cur.m;
-          if (sl != 13 && n > 0 && !(dbg & 4) && (sl != 11 || n > 4)) {
+      int incl = 0, g4 = 0;
+      if (wave != 3) {
+        const bool mine = tl < RC;
+        uint32_t my_meta = 0u, my_key = 0u;                                 // a culled slot has no lines
+        // Every candidate, whatever its kind, is "4 vertices in world or key-buffer space + a rank and a colour": a short kind-specific
+        // head produces them, ONE common tail transforms, culls and sets the span record up — a wavefront that holds several kinds
+        // of candidates runs the tail once, not once per kind.
+        float wx[4], wy[4];
+        int rank = 0, pal = 0, nn = 0;                                      // nn: 0 nothing; 4: vertices in world space; -4: in key-buffer space
+        bool eight = false, half2 = false;                                  // this slot sets up one half of an 8-gon / the SECOND half (edges 4..7)
+        const int q = (mine && c < Pv) ? quad_of(c, buf) : P;
+        if (q < P) {
+          // ---- road_poly entry
+          const uint32_t meta = cur.m;
+          const uint32_t tile1 = (meta >> 8) & 0x3ffu;
+          if (!(dbg & 18)) {
             wx[0] = cur.a.x; wy[0] = cur.a.y; wx[1] = cur.a.z; wy[1] = cur.a.w; wx[2] = cur.b.x; wy[2] = cur.b.y; wx[3] = cur.b.z; wy[3] = cur.b.w;
-            wx[4] = cur.c.x; wy[4] = cur.c.y; wx[5] = cur.c.z; wy[5] = cur.c.w; wx[6] = cur.d.x; wy[6] = cur.d.y; wx[7] = cur.d.z; wy[7] = cur.d.w;
-            uint32_t colr;
-            if (j < 8) colr = (j & 1) ? PAL_WHEELWHITE : PAL_BLACK;
-            else { colr = PAL_CAR0 + (cc & 7); if (p.use_ego_color) colr = (cc == agent) ? PAL_CAR0 + 0 : PAL_CAR0 + 1; }   // :402, :560-563
-            // only HULL_POLY3 (slots 10 + 11) has more than 4 vertices (mcr_create checks); k_dynamics pads to 8.  Both of its
-            // slots carry the key of the FIRST one: the fill reads the second record through the first one's meta word
-            half2 = sl == 11;
-            key = mk_key(RANK_SLOT0 + tid - (half2 ? 1 : 0), colr);
-            nn = (n > 4 && sl >= 10) ? 8 : 4;
+            uint32_t col = meta & 0xffu;
+            if (tile1) {                                                    // touched tile -> ROAD_COLOR (:102-104)
+              const uint32_t t0 = tile1 - 1u;
+              if ((trec[((t0 >> 7) << 1) | (t0 & 1u)] >> ((t0 >> 1) & 63u)) & 1ull) col = MCR_COL_ROAD0;
+            }
+            pal = col == MCR_COL_ROAD0 ? PAL_ROAD0 : col == MCR_COL_ROAD1 ? PAL_ROAD1 : col == MCR_COL_ROAD2 ? PAL_ROAD2 : col == MCR_COL_KERB_WHITE ? PAL_WHITE : PAL_RED255;
+            rank = RANK_SLOT0 + tl; nn = 4;
           }
-        } else if (sidx < F) {
-          const int h = sidx - 14 * N;
-          if (h < 7) {                                                      // gauges (:643-663), already in pixel units
-            const float gx0 = vr[VP_IND + h * 4], gx1 = vr[VP_IND + h * 4 + 1], gy0 = vr[VP_IND + h * 4 + 2], gy1 = vr[VP_IND + h * 4 + 3];
+        } else if (const int sidx = (mine && c >= SB) ? c - SB : -1; sidx >= 0 && sidx < F + G) {
+          // ---- specials
+          if (sidx < CS) {                                                  // Car.draw polygon
+            const int vc = sidx / 14, sl = sidx - vc * 14;
+            const int j = sl < 11 ? sl : sl - 1;
+            const int n = (int)cur.m;
+            if (sl != 13 && n > 0 && (sl != 11 || n > 4)) {
+              wx[0] = cur.a.x; wy[0] = cur.a.y; wx[1] = cur.a.z; wy[1] = cur.a.w; wx[2] = cur.b.x; wy[2] = cur.b.y; wx[3] = cur.b.z; wy[3] = cur.b.w;
+              const int cc = (int)vcar[buf][vc];
+              if (j < 8) pal = (j & 1) ? PAL_WHEELWHITE : PAL_BLACK;
+              else { pal = PAL_CAR0 + (cc & 7); if (p.use_ego_color) pal = (cc == agent) ? PAL_CAR0 + 0 : PAL_CAR0 + 1; }   // :402, :560-563
+              // only HULL_POLY3 (slots 10 + 11) has more than 4 vertices (mcr_create checks); k_dynamics pads to 8.  Both of its
+              // slots carry the rank of the FIRST one: the fill reads the second record through the first one's meta word
+              eight = n > 4 && sl >= 10 && sl <= 11;
+              half2 = sl == 11;
+              rank = RANK_SLOT0 + tl - (half2 ? 1 : 0);
+              nn = 4;
+            }
+          } else if (sidx < CS + TG) {                                      // a vertical gauge (:643-648) taller than the HUD bar: its part in the scene rows
+            const int h = sidx - CS;
+            const float gx0 = vr[VP_IND + h * 4], gx1 = vr[VP_IND + h * 4 + 1], gy0 = vr[VP_IND + h * 4 + 2] - (float)HUD_ROWS, gy1 = vr[VP_IND + h * 4 + 3] - (float)HUD_ROWS;
             if (gx1 > gx0 && gy1 > gy0) {
               wx[0] = gx0; wy[0] = gy0; wx[1] = gx1; wy[1] = gy0; wx[2] = gx1; wy[2] = gy1; wx[3] = gx0; wy[3] = gy1;
-              const uint32_t col = h == 0 ? PAL_WHITE : h <= 2 ? PAL_BLUE255 : h <= 4 ? PAL_PURPLE : h == 5 ? PAL_GREEN255 : PAL_RED255;
-              key = mk_key(RANK_SLOT0 + tid, col) | REC_HUD; nn = -4; cminY = 0;
+              pal = h == 0 ? PAL_WHITE : h <= 2 ? PAL_BLUE255 : PAL_PURPLE;
+              rank = RANK_SLOT0 + tl; nn = -4;
             }
-          } else if (h == 7) {                                              // backwards flag (:669-674): drawn with last step's flag
-            if ((old_flags & 1u) && p.backwards_flag) {
-              wx[0] = 900.0f * kx; wy[0] = 30.0f * ky; wx[1] = 925.0f * kx; wy[1] = 70.0f * ky; wx[2] = 950.0f * kx; wy[2] = 30.0f * ky; wx[3] = wx[2]; wy[3] = wy[2];
-              key = mk_key(RANK_SLOT0 + tid, PAL_BLUE255) | REC_HUD; nn = -4; cminY = 0;
-            }
-          } else {                                                          // playfield quad (:615-619), only when the view leaves it
+          } else if (sidx < F) {                                            // playfield quad (:615-619), only when the view leaves it
             const float PF = (float)MCR_PLAYFIELD;
             wx[0] = -PF; wy[0] = PF; wx[1] = PF; wy[1] = PF; wx[2] = PF; wy[2] = -PF; wx[3] = -PF; wy[3] = -PF;
-            key = mk_key(RANK_PLAYFIELD, PAL_GRASS0); nn = 4;
+            rank = RANK_PLAYFIELD; pal = PAL_GRASS0; nn = 4;
+          } else {                                                          // light grass square (:620-627)
+            const int g = sidx - F, iv = g / nu, iu = g - iv * nu;
+            const int tu = mu0 + iu + 10, tv = mv0 + iv + 10;
+            wx[0] = ghi[tu]; wy[0] = glo[tv]; wx[1] = glo[tu]; wy[1] = glo[tv]; wx[2] = glo[tu]; wy[2] = ghi[tv]; wx[3] = ghi[tu]; wy[3] = ghi[tv];
+            rank = RANK_GRASS; pal = PAL_GRASS1; nn = 4;
           }
-        } else {                                                            // light grass square (:620-627)
-          const int g = sidx - F, iv = g / nu, iu = g - iv * nu;
-          const int tu = mu0 + iu + 10, tv = mv0 + iv + 10;
-          wx[0] = ghi[tu]; wy[0] = glo[tv]; wx[1] = glo[tu]; wy[1] = glo[tv]; wx[2] = glo[tu]; wy[2] = ghi[tv]; wx[3] = ghi[tu]; wy[3] = ghi[tv];
-          key = mk_key(RANK_GRASS, PAL_GRASS1); nn = 4;
         }
-      }
-      // ---- common tail
-      if (nn != 0) {
-        const bool eight = nn == 8;
-        float px[8], py[8];
-        if (nn > 0) {                                                       // camera transform (world -> pixel)
+        // ---- common tail
+        if (nn != 0) {
+          my_key = ((uint32_t)rank << 24) | palc[pal];
+          float px[4], py[4];
+          if (nn > 0) {                                                     // camera transform (world -> key buffer)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { px[i] = __builtin_fmaf(m00, wx[i], __builtin_fmaf(m01, wy[i], ctx)); py[i] = __builtin_fmaf(m10, wx[i], __builtin_fmaf(m11, wy[i], cty)); }
-        } else {
+            for (int i = 0; i < 4; ++i) { px[i] = __builtin_fmaf(m00, wx[i], __builtin_fmaf(m01, wy[i], ctx)); py[i] = __builtin_fmaf(m10, wx[i], __builtin_fmaf(m11, wy[i], cty)); }
+          } else {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { px[i] = wx[i]; py[i] = wy[i]; }
-        }
-        float x0 = fminf(fminf(px[0], px[1]), fminf(px[2], px[3])), x1 = fmaxf(fmaxf(px[0], px[1]), fmaxf(px[2], px[3]));
-        float y0 = fminf(fminf(py[0], py[1]), fminf(py[2], py[3])), y1 = fmaxf(fmaxf(py[0], py[1]), fmaxf(py[2], py[3]));
-        float area = (px[0] * py[1] - px[1] * py[0]) + (px[1] * py[2] - px[2] * py[1]) + (px[2] * py[3] - px[3] * py[2]);
-        float x5[5], y5[5];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { x5[i] = px[i]; y5[i] = py[i]; }
-        x5[4] = px[0]; y5[4] = py[0];
-        if (eight) {
-#pragma unroll
-          for (int i = 4; i < 8; ++i) { px[i] = __builtin_fmaf(m00, wx[i], __builtin_fmaf(m01, wy[i], ctx)); py[i] = __builtin_fmaf(m10, wx[i], __builtin_fmaf(m11, wy[i], cty)); }
-          x0 = fminf(x0, fminf(fminf(px[4], px[5]), fminf(px[6], px[7]))); x1 = fmaxf(x1, fmaxf(fmaxf(px[4], px[5]), fmaxf(px[6], px[7])));
-          y0 = fminf(y0, fminf(fminf(py[4], py[5]), fminf(py[6], py[7]))); y1 = fmaxf(y1, fmaxf(fmaxf(py[4], py[5]), fmaxf(py[6], py[7])));
-          area = (area + (px[3] * py[4] - px[4] * py[3])) + ((px[4] * py[5] - px[5] * py[4]) + (px[5] * py[6] - px[6] * py[5]) + (px[6] * py[7] - px[7] * py[6]) + (px[7] * py[0] - px[0] * py[7]));
-          x5[4] = px[4]; y5[4] = py[4];
-          if (half2) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { x5[i] = px[4 + i]; y5[i] = py[4 + i]; }
-            x5[4] = px[0]; y5[4] = py[0];
+            for (int i = 0; i < 4; ++i) { px[i] = wx[i]; py[i] = wy[i]; }
           }
-        } else area += px[3] * py[0] - px[0] * py[3];
-        int i0, i1, j0, j1;
-        if (centre_range(x0, x1, 0, 95, i0, i1) && centre_range(y0, y1, cminY, 95, j0, j1)) {          // rows < 12: HUD bar
-          const uint32_t geo = setup_half(x5, y5, area, i0, i1, j0, j1, rdat, tid);
-          if (geo && !half2) my_meta = key | geo | (eight ? REC_CHAIN : 0u);
+          float x0 = fminf(fminf(px[0], px[1]), fminf(px[2], px[3])), x1 = fmaxf(fmaxf(px[0], px[1]), fmaxf(px[2], px[3]));
+          float y0 = fminf(fminf(py[0], py[1]), fminf(py[2], py[3])), y1 = fmaxf(fmaxf(py[0], py[1]), fmaxf(py[2], py[3]));
+          float area = (px[0] * py[1] - px[1] * py[0]) + (px[1] * py[2] - px[2] * py[1]) + (px[2] * py[3] - px[3] * py[2]);
+          float cx = px[0], cy = py[0];                                     // the vertex that closes my four edges
+          if (eight) {
+            // the two halves of the 8-gon sit in an even / odd lane pair: the partner's first vertex closes my edges, and bounding box
+            // and area are the whole polygon's (both lanes arrive at the same values: min, max and + commute)
+            cx = pair_swap(px[0]); cy = pair_swap(py[0]);
+            area += px[3] * cy - cx * py[3];
+            x0 = fminf(x0, pair_swap(x0)); x1 = fmaxf(x1, pair_swap(x1)); y0 = fminf(y0, pair_swap(y0)); y1 = fmaxf(y1, pair_swap(y1));
+            area += pair_swap(area);
+          } else area += px[3] * py[0] - px[0] * py[3];
+          int i0, i1, j0, j1;
+          if (centre_range(x0, x1, 0, 95, i0, i1) && centre_range(y0, y1, 0, ROWS - 1, j0, j1)) {
+            const uint32_t geo = setup_half(px, py, cx, cy, area, i0, i1, j0, j1, rdat, tl);
+            // the second half keeps its bound bits (the fill reads them through the first half's chain bit) but has no lines of its own
+            if (geo) my_meta = half2 ? (geo & 0xfu) : geo | (eight ? REC_CHAIN : 0u);
+          }
         }
-      }
-      if (tid < RC) rmeta[tid] = my_meta;
-      // line counts in slot order -> block-wide exclusive prefix sum of the 4-line task groups
-      const int nl = (int)(my_meta >> 25);
-      const int g4 = (nl + 3) >> 2;
-      int incl = g4;
+        if (mine) { rmeta[tl] = my_meta; rkey[tl] = my_key; }
+        // line counts in slot order -> exclusive prefix sum of the 4-line task groups over the three wavefronts
+        const int nl = (int)(my_meta >> REC_NL_SHIFT);
+        g4 = (nl + 3) >> 2;
+        incl = g4;
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-      if (lane == 63) wsum[wave] = incl;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (ll >= o) incl += t; }
+        if (ll == 63) wsum[wave] = incl;
+      }
       PHASE_ACC(2);
       __syncthreads();                                                      // records and line counts of the round are in LDS
       PHASE_ACC(3);
       // next round's candidates (or round 0 of the next agent's view: the same quads): their HBM / L2 data travels
       // while this round's spans are drawn
-      if (tid < RC) {
-        if (rd + 1 < nround) nxt = fetch_raw(c + RC, Pv, SB, buf, slot, P, env);
-        else if (nv_ok) {                                                   // round 0 of the next view (its record and block list are in LDS)
-          const float* __restrict__ vn = vrec[buf ^ 1];
-          const int pvn = UNI(nvb[buf ^ 1]) * MCR_QBLK;
-          const int gn = UNI(__float_as_int(vn[VP_GRASS + 1])) * UNI(__float_as_int(vn[VP_GRASS + 3]));
-          const int fn = 14 * N + 8 + (UNI(__float_as_int(vn[VP_GRASS + 4])) ? 0 : 1);
-          const int nsn = (fn + gn + 1) & ~1;
-          const int sbn = spread_layout(pvn, fn, gn) ? 128 - 14 * N : (pvn + nsn + RC - 1) / RC * RC - nsn;
-          nxt = fetch_raw(tid, pvn, sbn, buf ^ 1, slot_v, last ? UNI(P_nv) : P, env_v);
+      if (tl < RC) {
+        if (rd + 1 < nround) nxt = fetch_raw(c + RC, Pv, SB, CS, buf, slot, P, env);
+        else if (nv_ok) {                                                   // round 0 of the next view (its record, block and car lists are in LDS)
+          const Layout Ln = layout_of(buf ^ 1);
+          nxt = fetch_raw(tl, Ln.pv, Ln.sb, Ln.cs, buf ^ 1, slot_v, last ? UNI(P_nv) : P, env_v);
         }
       }
-      // score label (:665-666): white glyph cells stamped with the top key; 16 x 4 pixel centres cover its window box
-      if (rd + 1 == nround && wave == 2) {
-        const int lx = 1 + (lane & 15), ly = 4 + (lane >> 4);
-        const int value = UNI(__float_as_int(vr[VP_SCORE]));
-        if (label_on(value, ((float)lx + 0.5f) * (1000.0f / 96.0f), ((float)ly + 0.5f) * (800.0f / 96.0f), glyphs))
-          atomicMax(&keyb[ly * KS + lx], ((uint32_t)RANK_LABEL << 24) | 0xffffffu);
-      }
       int off = incl - g4;
-      for (int w = 0; w < 4; ++w) if (w < wave) off += wsum[w];
-      const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+      if (wave >= 1) off += wsum[0];
+      if (wave >= 2) off += wsum[1];
+      const int total = wsum[0] + wsum[1] + wsum[2];
       int t0 = 0;
       do {
         for (int k4 = 0; k4 < g4; ++k4) {
           const int idx = off + k4 - t0;
-          if ((unsigned)idx < (unsigned)TASK4_CAP) tasks4[idx] = (uint16_t)((tid << 5) | k4);
+          if ((unsigned)idx < (unsigned)TASK4_CAP) tasks4[idx] = (uint16_t)((tl << 5) | k4);
         }
         PHASE_ACC(4);
         __syncthreads();
         PHASE_ACC(5);
         const int nlines = min(TASK4_CAP, total - t0) * 4;
-        // Two line tasks per lane and trip: the three dependent LDS reads of a task (task entry -> record meta -> record) are
+        // Two line tasks per ll and trip: the dependent LDS reads of a task (task entry -> record meta -> record) are
         // issued for both before either is used — the phase is bound by that latency chain, not by the arithmetic.  Lanes
         // without a task read entry 0 (harmless) and end up with an empty span.
         for (int i0 = 0; i0 < nlines; i0 += 2 * VIEW_THREADS) {
-          const int iA = i0 + tid, iB = iA + VIEW_THREADS;
+          const int iA = i0 + tl, iB = iA + VIEW_THREADS;
           const bool inA = iA < nlines, inB = iB < nlines;
           const uint32_t eA = tasks4[inA ? iA >> 2 : 0], eB = tasks4[inB ? iB >> 2 : 0];
           const int slA = min((int)(eA >> 5), RC - 1), slB = min((int)(eB >> 5), RC - 1);
           const int kA = (int)((eA & 31u) << 2) | (iA & 3), kB = (int)((eB & 31u) << 2) | (iB & 3);
           const uint32_t mA = rmeta[slA], mB = rmeta[slB];
-          const float4 SA = rdat[slA][0], LA = rdat[slA][1], HA = rdat[slA][2];
-          const float4 SB4 = rdat[slB][0], LB = rdat[slB][1], HB = rdat[slB][2];
-          const uint32_t cA = palc[mA & 31u], cB = palc[mB & 31u];
-          auto span = [&](bool in, uint32_t meta, int sl, int k, const float4 Sl, const float4 Lo, const float4 Hi, uint32_t col,
+          const uint32_t cA = rkey[slA], cB = rkey[slB];
+          const float4 SA = rdat[slA][0], CA = rdat[slA][1];
+          const float4 SB4 = rdat[slB][0], CB = rdat[slB][1];
+          auto bounds = [&](uint32_t kinds, const float4 Sl, const float4 Cn, float v, float& lo, float& hi) {
+            const float b0 = __builtin_fmaf(Sl.x, v, Cn.x), b1 = __builtin_fmaf(Sl.y, v, Cn.y), b2 = __builtin_fmaf(Sl.z, v, Cn.z), b3 = __builtin_fmaf(Sl.w, v, Cn.w);
+            const bool l0 = (kinds & 1u) != 0u, l1 = (kinds & 2u) != 0u, l2 = (kinds & 4u) != 0u, l3 = (kinds & 8u) != 0u;
+            lo = fmaxf(lo, fmaxf(fmaxf(l0 ? b0 : -BIG, l1 ? b1 : -BIG), fmaxf(l2 ? b2 : -BIG, l3 ? b3 : -BIG)));
+            hi = fminf(hi, fminf(fminf(l0 ? BIG : b0, l1 ? BIG : b1), fminf(l2 ? BIG : b2, l3 ? BIG : b3)));
+          };
+          auto span = [&](bool in, uint32_t meta, int sl, int k, const float4 Sl, const float4 Cn, uint32_t col,
                           int& len, int& addr, int& stride, uint32_t& key) {
             len = 0; addr = 0; stride = 1; key = 0u;
-            if (in && k < (int)(meta >> 25)) {
-              const int line = (int)((meta >> 18) & 127u) + k;
+            if (in && k < (int)(meta >> REC_NL_SHIFT)) {
+              const int line = (int)((meta >> REC_L0_SHIFT) & 127u) + k;
               const float v = (float)line + 0.5f;
-              float lo = fmaxf(fmaxf(__builtin_fmaf(Sl.x, v, Lo.x), __builtin_fmaf(Sl.y, v, Lo.y)), fmaxf(__builtin_fmaf(Sl.z, v, Lo.z), __builtin_fmaf(Sl.w, v, Lo.w)));
-              float hi = fminf(fminf(__builtin_fmaf(Sl.x, v, Hi.x), __builtin_fmaf(Sl.y, v, Hi.y)), fminf(__builtin_fmaf(Sl.z, v, Hi.z), __builtin_fmaf(Sl.w, v, Hi.w)));
-              if (meta & REC_CHAIN) {
-                const float4 S2 = rdat[sl + 1][0], L2 = rdat[sl + 1][1], H2 = rdat[sl + 1][2];
-                lo = fmaxf(lo, fmaxf(fmaxf(__builtin_fmaf(S2.x, v, L2.x), __builtin_fmaf(S2.y, v, L2.y)), fmaxf(__builtin_fmaf(S2.z, v, L2.z), __builtin_fmaf(S2.w, v, L2.w))));
-                hi = fminf(hi, fminf(fminf(__builtin_fmaf(S2.x, v, H2.x), __builtin_fmaf(S2.y, v, H2.y)), fminf(__builtin_fmaf(S2.z, v, H2.z), __builtin_fmaf(S2.w, v, H2.w))));
-              }
-              key = ((meta << 19) & 0xff000000u) | col;
               const bool row = (meta & REC_ROW) != 0u;
-              // rows < 12 belong to the HUD: scene polygons stop at y = 12 (row scans are clipped by their line range)
-              const float cmin = (meta & (REC_ROW | REC_HUD)) ? 0.0f : 12.0f;
-              lo = fmaxf(lo, cmin); hi = fminf(hi, 96.0f);
+              float lo = 0.0f, hi = row ? 96.0f : (float)ROWS;              // the scene rectangle
+              bounds(meta, Sl, Cn, v, lo, hi);
+              if (meta & REC_CHAIN) bounds(rmeta[sl + 1], rdat[sl + 1][0], rdat[sl + 1][1], v, lo, hi);
+              key = col;
               const int a = (int)ceilf(lo - 0.5f), b = (int)floorf(hi - 0.5f);    // pixel centres a+.5 .. b+.5 lie in [lo, hi]
               len = b - a + 1;
               addr = (row ? line : a) * KS + (row ? a : line);
@@ -503,11 +580,12 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
             }
           };
           int lenA, addrA, strideA, lenB, addrB, strideB; uint32_t keyA, keyB;
-          span(inA, mA, slA, kA, SA, LA, HA, cA, lenA, addrA, strideA, keyA);
-          span(inB, mB, slB, kB, SB4, LB, HB, cB, lenB, addrB, strideB, keyB);
-          // a lane leaves a loop when its span is drawn (the wavefront iterates to its longest span)
+          span(inA, mA, slA, kA, SA, CA, cA, lenA, addrA, strideA, keyA);
+          span(inB, mB, slB, kB, SB4, CB, cB, lenB, addrB, strideB, keyB);
+          // a ll leaves a loop when its span is drawn (the wavefront iterates to its longest span)
           // (two pixels per trip: the loop's bookkeeping — 3 scalar + 2 vector instructions — is what the phase issues most of;
-          // the second ds_max of an odd span's last trip carries key 0, which changes nothing wherever it lands)
+          // the second ds_max of an odd span's last trip carries key 0, which changes nothing wherever it lands — a column scan's
+          // can land one row behind the buffer, in the records: max(x, 0) = x there as well)
           if (lenA > 0) { int j = 0; do { atomicMax(&keyb[addrA], keyA); atomicMax(&keyb[addrA + strideA], j + 1 < lenA ? keyA : 0u); addrA += 2 * strideA; j += 2; } while (j < lenA); }
           if (lenB > 0) { int j = 0; do { atomicMax(&keyb[addrB], keyB); atomicMax(&keyb[addrB + strideB], j + 1 < lenB ? keyB : 0u); addrB += 2 * strideB; j += 2; } while (j < lenB); }
         }
@@ -517,22 +595,23 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
         t0 += TASK4_CAP;
       } while (t0 < total);
     }
-    // ---- resolve + packed RGB write-out: 4 pixels -> 12 bytes per lane, rows top-down (arr[::-1], :602)
+    // ---- resolve + packed RGB write-out of the scene rows: 4 pixels -> 12 bytes per ll, rows top-down (arr[::-1], :602)
     if (!(dbg & 8)) {
       uint32_t* __restrict__ out = (uint32_t*)(p.obs + (size_t)vw * (96 * 96 * 3));
-      // 9 groups of 4 pixels per thread: the winners' RGB bytes are packed with three byte permutes
-#pragma unroll 3
-      for (int g0 = 0; g0 < 9; ++g0) {
-        const int g = g0 * VIEW_THREADS + tid, r = g / 24, x4 = (g - r * 24) * 4;
-        const uint32_t* kp = &keyb[(95 - r) * KS + x4];
-        const uint32_t c0 = kp[0], c1 = kp[1], c2 = kp[2], c3 = kp[3];
-        uint3 w;
-        w.x = __builtin_amdgcn_perm(c1, c0, 0x04020100u); w.y = __builtin_amdgcn_perm(c2, c1, 0x05040201u); w.z = __builtin_amdgcn_perm(c3, c2, 0x06050402u);
-        // streaming store: the frames of a step (226 MB at B = 4096, N = 2) are written once and read by nobody on the
-        // device — they must not evict the state the step's latency-bound chains live on from L2 / MALL
-        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-        u32x3 wv; wv.x = w.x; wv.y = w.y; wv.z = w.z;
-        __builtin_nontemporal_store(wv, (u32x3*)(out + (size_t)g * 3));
+      // 8 groups of 4 pixels per thread (the last trip: 224 of them): the winners' RGB bytes are packed with three byte permutes
+#pragma unroll 4
+      for (int g0 = 0; g0 < (ROWS * 24 + VIEW_THREADS - 1) / VIEW_THREADS; ++g0) {
+        const int g = g0 * VIEW_THREADS + tl, r = g / 24, x4 = (g - r * 24) * 4;
+        if (g < ROWS * 24) {
+          const uint32_t* kp = &keyb[(ROWS - 1 - r) * KS + x4];
+          const uint32_t c0 = kp[0], c1 = kp[1], c2 = kp[2], c3 = kp[3];
+          // streaming store: the frames of a step (226 MB at B = 4096, N = 2) are written once and read by nobody on the
+          // device — they must not evict the state the step's latency-bound chains live on from L2 / MALL
+          typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+          u32x3 wv;
+          wv.x = __builtin_amdgcn_perm(c1, c0, 0x04020100u); wv.y = __builtin_amdgcn_perm(c2, c1, 0x05040201u); wv.z = __builtin_amdgcn_perm(c3, c2, 0x06050402u);
+          __builtin_nontemporal_store(wv, (u32x3*)(out + (size_t)g * 3));
+        }
       }
     }
     PHASE_ACC(8);
@@ -547,7 +626,7 @@ __global__ __launch_bounds__(VIEW_THREADS, 3) void k_view(McrParams p, unsigned 
   }
   if (!has_next) break;
   // hand-over: every thread is past the last barrier of the view's span fill, nobody reads the tile flags any more
-  env = env_n; slot = slot_n; P = UNI(P_nv); tfl[tid] = tfl_n; a_lo = a_lo_n;
+  env = env_n; slot = slot_n; P = UNI(P_nv); pack_tile_flags(tfl_n); a_lo = a_lo_n;
   }
   join_tail();
 }

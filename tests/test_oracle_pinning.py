@@ -242,3 +242,35 @@ def test_event_order_is_a_function_of_the_fat_aabbs(oracle):
         assert np.array_equal(ea["tile_visited_count"], eb["tile_visited_count"]) and np.array_equal(ea["visited"], eb["visited"])
         assert np.array_equal(a.state()["bodies"], b.state()["bodies"])
     a.close(); b.close()
+
+
+# ----------------------------------------------------------------------------- the raster's hard-wired backwards flag
+def test_hud_flag_masks_follow_from_the_triangle():
+    """k_view.h composes the HUD rows analytically; the backwards flag (mcr.py:669-674: triangle (W-100,30) (W-75,70) (W-50,30) in
+    window units) is a table of byte masks there.  Re-derive the table from the vertices (pixel centres, closed edges) and check
+    that no centre is near an edge — the table is then what any correct rasteriser draws."""
+    import os
+    import re
+    kx, ky = 96 / 1000.0, 96 / 800.0
+    V = np.array([[900 * kx, 30 * ky], [925 * kx, 70 * ky], [950 * kx, 30 * ky]])
+    cover, margin = {}, 1e9
+    for row in range(12):
+        for x in range(96):
+            c = np.array([x + 0.5, row + 0.5])
+            d = []
+            for i in range(3):
+                a, b = V[i], V[(i + 1) % 3]
+                e = b - a
+                d.append(-(e[0] * (c[1] - a[1]) - e[1] * (c[0] - a[0])) / np.hypot(*e))      # + inside (the triangle is clockwise)
+            margin = min(margin, min(abs(t) for t in d))
+            if min(d) >= 0:
+                cover.setdefault(row, []).append(x)
+    assert cover == {4: [87, 88, 89, 90], 5: [87, 88, 89], 6: [88, 89], 7: [88]} and margin > 0.08, (cover, margin)
+    # as byte masks of the 4-pixel groups 21 (x 84..87) and 22 (x 88..91), rows 4 + r4
+    def mask(row, g):
+        return sum(0xff << (8 * (x - 4 * g)) for x in cover.get(row, []) if x // 4 == g)
+    g21 = [mask(4 + r, 21) for r in range(4)]; g22 = [mask(4 + r, 22) for r in range(4)]
+    assert g21 == [0xff000000, 0xff000000, 0, 0] and g22 == [0x00ffffff, 0x0000ffff, 0x0000ffff, 0x000000ff]
+    src = open(os.path.join(os.path.dirname(__file__), "..", "multi_car_racing_amd", "csrc", "k_view.h")).read()
+    m = re.search(r"hud_flag_mask\(int cg, int r4\) \{(.*?)\n\}", src, re.S)
+    assert m and "r4 < 2 ? 0xff000000u : 0u" in m.group(1) and "r4 == 0 ? 0x00ffffffu : r4 <= 2 ? 0x0000ffffu : 0x000000ffu" in m.group(1)
