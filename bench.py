@@ -66,12 +66,20 @@ def cpu_baseline(num_agents, obs):
     v0, s0, d0, t = _cpu_leg(O, envs, num_agents, False, cores, seed, t, 5.0)
     for o in envs:
         o.close()
+    # BASELINE configs[0]: the reference's own CPU-runnable case — ONE env, num_agents=1 (the CarRacing-v0 special case of README:66-71:
+    # use_random_direction=False, backwards_flag=False), state_pixels every step, one thread
+    o1 = O.OracleEnv(1, backwards_flag=False)
+    o1.reset(oracle_episode(O, 1, 12345, 0, use_random_direction=False), render=False)
+    _, _, _, tc = _cpu_leg(O, [o1], 1, True, 1, seed, 0, 0.5)
+    vc, sc, dc, _ = _cpu_leg(O, [o1], 1, True, 1, seed, tc, 3.0)
+    o1.close()
     what = "oracle/mcr_oracle.cpp with OpenMP over envs (CPU restatement; the reference's Box2D+pyglet path is not installable here)"
     return {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{n_envs} envs x {steps} steps, num_agents={num_agents}, obs={'96x96x3' if obs else 'none'}, {what}, "
                       f"{dt:.1f} s wall; host reports {os.cpu_count()} logical CPUs, cgroup/affinity allows {cores}",
             "legs": [{"value": v1, "unit": "env-steps/s", "cores": 1, "sample": f"8 envs x {s1} steps, obs={'96x96x3' if obs else 'none'}, {d1:.1f} s"},
-                     {"value": v0, "unit": "env-steps/s", "cores": cores, "sample": f"{n_envs} envs x {s0} steps, obs=none (physics + bookkeeping only), {d0:.1f} s"}]}
+                     {"value": v0, "unit": "env-steps/s", "cores": cores, "sample": f"{n_envs} envs x {s0} steps, obs=none (physics + bookkeeping only), {d0:.1f} s"},
+                     {"value": vc, "unit": "env-steps/s", "cores": 1, "sample": f"BASELINE configs[0]: 1 env x {sc} steps, num_agents=1, use_random_direction=False, backwards_flag=False, obs=96x96x3, {dc:.1f} s"}]}
 
 
 def _free_port():
@@ -108,6 +116,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event time all three kernels (adds overhead)")
     ap.add_argument("--action-seed", type=int, default=1234)
+    ap.add_argument("--actions", choices=["random", "drive"], default="random", help="random (default): i.i.d. actions over the action space (BASELINE's random-action rollout); "
+                    "drive: gas 1, brake 0, steering noise +-0.1 from the same counter-based stream — cars that actually drive off the grid, lap and collide "
+                    "(what a competent policy's rollout looks like to the contact chain); reported with the contact-list length")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket the raster launch with HIP events (no roofline object; lets --graph 1 replay)")
     ap.add_argument("--emulate-world", type=int, default=0, help="W > 1: ONE GPU, but the host side of a W-rank job on this node: the process is pinned to 1/W of the "
                     "cores the cgroup allows and its track generator takes the threads VecMultiCarRacing gives a rank of a W-rank job; reports "
@@ -183,6 +194,9 @@ def main():
         blk, j = divmod(t, ACT_BLOCK)
         if j == 0:
             env.env.synth_actions(t, seed=args.action_seed, out=act[blk & 1], steps=ACT_BLOCK)
+            if args.actions == "drive":             # three tiny in-place kernels per ACT_BLOCK steps
+                a = act[blk & 1]
+                a[..., 0].mul_(0.1); a[..., 1].fill_(1.0); a[..., 2].zero_()
         return act[blk & 1][j]
     # Steady state before anything is timed: a real rollout has its episodes ending at different steps, not all
     # B TimeLimits expiring in the same step (which would put B host track generations into one burst).  One
@@ -289,14 +303,16 @@ def main():
             "value": m["env_steps"] / m["elapsed_s"], "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": m["elapsed_s"] / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 rigid-body state / f64 tyre model / u8 pixels", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: num_agents=%d, batch=%d envs/GPU, %s, random-action rollout, "
-                                   "TimeLimit 1000 auto-reset incl. host track generation%s" % (N, B, "96x96 RGB obs" if args.obs else "obs=none", ", episode phases staggered (steady state)" if args.stagger else ", all episodes in phase"),
+            "config": {"workload": "BASELINE.json configs[1]: num_agents=%d, batch=%d envs/GPU, %s, %s rollout, "
+                                   "TimeLimit 1000 auto-reset incl. host track generation%s" % (N, B, "96x96 RGB obs" if args.obs else "obs=none", "random-action" if args.actions == "random" else "DRIVING-action (gas 1, brake 0, steer noise +-0.1)", ", episode phases staggered (steady state)" if args.stagger else ", all episodes in phase"),
                        "global_batch": B * world, "parallelism": "env-sharded dp%d (no data-path collective)" % world,
                        "episodes_reset_in_timed_region": m["episodes"], "mean_episode_return_per_env": (m["return_sum"] / m["episodes"]) if m["episodes"] else None,
                        "tracks_generated_on_host_in_timed_region_rank0": generated,
                        "env_steps_frozen_waiting_for_host_rank0": int(env.env.debug_counters()[3] - ctr0[3]),
                        "touch_verdict_mismatches_rank0": env.env.verdict_mismatches(),
-                       "contact_pass_beside_dynamics": bool(env.env.L.mcr_concurrent_collide(env.env.h))},
+                       "contact_pass_beside_dynamics": bool(env.env.L.mcr_concurrent_collide(env.env.h)),
+                       "contact_envs_per_step_rank0": float(env.env.debug_counters()[2] - ctr0[2]) / K,
+                       "deferred_envs_per_step_rank0": float(env.env.debug_counters()[0] - ctr0[0]) / K},
             "roofline": roofline,
         }
         out["config"]["step_blocked_on_refill_s_rank0"] = env.env.blocked_s - blocked0

@@ -23,7 +23,7 @@
 // The key buffer holds the 84 SCENE rows only (32,592 B).  The 12 rows below them are the HUD (window y < 100: the black
 // quad of :638-642 overdraws whatever the scene put there): the fourth wavefront, which has no candidate slots, composes
 // them analytically — bar, the 7 gauges in draw order, score label (:665-666), backwards flag — and stores them straight
-// into the frame while the other three set their candidates up (hud_rows below).
+// into the frame (hud_prep while the other three set their candidates up, hud_store while they lay out the span tasks).
 // Sampling rule: pixel centres; a centre belongs to a convex polygon iff it lies inside every edge (closed).  Span
 // ends are computed by division instead of evaluating the edge function at the centre; the two agree except for
 // centres within ~1e-5 px of an edge — inside the 0.02 px band in which the oracle declares a pixel ambiguous.
@@ -34,7 +34,7 @@ namespace view {
 
 constexpr int KS = 97;                 // key-buffer row stride in words: odd, so that a column of pixels walks all LDS banks
 constexpr int ROWS = 84;               // scene rows of the key buffer: GL rows 12 .. 95 (row 0 of the buffer = GL row 12)
-constexpr int HUD_ROWS = 12;           // GL rows 0 .. 11 = array rows 84 .. 95: hud_rows()
+constexpr int HUD_ROWS = 12;           // GL rows 0 .. 11 = array rows 84 .. 95: hud_prep() / hud_store()
 constexpr int RC = 168;                // candidate slots (= record slots) per round: wavefronts 0, 1 and the first 40 lanes of wavefront 2
 constexpr int TASK4_CAP = 320;         // task entries per chunk; an entry covers 4 consecutive scan lines of one record
 constexpr int KEYW4 = ROWS * KS / 4;   // the key buffer in 16-byte units
@@ -102,54 +102,93 @@ __device__ __forceinline__ uint32_t hud_flag_mask(int cg, int r4) {
 // 84..95): black bar, the 7 gauge rectangles of the view record in draw order (a later one overwrites an earlier one), the score label,
 // the backwards flag.  Lanes 0..47: the 4-pixel group lane % 24 of GL rows 2k + lane / 24, k = 0..5.  A pixel is a colour CLASS in a byte
 // (0 black, 1 white, 2 blue, 3 purple, 4 green, 5 red) until three byte permutes turn the four classes of a lane into R, G and B planes.
-__device__ __forceinline__ void hud_rows(const float* __restrict__ vr, const uint8_t* __restrict__ glyphs, uint32_t* __restrict__ frame, const int lane, const bool flag_on) {
-  // score label (:665-666): the glyph cells that 16 x 4 pixel centres (x 1..16, GL rows 4..7: they cover its window box) see, as one bit per lane
+// What does not depend on the lane's pixels is computed once, by a lane or by the scalar unit: a gauge's pixel-centre ranges by lane i
+// (then broadcast), the label's characters as a uniform BCD word.
+// Two parts: hud_prep (no memory traffic) and hud_store (six streaming stores per lane); the caller consumes its own outstanding loads
+// between them.  On gfx9 stores count in vmcnt like loads: a wait for a load issued BEHIND them would wait for the stores' acknowledgements
+// from a memory system the raster keeps saturated.
+struct HudState { uint32_t xm[7], rm[7], rows_any, lvalid; unsigned long long lmask; int cg, rsel; };
+__device__ __forceinline__ HudState hud_prep(const float* __restrict__ vr, const uint8_t* __restrict__ glyphs, const int lane, const bool flag_on) {
+  HudState H;
+  // ---- gauges (vertical_ind x 5, horiz_ind x 2, :643-663), lane i < 7: columns [a, b1) and rows [ra, rb1) whose pixel centres the rectangle
+  // holds (closed), clipped to the HUD rows, as a | b1 << 8 | row mask << 16 (0 when it holds none)
+  uint32_t gw;
+  {
+    const int i = min(lane, 6);
+    const float x0 = vr[VP_IND + i * 4], x1 = vr[VP_IND + i * 4 + 1], y0 = vr[VP_IND + i * 4 + 2], y1 = vr[VP_IND + i * 4 + 3];
+    const int a = max((int)ceilf(x0 - 0.5f), 0), b1 = min((int)floorf(x1 - 0.5f), 95) + 1;
+    const int ra = max((int)ceilf(y0 - 0.5f), 0), rb1 = min((int)floorf(y1 - 0.5f), HUD_ROWS - 1) + 1;
+    gw = (b1 > a && rb1 > ra) ? (uint32_t)a | ((uint32_t)b1 << 8) | (((1u << rb1) - (1u << ra)) << 16) : 0u;
+  }
+  // ---- score label (:665-666), "%04i" % value: the characters as a uniform BCD word (digit k of |value| in bits [4k, 4k + 4)), then the
+  // glyph cells that 16 x 4 pixel centres (x 1..16, GL rows 4..7: they cover its window box) see, one bit per lane
   const int value = UNI(__float_as_int(vr[VP_SCORE]));
-  const unsigned long long lmask = __ballot(label_on(value, ((float)(1 + (lane & 15)) + 0.5f) * (1000.0f / 96.0f), ((float)(4 + (lane >> 4)) + 0.5f) * (800.0f / 96.0f), glyphs));
-  if (lane >= 48) return;
-  const int cg = lane >= 24 ? lane - 24 : lane, rsel = lane >= 24 ? 1 : 0;
-  // x part of the gauges: which of my 4 pixel centres lie in [x0, x1]
-  uint32_t xm[7]; float gy0[7], gy1[7];
+  const int neg = value < 0 ? 1 : 0;
+  unsigned long long bcd = 0ull; int nd = 0;
+  for (unsigned t = (unsigned)(neg ? -(long long)value : value); ; ) { const unsigned q = t / 10u; bcd |= (unsigned long long)(t - q * 10u) << (4 * nd); ++nd; t = q; if (t == 0u) break; }
+  nd = max(nd, 4 - neg);                                                     // zero padding of %04i (the sign counts)
+  bool lit = false;
+  {
+    const float fx = ((float)(1 + (lane & 15)) + 0.5f) * (1000.0f / 96.0f) - LABEL_X0, fy = (((float)(4 + (lane >> 4)) + 0.5f) * (800.0f / 96.0f) - LABEL_Y0) * (1.0f / LABEL_CELL_H);
+    const int j = (int)floorf(fx * (1.0f / LABEL_ADV));                      // character
+    const int c = (int)floorf((fx - (float)j * LABEL_ADV) * (1.0f / LABEL_CELL_W));
+    if (fx >= 0.0f && fy >= 0.0f && fy < 7.0f && j < nd + neg && c < 5) {
+      const int d = nd - 1 - (j - neg);                                      // digit index, least significant = 0
+      const int g = (neg && j == 0) ? 10 : (int)((bcd >> (4 * max(d, 0))) & 15ull);
+      lit = (((uint32_t)glyphs[g * 7 + 6 - (int)floorf(fy)] >> (4 - c)) & 1u) != 0u;
+    }
+  }
+  H.lmask = __ballot(lit);
+  const int cg = lane >= 24 ? (lane >= 48 ? 23 : lane - 24) : lane;
+  H.cg = cg; H.rsel = lane >= 24 ? 1 : 0;
+  // x part of the gauges: the bytes of my 4 pixels inside [a, b1).  M(k) = the low k bytes = the high word of 0xffffffff << 8k
+  H.rows_any = 0u;
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
-    const float x0 = vr[VP_IND + i * 4], x1 = vr[VP_IND + i * 4 + 1];
-    gy0[i] = vr[VP_IND + i * 4 + 2]; gy1[i] = vr[VP_IND + i * 4 + 3];
-    uint32_t m = 0u;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const float cx = (float)(4 * cg + j) + 0.5f; if (x0 <= cx && cx <= x1) m |= 0xffu << (8 * j); }
-    xm[i] = m;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)gw, i);
+    const int lo = min(max((int)(w & 255u) - 4 * cg, 0), 4), hi = min(max((int)((w >> 8) & 255u) - 4 * cg, 0), 4);
+    const uint32_t mlo = (uint32_t)((0xffffffffull << (8 * lo)) >> 32), mhi = (uint32_t)((0xffffffffull << (8 * hi)) >> 32);
+    H.xm[i] = mhi & ~mlo;
+    H.rm[i] = w >> 16; H.rows_any |= H.rm[i];
   }
+  if (H.lmask || flag_on) H.rows_any |= 0xf0u;
   // label bits of my group: bit (row - 4) * 16 + (x - 1) of lmask, x = 4 cg + j; x = 0 and x > 16 are outside the sampled window
-  const uint32_t lvalid = cg == 0 ? 0xeu : cg < 4 ? 0xfu : cg == 4 ? 0x1u : 0u;
+  H.lvalid = cg == 0 ? 0xeu : cg < 4 ? 0xfu : cg == 4 ? 0x1u : 0u;
+  return H;
+}
+__device__ __forceinline__ void hud_store(const HudState& H, uint32_t* __restrict__ frame, const int lane, const bool flag_on) {
+  if (lane >= 48) return;
+  const int cg = H.cg, rsel = H.rsel;
+  typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 #pragma unroll
   for (int k = 0; k < HUD_ROWS / 2; ++k) {
     const int row = 2 * k + rsel;
-    const float cy = (float)row + 0.5f;
-    uint32_t win = 0u;                                                       // black bar (:638-642)
+    u32x3 wv; wv.x = wv.y = wv.z = 0u;                                       // black bar (:638-642)
+    {                                                                        // (no "nothing is drawn in these two rows" shortcut: the six trips are
+      uint32_t win = 0u;                                                     // independent dependency chains that the scheduler interleaves — branches between them would stop it)
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {                                            // vertical_ind x 5, horiz_ind x 2 (:643-663)
-      const uint32_t cls = i == 0 ? 0x01010101u : i <= 2 ? 0x02020202u : i <= 4 ? 0x03030303u : i == 5 ? 0x04040404u : 0x05050505u;
-      const uint32_t m = (gy0[i] <= cy && cy <= gy1[i]) ? xm[i] : 0u;
-      win = (win & ~m) | (cls & m);
-    }
-    if (k == 2 || k == 3) {                                                  // GL rows 4..7: label, then flag
-      const int r4 = row - 4;
-      uint32_t nib = cg == 0 ? ((uint32_t)(lmask >> (r4 * 16)) << 1) : (uint32_t)(lmask >> (r4 * 16 + 4 * min(cg, 4) - 1));
-      nib &= lvalid;
-      const uint32_t lm = ((nib * 0x00204081u) & 0x01010101u) * 0xffu;
-      win = (win & ~lm) | (0x01010101u & lm);
-      if (flag_on) {
-        const uint32_t fm = hud_flag_mask(cg, r4);
-        win = (win & ~fm) | (0x02020202u & fm);
+      for (int i = 0; i < 7; ++i) {
+        const uint32_t cls = i == 0 ? 0x01010101u : i <= 2 ? 0x02020202u : i <= 4 ? 0x03030303u : i == 5 ? 0x04040404u : 0x05050505u;
+        const uint32_t m = H.xm[i] & (uint32_t)__builtin_amdgcn_sbfe((int)H.rm[i], row, 1);  // all ones iff the gauge holds my row
+        win = (win & ~m) | (cls & m);
       }
+      if (k == 2 || k == 3) {                                                // GL rows 4..7: label, then flag
+        const int r4 = row - 4;
+        uint32_t nib = cg == 0 ? ((uint32_t)(H.lmask >> (r4 * 16)) << 1) : (uint32_t)(H.lmask >> (r4 * 16 + 4 * min(cg, 4) - 1));
+        nib &= H.lvalid;
+        const uint32_t lm = ((nib * 0x00204081u) & 0x01010101u) * 0xffu;
+        win = (win & ~lm) | (0x01010101u & lm);
+        if (flag_on) {
+          const uint32_t fm = hud_flag_mask(cg, r4);
+          win = (win & ~fm) | (0x02020202u & fm);
+        }
+      }
+      // classes -> planes (table byte = the class's channel value: R 0 255 0 51 0 255, G 0 255 0 0 255 0, B 0 255 255 255 0 0) -> packed RGB
+      const uint32_t R4 = __builtin_amdgcn_perm(0x0000ff00u, 0x3300ff00u, win), G4 = __builtin_amdgcn_perm(0x000000ffu, 0x0000ff00u, win), B4 = __builtin_amdgcn_perm(0u, 0xffffff00u, win);
+      wv.x = __builtin_amdgcn_perm(B4, __builtin_amdgcn_perm(G4, R4, 0x01000400u), 0x03040100u);      // R0 G0 B0 R1
+      wv.y = __builtin_amdgcn_perm(B4, __builtin_amdgcn_perm(G4, R4, 0x06020005u), 0x03020500u);      // G1 B1 R2 G2
+      wv.z = __builtin_amdgcn_perm(B4, __builtin_amdgcn_perm(G4, R4, 0x00070300u), 0x07020106u);      // B2 R3 G3 B3
     }
-    // classes -> planes (table byte = the class's channel value: R 0 255 0 51 0 255, G 0 255 0 0 255 0, B 0 255 255 255 0 0) -> packed RGB
-    const uint32_t R4 = __builtin_amdgcn_perm(0x0000ff00u, 0x3300ff00u, win), G4 = __builtin_amdgcn_perm(0x000000ffu, 0x0000ff00u, win), B4 = __builtin_amdgcn_perm(0u, 0xffffff00u, win);
-    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-    u32x3 wv;
-    wv.x = __builtin_amdgcn_perm(B4, __builtin_amdgcn_perm(G4, R4, 0x01000400u), 0x03040100u);      // R0 G0 B0 R1
-    wv.y = __builtin_amdgcn_perm(B4, __builtin_amdgcn_perm(G4, R4, 0x06020005u), 0x03020500u);      // G1 B1 R2 G2
-    wv.z = __builtin_amdgcn_perm(B4, __builtin_amdgcn_perm(G4, R4, 0x00070300u), 0x07020106u);      // B2 R3 G3 B3
     __builtin_nontemporal_store(wv, (u32x3*)(frame + (size_t)((95 - row) * 24 + cg) * 3));
   }
 }
@@ -160,11 +199,16 @@ __device__ __forceinline__ void hud_rows(const float* __restrict__ vr, const uin
 // summed over the rounds of the view.  A separate instantiation: the accumulators cost registers the kernel does not have.
 #define PHASE_ACC(i) do { if constexpr (PHASES) { const unsigned long long now_ = __builtin_readcyclecounter(); pacc[i] += now_ - tprev; tprev = now_; } } while (0)
 
-// Main launches are built for 4 workgroups per CU (16 wavefronts: 128 VGPRs, 40,960 B of LDS); the list launches (a handful of
-// workgroups that walk a list) have registers of their own.
-template <bool PHASES, bool PERSIST>
-__global__ __launch_bounds__(VIEW_THREADS, PERSIST ? 3 : 4) void k_view(McrParams p, unsigned long long* __restrict__ stamps, const int only_just_reset) {
+// Main launches (one env per workgroup) are built for 4 workgroups per CU (16 wavefronts: 128 VGPRs, 40,960 B of LDS); the list launches
+// (LIST: a handful of workgroups that walk a device-side list, with the cars' bookkeeping inlined) have registers of their own.
+// (Round 4 also built the main launch as 1024 workgroups that stay and take envs off a queue in device memory — every view finds its data
+// requested a view ahead, the three dependent round trips to HBM of a workgroup's first view are paid once per workgroup instead of once
+// per env —: every view then costs what the FIRST view of a workgroup costs here (it carries the next view's block list and fetch), and
+// the launch ends with a tail of one env's time (20 us of 80): 102 us instead of 81.  NOTES.md.)
+template <bool PHASES, bool LIST>
+__global__ __launch_bounds__(VIEW_THREADS, LIST ? 3 : 4) void k_view(McrParams p, unsigned long long* __restrict__ stamps, const int only_just_reset) {
   using namespace view;
+  constexpr bool PERSIST = LIST;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = UNI(tid >> 6);
@@ -178,9 +222,9 @@ __global__ __launch_bounds__(VIEW_THREADS, PERSIST ? 3 : 4) void k_view(McrParam
   // Whose business is a work slot?
   //   role >= 2 (side streams): the envs of the contact / deferred lists;  use_vorder (step path): the order k_dynamics
   //   recorded, heavy (zoomed-out) envs first;  role 1: not the envs the side streams draw;  only_just_reset: reset().
-  if (PERSIST) __builtin_amdgcn_s_setprio(3);                               // a few envs beside the main launch that fills every CU: they go first
-  const int vgrid = (int)gridDim.x - (PERSIST ? p.flags_blocks : 0);        // workgroups that draw; the rest: the list's bookkeeping
-  if (PERSIST && (int)blockIdx.x >= vgrid) {
+  if (LIST) __builtin_amdgcn_s_setprio(3);                                  // a few envs beside the main launch that fills every CU: they go first
+  const int vgrid = (int)gridDim.x - (LIST ? p.flags_blocks : 0);           // workgroups that draw; the rest: the list's bookkeeping
+  if (LIST && (int)blockIdx.x >= vgrid) {
     // the bookkeeping of the list's cars (k_flags.h: backward / on-grass flags, the env's touch verdict for the next step), one wavefront
     // per car.  Contact list for the contact chain's raster, deferred list otherwise (the re-spawned envs' cars take none in this step).
     const int32_t* __restrict__ L = p.role == 2 ? p.clist : p.dlist;
@@ -192,9 +236,9 @@ __global__ __launch_bounds__(VIEW_THREADS, PERSIST ? 3 : 4) void k_view(McrParam
   // List launches with `split_views`: a work slot is ONE VIEW (list entry s / N, agent s % N) instead of an env with its N views —
   // the few envs of a list are the tail of a chain on the step's critical path, and their views side by side take half the time
   // of one after the other (what an env's views share is fetched once per view then).
-  const bool split_views = PERSIST && p.split_views != 0;
+  const bool split_views = LIST && p.split_views != 0;
   {
-    const int s = (int)blockIdx.x + (PERSIST ? lane * vgrid : 0);
+    const int s = (int)blockIdx.x + (LIST ? lane * vgrid : 0);
     int e = -1;
     bool ojr = only_just_reset != 0;
     if (p.role == 5) {
@@ -223,9 +267,9 @@ __global__ __launch_bounds__(VIEW_THREADS, PERSIST ? 3 : 4) void k_view(McrParam
     }
     my_env = e;
   }
-  unsigned long long todo = PERSIST ? __ballot(my_env >= 0) : (my_env >= 0 ? 1ull : 0ull);
+  unsigned long long todo = LIST ? __ballot(my_env >= 0) : (my_env >= 0 ? 1ull : 0ull);
   // (soft_sync: the step's join, see McrParams::await_tail)
-  auto join_tail = [&]() { if (PERSIST && p.await_tail && blockIdx.x == 0 && threadIdx.x == 0) { (void)mcr_await(p, W_SIDE); (void)mcr_await(p, W_MAIN); } };
+  auto join_tail = [&]() { if (LIST && p.await_tail && blockIdx.x == 0 && threadIdx.x == 0) { (void)mcr_await(p, W_SIDE); (void)mcr_await(p, W_MAIN); } };
   if (!todo) { join_tail(); return; }
   auto slot_of = [&](int k) -> const uint8_t* {
     return p.slots + ((size_t)__builtin_amdgcn_readlane(my_env, k) * 2 + __builtin_amdgcn_readlane(my_slot, k)) * MCR_SLOT_BYTES;
@@ -237,7 +281,7 @@ __global__ __launch_bounds__(VIEW_THREADS, PERSIST ? 3 : 4) void k_view(McrParam
   // its vertex count (the 8-gon's two slots fetch vertices 0..3 and 4..7)
   struct Raw { float4 a, b; uint32_t m; };
   Raw nxt; nxt.a = nxt.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f); nxt.m = 0u;
-  P = (!PERSIST && my_P >= 0) ? my_P : ((const McrSlotHeader*)slot)->P;
+  P = (!LIST && my_P >= 0) ? UNI(my_P) : ((const McrSlotHeader*)slot)->P;
   const int dbg = p.debug;
   unsigned long long pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = PHASES ? __builtin_readcyclecounter() : 0ull;
 
@@ -257,22 +301,34 @@ __global__ __launch_bounds__(VIEW_THREADS, PERSIST ? 3 : 4) void k_view(McrParam
   __shared__ int nvb[2], nvc[2];
   static_assert(MCR_TILE_CAP / 2 == VIEW_THREADS, "one tile-flag word per thread");
   static_assert(view::PAL_COUNT <= 24, "palette copy");
-  // Wavefront 3 lists, per view, the road_poly blocks (runs of MCR_QBLK consecutive entries; boxes from the track
+  // One wavefront lists, per view, the road_poly blocks (runs of MCR_QBLK consecutive entries; boxes from the track
   // generator) the scene rectangle (obs x 0..96, y 12..96) can see: only their entries become candidates.  Separating-
   // axis test both ways — the box in pixel space against the rectangle, the rectangle in world space against the box —
   // with a pixel of slack.  Lanes 48 .. 48 + N list the cars whose polygons can reach the scene rectangle.
-  auto list_blocks = [&](const uint8_t* __restrict__ sl, int e, int vw, int buf, const int lane) {
-    float4 bbox = make_float4(1.0f, 1.0f, -1.0f, -1.0f);
-    if (lane < NBLK) bbox = ((const float4*)(sl + MCR_OFF_QBLK))[lane];
+  // In two parts, so that what runs between them (the HUD's preparation) covers the loads: lb_load requests a lane's box, a car's anchor and — lanes
+  // 0..11, one float each: vector loads, which unlike scalar ones are not waited for by the first LDS access — the view's camera and its inverse.
+  struct LbRaw { float4 bbox; float a0, a1, a8, a9, cam; };
+  auto lb_load = [&](const uint8_t* __restrict__ sl, int e, int vw, const int lane) -> LbRaw {
+    LbRaw r; r.bbox = make_float4(1.0f, 1.0f, -1.0f, -1.0f); r.a0 = r.a1 = r.a8 = r.a9 = 0.0f;
+    if (lane < NBLK) r.bbox = ((const float4*)(sl + MCR_OFF_QBLK))[lane];
     const int cc = lane - NBLK;
-    float ax = 0.0f, ay = 0.0f;
-    if (cc >= 0 && cc < N) {                                                // the middle of two opposite vertices of the hull's 8-gon (Car.draw polygon 10)
+    if (cc >= 0 && cc < N) {                                                // two opposite vertices of the hull's 8-gon (Car.draw polygon 10)
       const float* __restrict__ cp = p.carpoly + (size_t)(e * N + cc) * MCR_CARPOLY_FLOATS + 10 * 16;
-      ax = 0.5f * (cp[0] + cp[8]); ay = 0.5f * (cp[1] + cp[9]);
+      r.a0 = cp[0]; r.a1 = cp[1]; r.a8 = cp[8]; r.a9 = cp[9];
     }
-    const float* __restrict__ vp = p.viewp + (size_t)vw * MCR_VIEWP_FLOATS;
-    const float c0 = vp[VP_CAM + 0], c1 = vp[VP_CAM + 1], c2 = vp[VP_CAM + 2], c3 = vp[VP_CAM + 3], c4 = vp[VP_CAM + 4], c5 = vp[VP_CAM + 5];
-    const float v0 = vp[VP_INV + 0], v1 = vp[VP_INV + 1], v2 = vp[VP_INV + 2], v3 = vp[VP_INV + 3], v4 = vp[VP_INV + 4], v5 = vp[VP_INV + 5];
+    r.cam = p.viewp[(size_t)vw * MCR_VIEWP_FLOATS + min(lane, 11)];         // VP_CAM (6) then VP_INV (6)
+    return r;
+  };
+  static_assert(VP_CAM == 0 && VP_INV == 6, "lb_load fetches the first 12 floats of a view record");
+  auto lb_finish = [&](const LbRaw& r, int buf, const int lane) {
+    const float4 bbox = r.bbox;
+    const int cc = lane - NBLK;
+    const float ax = 0.5f * (r.a0 + r.a8), ay = 0.5f * (r.a1 + r.a9);       // the middle of the hull
+    const int cam = __float_as_int(r.cam);
+    const float c0 = __int_as_float(__builtin_amdgcn_readlane(cam, 0)), c1 = __int_as_float(__builtin_amdgcn_readlane(cam, 1)), c2 = __int_as_float(__builtin_amdgcn_readlane(cam, 2));
+    const float c3 = __int_as_float(__builtin_amdgcn_readlane(cam, 3)), c4 = __int_as_float(__builtin_amdgcn_readlane(cam, 4)), c5 = __int_as_float(__builtin_amdgcn_readlane(cam, 5));
+    const float v0 = __int_as_float(__builtin_amdgcn_readlane(cam, 6)), v1 = __int_as_float(__builtin_amdgcn_readlane(cam, 7)), v2 = __int_as_float(__builtin_amdgcn_readlane(cam, 8));
+    const float v3 = __int_as_float(__builtin_amdgcn_readlane(cam, 9)), v4 = __int_as_float(__builtin_amdgcn_readlane(cam, 10)), v5 = __int_as_float(__builtin_amdgcn_readlane(cam, 11));
     float pxl = BIG, pxh = -BIG, pyl = BIG, pyh = -BIG, wxl = BIG, wxh = -BIG, wyl = BIG, wyh = -BIG;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -305,7 +361,7 @@ __global__ __launch_bounds__(VIEW_THREADS, PERSIST ? 3 : 4) void k_view(McrParam
   if (tid >= 128 && tid < 128 + 77) glyphs[tid - 128] = ((const uint8_t*)LABEL_GLYPHS)[tid - 128];
   pack_tile_flags(((const uint32_t*)(p.tile_flags + (size_t)env * MCR_TILE_CAP))[tid]);
   if (tid >= 64 && tid < 64 + MCR_VIEWP_FLOATS) vrec[0][tid - 64] = p.viewp[(size_t)(env * N + a_lo) * MCR_VIEWP_FLOATS + (tid - 64)];
-  if (wave == 3) list_blocks(slot, env, env * N + a_lo, 0, lane);
+  if (wave == 3) lb_finish(lb_load(slot, env, env * N + a_lo, lane), 0, lane);
   // grass lattice as the reference builds it (:620-627): f32(k*x) and f32(k*x + k) for x = -20, -18, .., 18
   if (tid >= 224 && tid < 244) { const double k = MCR_PLAYFIELD / 20.0, x = 2.0 * (double)(tid - 224 - 10); glo[tid - 224] = (float)(k * x + 0); ghi[tid - 224] = (float)(k * x + k); }
   // Candidates of a view (env e, episode slot sl with pe road_poly entries, visible blocks vblk[buf][0 .. pv / QBLK), visible
@@ -355,11 +411,11 @@ __global__ __launch_bounds__(VIEW_THREADS, PERSIST ? 3 : 4) void k_view(McrParam
 #pragma nounroll
   for (;;) {
   // the workgroup's next env, if any
-  const bool has_next = PERSIST && todo != 0ull;
+  const bool has_next = LIST && todo != 0ull;
   int env_n = env, a_lo_n = 0; const uint8_t* __restrict__ slot_n = slot;
-  if (has_next) { const int k = UNI(__builtin_ctzll(todo)); todo &= todo - 1; env_n = __builtin_amdgcn_readlane(my_env, k); slot_n = slot_of(k); a_lo_n = __builtin_amdgcn_readlane(my_agent, k); }
-  const int a_hi = split_views ? a_lo + 1 : N;
   uint32_t tfl_n = 0u; int P_nv = 0;
+  if (LIST && has_next) { const int k = UNI(__builtin_ctzll(todo)); todo &= todo - 1; env_n = __builtin_amdgcn_readlane(my_env, k); slot_n = slot_of(k); a_lo_n = __builtin_amdgcn_readlane(my_agent, k); }
+  const int a_hi = split_views ? a_lo + 1 : N;
 #pragma nounroll
   for (int agent = a_lo; agent < a_hi; ++agent, ++vs) {
     const int vw = env * N + agent;
@@ -377,10 +433,14 @@ __global__ __launch_bounds__(VIEW_THREADS, PERSIST ? 3 : 4) void k_view(McrParam
     PHASE_ACC(0);
     __syncthreads();                                                        // this view's record and block list are in LDS; the previous view's resolve is through with the key buffer
     PHASE_ACC(1);
+    const unsigned long long tview = PHASES ? __builtin_readcyclecounter() : 0ull;
     if (!PERSIST && vs == 0 && tl == 0 && my_P >= 0) p.vorder[blockIdx.x] = -1;   // every wavefront has read the entry: free it for the step after next
     // the next view's record and (new env) tile flags / entry count travel while this one is drawn
-    if (nv_ok && tl >= 64 && tl < 64 + MCR_VIEWP_FLOATS) vrec[buf ^ 1][tl - 64] = p.viewp[(size_t)vw_v * MCR_VIEWP_FLOATS + (tl - 64)];
-    if (last && has_next) { tfl_n = ((const uint32_t*)(p.tile_flags + (size_t)env_n * MCR_TILE_CAP))[tl]; P_nv = ((const McrSlotHeader*)slot_n)->P; }
+    // (requested here, stored to LDS behind the candidates: nobody waits for it)
+    const bool vrec_mine = nv_ok && tl >= 64 && tl < 64 + MCR_VIEWP_FLOATS;
+    float vrec_n = 0.0f;
+    if (vrec_mine) vrec_n = p.viewp[(size_t)vw_v * MCR_VIEWP_FLOATS + (tl - 64)];
+    if (last && has_next) { tfl_n = ((const uint32_t*)(p.tile_flags + (size_t)env_n * MCR_TILE_CAP))[tl]; if (LIST) P_nv = ((const McrSlotHeader*)slot_n)->P; }
     // camera, shifted so that key-buffer row 0 is GL row 12
     const float m00 = vr[VP_CAM + 0], m01 = vr[VP_CAM + 1], m10 = vr[VP_CAM + 2], m11 = vr[VP_CAM + 3], ctx = vr[VP_CAM + 4], cty = vr[VP_CAM + 5] - (float)HUD_ROWS;
     // grass squares the viewport can see / "is the whole viewport inside the playfield" (k_dynamics, from the inverse camera)
@@ -393,10 +453,19 @@ __global__ __launch_bounds__(VIEW_THREADS, PERSIST ? 3 : 4) void k_view(McrParam
       for (int i = tl; i < KEYW4; i += VIEW_THREADS) k4[i] = make_uint4(kbase, kbase, kbase, kbase);
     }
     if (wave == 3) {
-      // ---- the wavefront without candidate slots: the next view's block / car lists, then this view's HUD rows straight into the frame,
-      // while the other three set the first round's candidates up
-      if (nv_ok) list_blocks(slot_v, env_v, vw_v, buf ^ 1, ll);
-      if (!(dbg & 8)) hud_rows(vr, glyphs, (uint32_t*)(p.obs + (size_t)vw * (96 * 96 * 3)), ll, (__float_as_uint(vr[VP_OLDFLAGS]) & 1u) != 0u && p.backwards_flag != 0);
+      // ---- the wavefront without candidate slots, while the other three set the first round's candidates up
+      // The next view's block / car lists and this view's HUD rows, straight into the frame: loads first, their use after the HUD's
+      // preparation, the HUD's stores last.  This block is one long dependency chain (16 ticks per instruction at equal priority, 10 for
+      // the candidate code of the others) and the phase's critical path: it issues first.  (Measured with the lists in wavefront 0, whose
+      // candidates are road quads only: that one then arrives last — 82 instead of 79 us.)
+      __builtin_amdgcn_s_setprio(2);
+      LbRaw lbr; lbr.bbox = make_float4(1.0f, 1.0f, -1.0f, -1.0f); lbr.a0 = lbr.a1 = lbr.a8 = lbr.a9 = lbr.cam = 0.0f;
+      if (nv_ok) lbr = lb_load(slot_v, env_v, vw_v, ll);
+      const bool hud_flag = (__float_as_uint(vr[VP_OLDFLAGS]) & 1u) != 0u && p.backwards_flag != 0;
+      const HudState hud = hud_prep(vr, glyphs, ll, hud_flag);
+      if (nv_ok) lb_finish(lbr, buf ^ 1, ll);
+      if (!(dbg & 8)) hud_store(hud, (uint32_t*)(p.obs + (size_t)vw * (96 * 96 * 3)), ll, hud_flag);
+      __builtin_amdgcn_s_setprio(LIST ? 3 : 0);
     }
     const Layout L = layout_of(buf);
     const int Pv = L.pv, CS = L.cs, TG = L.tg, F = L.f, G = L.g, nround = L.nround, SB = L.sb;
@@ -517,6 +586,8 @@ __global__ __launch_bounds__(VIEW_THREADS, PERSIST ? 3 : 4) void k_view(McrParam
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (ll >= o) incl += t; }
         if (ll == 63) wsum[wave] = incl;
       }
+      if (rd == 0 && vrec_mine) vrec[buf ^ 1][tl - 64] = vrec_n;
+      if constexpr (PHASES) { if (rd == 0 && wave > 0 && ll == 0 && stamps) stamps[(size_t)vw * 16 + 12 + wave] = __builtin_readcyclecounter() - tview; }   // when wavefronts 1..3 reach the barrier
       PHASE_ACC(2);
       __syncthreads();                                                      // records and line counts of the round are in LDS
       PHASE_ACC(3);

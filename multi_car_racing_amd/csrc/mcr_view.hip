@@ -10,7 +10,7 @@
 #include "k_view.h"
 #include <hip/hip_ext.h>
 
-// variant: 0 main launch, 1 main launch with the per-phase clocks (debug bit 5), 2 list launch (persistent workgroups)
+// variant: 0 main launch, 1 main launch with the per-phase clocks (debug bit 5), 2 list launch (persistent workgroups that walk a list)
 // stop: an event the launch itself completes (hipExtLaunchKernelGGL: the dispatch packet's completion signal — no marker packet
 // behind the kernel, which costs ~3 us in-stream and ~3.5 us more on a stream hop; tools/ubench/event_gap.hip), or nullptr
 void mcr_view_launch(int variant, int grid, hipStream_t st, const McrParams& P, unsigned long long* stamps, int only_just_reset, hipEvent_t stop) {
