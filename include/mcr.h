@@ -8,7 +8,7 @@
  * Conventions: plain pointers and sizes only, `int` status returns (0 = MCR_OK, <0 = error enum),
  * nothing throws across the boundary, no exit().  `d_*` pointers are DEVICE pointers on the handle's
  * HIP device; `stream` is a `hipStream_t` passed as `void*` (NULL = the null stream).  Kernels are only
- * enqueued — no hidden device synchronisation in mcr_step / mcr_reset.
+ * enqueued — no hidden device synchronisation in mcr_step / mcr_reset (the one check that needs one is mcr_bind_stream).
  * One handle = one device = one env slice; handles are independent (thread-compatible).
  */
 #ifndef MCR_H
@@ -189,18 +189,32 @@ int mcr_debug_read_verdict_mismatches(mcr_env* h, uint64_t* out1);
 int mcr_concurrent_collide(const mcr_env* h);
 /* How the streams of the three-chain step are ordered (bit mask; 0 for a single-stream handle):
  *   1  phase words in device memory, posted and awaited by kernels (no marker / barrier packets; needs overlapping kernels, like
- *      the concurrent contact pass; MCR_SOFT_SYNC=0 turns it off) — otherwise events;
+ *      the concurrent contact pass; MCR_SOFT_SYNC=0 turns it off) — for steps launched on a caller stream that mcr_bind_stream
+ *      accepted; on any other stream, and without this bit: events;
  *   2  on the event path, events are completed by the launches they mark (hipExtLaunchKernelGGL) rather than recorded behind them
- *      (MCR_STOP_EVENTS=0 turns it off).
- * A wait that gave up (status word 0) puts the handle on the event path for the rest of its life. */
+ *      (MCR_STOP_EVENTS=0 turns it off);
+ *   4  kernels do overlap here, but another live handle of this process holds the device's one phase-word token: this handle
+ *      runs on events (same results, ~0.02 ms more per step).
+ * A wait that gave up (status word 0) puts the handle on the event path for the rest of its life.
+ * gfx950-specific: a phase word is posted with a RELAXED agent-scope store behind the end-of-kernel write-back of the kernels it
+ * follows and polled with RELAXED agent-scope loads (sc1 accesses, served by the memory side — the device's coherence point); the
+ * release / acquire pair the HIP memory model asks for between kernels of different streams costs +12 us per step (measured) and
+ * is not used.  The event path makes no such assumption. */
 int mcr_step_ordering(const mcr_env* h);
+/* Check ONCE whether steps launched on caller stream `stream` may use the phase-word ordering: two probe kernels and device
+ * synchronisations (~1 ms).  Call it when a stream is first used with the handle (VecMultiCarRacing.step does); mcr_step itself never
+ * synchronises: a step on a stream that was not bound, or that the check rejected, orders the internal streams with events. */
+int mcr_bind_stream(mcr_env* h, void* stream);
 /* number of touching car<->car fixture pairs (stored manifolds) per env after the last collide pass */
 int mcr_debug_read_contact_counts(mcr_env* h, int32_t* out /*[num_envs]*/);
-/* Conditions that make results wrong are reported by the kernels in mapped host memory and turned into MCR_ERR_STATE by the
- * next mcr_step (no synchronisation: a condition raised by a step still in flight surfaces one call later).  Words:
- * [0] the main dynamics gave up waiting for the contact pass (three-chain step; the handle then runs the contact pass in front),
- * [1] contact pass vs one-step-ahead touch verdict mismatches, [2] car<->car manifold store / LDS pool overflows (excess
- * dropped), [3] tile begin-event queue overflows.  mcr_status copies the cumulative counts (n_words <= 8). */
+/* Conditions reported by the kernels in mapped host memory (counted on the device, stored with system scope: no PCIe atomics needed),
+ * read by mcr_step without synchronising (a condition raised by a step still in flight surfaces one call later).  Words:
+ * [0] a bounded in-kernel wait gave up (the main dynamics for the contact pass of an env, any kernel for a phase word),
+ * [1] contact pass vs one-step-ahead touch verdict mismatches — FATAL: the next mcr_step returns MCR_ERR_STATE once per change (the
+ *     handle then runs the contact pass in front of the dynamics and orders its streams with events);
+ * [2] car<->car manifold store / LDS pool overflows, [3] tile begin-event queue overflows — DEGRADED: a documented capacity was
+ *     exceeded and the excess dropped; the rollout goes on, the counts are visible here.
+ * mcr_status copies the cumulative counts (n_words <= 8). */
 int mcr_status(mcr_env* h, uint32_t* out, int n_words);
 /* The sensor predicate of the contact pass (Box2D's b2TestOverlap: GJK b2Distance behind mcr.py:428 -> b2Contact::Update) on
  * caller-supplied cases, for differential tests: case i = a tile given by its 4 points quads[i][8] (host, f32; the hull is

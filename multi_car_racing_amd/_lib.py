@@ -58,6 +58,7 @@ SYMBOLS = {
     "mcr_debug_read_verdict_mismatches": (_i, [_vp, _vp]),
     "mcr_concurrent_collide": (_i, [_vp]),
     "mcr_step_ordering": (_i, [_vp]),
+    "mcr_bind_stream": (_i, [_vp, _vp]),
     "mcr_debug_overlap": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
     "mcr_status": (_i, [_vp, _vp, _i]),
     "mcr_debug_read_dynamics_stamps": (_i, [_vp, _vp, _i]),
@@ -76,6 +77,10 @@ _lib = None
 
 class McrError(RuntimeError):
     pass
+
+
+class McrWarning(UserWarning):
+    """the build works, but not the way its numbers were measured (e.g. a second handle on a device orders its streams with events)"""
 
 
 def load():

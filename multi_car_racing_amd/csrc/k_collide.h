@@ -313,7 +313,7 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   // count accumulators; the road_visited bits of the tiles involved live in LDS during the replay.
   {
     int n = evn;
-    if (n > EVQ_CAP) { if (lane == 0) atomicAdd(&p.status[ST_EVENT_OVERFLOW], 1u); n = EVQ_CAP; }
+    if (n > EVQ_CAP) { if (lane == 0) mcr_raise(p, ST_EVENT_OVERFLOW); n = EVQ_CAP; }
     unsigned long long k0 = lane < n ? evq[lane] : 0ull, k1 = lane + 64 < n ? evq[lane + 64] : 0ull;
     const unsigned long long m0 = k0, m1 = k1;
     for (int i = 0; i < n; ++i) {
@@ -447,7 +447,7 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
     __syncthreads();
     const int nn = base < MCR_CC_MAX ? base : MCR_CC_MAX;
     for (int i = lane; i < nn * 16; i += 64) store[4 + (i >> 4) * MCR_CC_WORDS + (i & 15)] = newrec[i >> 4][i & 15];
-    if (lane == 0) { store[0] = (uint32_t)nn; store[1] = base > MCR_CC_MAX ? 1u : 0u; if (base > MCR_CC_MAX) atomicAdd(&p.status[ST_CC_OVERFLOW], 1u); }
+    if (lane == 0) { store[0] = (uint32_t)nn; store[1] = base > MCR_CC_MAX ? 1u : 0u; if (base > MCR_CC_MAX) mcr_raise(p, ST_CC_OVERFLOW); }
     nn_final = nn;
   } else if (lane == 0 && pass == 1) store[0] = 0;
   // side-stream partition: envs whose dynamics chain is going to be long (a touching car<->car pair).  cc_mode: the verdict
@@ -456,7 +456,7 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   if (pass == 0 && p.split && lane == 0) {
     if (nn_final > 0) { p.clist[1 + atomicAdd(&p.clist[0], 1)] = env; atomicAdd(&p.counters[2], 1ull); }
     if (!p.cc_mode) p.part[env] = nn_final > 0 ? 1 : 0;         // the contact pass runs first: it is the one that marks the contact chain's envs
-    else if ((nn_final > 0) != (p.part[env] != 0)) { atomicAdd(&p.counters[4], 1ull); atomicAdd(&p.status[ST_VERDICT], 1u); }
+    else if ((nn_final > 0) != (p.part[env] != 0)) { atomicAdd(&p.counters[4], 1ull); mcr_raise(p, ST_VERDICT); }
   }
   if (pass == 0 && p.cc_mode && !((p.debug & 4096) && env == p.env0)) {     // the main dynamics, running beside this launch, may read this env's results now
     // (debug bit 12: env 0's word is withheld — what a starved contact pass looks like to the dynamics; tests)

@@ -587,7 +587,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
     int incl = need;
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
     pool_base = incl - need;
-    if (agent == 0 && pool_base + ccn > DYN_VC_POOL) { ccn = DYN_VC_POOL - pool_base; if (ccn < 0) ccn = 0; store[1] = 2u; atomicAdd(&p.status[ST_CC_OVERFLOW], 1u); }
+    if (agent == 0 && pool_base + ccn > DYN_VC_POOL) { ccn = DYN_VC_POOL - pool_base; if (ccn < 0) ccn = 0; store[1] = 2u; mcr_raise(p, ST_CC_OVERFLOW); }
     ccn = __shfl(ccn, leader_lane); pool_base = __shfl(pool_base, leader_lane);
     if (ccn > 0) {
 #pragma unroll
@@ -892,7 +892,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
     int spin = 0;
     if (p.debug & 2048) { for (; spin < bound && __hip_atomic_load(&p.collide_epoch[env], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch; ++spin) __builtin_amdgcn_s_sleep(8); }
     else { for (; spin < bound && __hip_atomic_load(&p.collide_epoch[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch; ++spin) __builtin_amdgcn_s_sleep(8); }
-    if (spin == bound) { atomicAdd(&p.counters[5], 1ull); atomicAdd(&p.status[ST_SPIN_GIVEUP], 1u); }
+    if (spin == bound) { atomicAdd(&p.counters[5], 1ull); mcr_raise(p, ST_SPIN_GIVEUP); }
   }
   const bool cc_wait = p.cc_mode && mode == 0 && p.role == 1;
   uint32_t onroad_new = 0;

@@ -51,7 +51,7 @@ struct mcr_env {
   int step_parity;            // which contact-list buffer the next step fills
   int32_t* stage_ids;         // [B] device scratch of mcr_stage_episodes
   hipStream_t s_side, s_defer; // internal streams: the contact envs' chain, the deferred envs' chain
-  hipEvent_t ev_fork, ev_join, ev_fork2, ev_join2, ev_col, ev_chain;
+  hipEvent_t ev_fork, ev_join, ev_fork2, ev_join2, ev_col;
   unsigned long long* view_stamps;   // [BN][16] phase clocks of the rasteriser (debug bit 5)
   // hipGraph of one step (mcr_set_step_graph): one per contact-list parity, re-captured when any argument changes
   struct StepGraph { bool valid; McrParams P; hipStream_t st; int view_flags; hipGraph_t graph; hipGraphExec_t exec; };
@@ -66,20 +66,12 @@ struct mcr_env {
   int simd_count;             // SIMDs of the device (4 per CU)
   int32_t* dev_step_ctr;      // device-side step counter (the epoch of a replayed step graph)
   bool viewprep_in_flags;     // three-chain step: k_viewprep (side stream, beside the bookkeeping) produces the main envs' view records / car polygons
-  bool fuse_side = false, fuse_resume = false;   // the same on the phase-word path, per chain
-  bool fuse_flags;            // N <= 2: the list chains do their cars' bookkeeping themselves (one launch less per chain)
-  bool split_views;           // list raster launches draw one view per workgroup
   int list_view_grid;         // workgroups of a list raster launch
-  bool merge_list_views = true;   // the deferred and the re-spawned envs' frames in one list launch at the tail of the resume chain
-  hipStream_t probed_stream = (hipStream_t)-1;   // the caller's stream the phase-word ordering was last checked against (mcr_step)
-  bool merge_flags_viewprep = true;   // soft_sync path: the main envs' view records and bookkeeping in one launch
-  int defer_after = MCR_DEFER_AFTER;   // position sweeps the main dynamics grants an env before it defers it (MCR_DEFER_AFTER in the environment: measurements)
-  bool flags_on_caller = true;   // phase-word path, no view records in the bookkeeping launch (N > 3): the main envs' bookkeeping runs on the caller's stream
-  bool flags_in_view = true;  // phase-word path: the list chains' bookkeeping runs in workgroups of the chains' raster launches (McrParams::flags_blocks)
+  std::vector<std::pair<hipStream_t, bool>> bound;   // caller streams checked by mcr_bind_stream: may the step order its streams with phase words when launched on this one?
+  bool soft_denied = false;   // kernels overlap here, but another handle of this process holds the device's one phase-word token (mcr_create)
   bool soft_token = false;    // this handle is its device's one phase-word handle (mcr_create)
   bool soft_sync = false;     // the step's streams meet through phase words in device memory (mcr_kernels.h: mcr_post / mcr_await) instead of events
   bool stop_events = true;    // events completed by the launches they mark (hipExtLaunchKernelGGL) instead of marker packets behind them
-  bool resume_on_caller;      // three-chain step: the resume chain keeps the caller's stream, bookkeeping + main raster hop to the third stream
   int chain_grid;             // workgroups of a list chain launch (each walks the list, 2 envs at a time)
   bool vorder_dirty[2];       // the raster order list of that step parity was filled by a step that did not draw
 };
@@ -104,7 +96,7 @@ __global__ void k_probe_wait(int* flag, int* result) {
   for (int i = 0; i < 20000 && !seen; ++i) { seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __builtin_amdgcn_s_sleep(32); }
   *result = seen;
 }
-__global__ void k_step_begin(int32_t* step_ctr) { *step_ctr += 1; }
+__global__ void k_step_begin(int32_t* step_ctr) { *step_ctr = (int32_t)((uint32_t)*step_ctr + 1u); }      // (wraps: epochs are compared as 32-bit distances)
 __global__ void k_probe_set(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 static bool kernels_overlap(hipStream_t sa, hipStream_t sb) {
   int* d = nullptr; int r = 0;
@@ -131,19 +123,8 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   // every further round of the walk adds a whole chain (~300 us) to the side stream: the grid covers 1024 envs in one round;
   // surplus workgroups exit on their first load.
   h->chain_grid = 4 * MCR_LIST_GRID;
-  h->resume_on_caller = true;
   h->viewprep_in_flags = cfg->num_agents <= 3;     // beyond three cars per env the bookkeeping + raster chain is the step's critical path: the epilogue stays in the dynamics (round 3, phase-word path: N = 3 13.4 -> 13.7 M with it, N = 4 10.8 -> 10.6, N = 8 no difference)
-  if (const char* g = getenv("MCR_VIEWPREP_IN_FLAGS")) h->viewprep_in_flags = atoi(g) != 0;
-  h->fuse_flags = true;
-  if (const char* g = getenv("MCR_FUSE_FLAGS")) h->fuse_flags = h->fuse_side = h->fuse_resume = atoi(g) != 0;
-  if (const char* g = getenv("MCR_FUSE_SIDE")) h->fuse_side = atoi(g) != 0;
-  if (const char* g = getenv("MCR_FUSE_RESUME")) h->fuse_resume = atoi(g) != 0;
   h->list_view_grid = cfg->num_agents <= 2 ? MCR_LIST_GRID : 8 * MCR_LIST_GRID;
-  if (const char* g = getenv("MCR_LIST_VIEW_GRID")) { const int v = atoi(g); if (v > 0) h->list_view_grid = v; }
-  h->split_views = true;
-  if (const char* g = getenv("MCR_SPLIT_VIEWS")) h->split_views = atoi(g) != 0;
-  if (const char* g = getenv("MCR_RESUME_ON_CALLER")) h->resume_on_caller = atoi(g) != 0;
-  if (const char* g = getenv("MCR_CHAIN_GRID")) { const int v = atoi(g); if (v > 0) h->chain_grid = v; }
   h->status_host = nullptr; h->step_count = 0; h->bp_fresh = false; memset(h->status_seen, 0, sizeof(h->status_seen));
   { hipDeviceProp_t prop; h->simd_count = (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess ? prop.multiProcessorCount : 256) * 4; }
   for (int i = 0; i < MCR_TIMING_SLOTS; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
@@ -169,6 +150,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   const size_t o_rlist = carve(sizeof(int32_t) * 2 * ((size_t)B + 1));
   const size_t o_dstate = carve(BN);
   const size_t o_counters = carve(sizeof(unsigned long long) * 8);
+  const size_t o_statusdev = carve(sizeof(uint32_t) * MCR_STATUS_WORDS);
   const size_t o_stage_ids = carve(sizeof(int32_t) * (size_t)B);
   const size_t o_stats = carve(sizeof(double) * 2);
   const size_t o_vorder = carve(sizeof(int32_t) * 2 * ((size_t)B + 2));
@@ -194,7 +176,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   P.cc_store = (uint32_t*)(base + o_cc); P.bpf = (float*)(base + o_bpf); P.bp_stamp = (uint32_t*)(base + o_bpstamp); P.shapes = (const McrShapes*)(base + o_shapes); P.slots = base + o_slots;
   h->view_stamps = (unsigned long long*)(base + o_vscratch);
   P.viewp = (float*)(base + o_viewp);
-  P.part = base + o_part; P.dpart = base + o_dpart; P.collide_epoch = (int32_t*)(base + o_epoch); h->dev_step_ctr = P.collide_epoch + B; P.sync_words = (int32_t*)(base + o_sync); P.dlist = (int32_t*)(base + o_dlist); P.rlist = (int32_t*)(base + o_rlist); P.defer_state = base + o_dstate; P.counters = (unsigned long long*)(base + o_counters); P.stats = (double*)(base + o_stats);
+  P.part = base + o_part; P.dpart = base + o_dpart; P.collide_epoch = (int32_t*)(base + o_epoch); h->dev_step_ctr = P.collide_epoch + B; P.sync_words = (int32_t*)(base + o_sync); P.dlist = (int32_t*)(base + o_dlist); P.rlist = (int32_t*)(base + o_rlist); P.defer_state = base + o_dstate; P.counters = (unsigned long long*)(base + o_counters); P.status_dev = (uint32_t*)(base + o_statusdev); P.stats = (double*)(base + o_stats);
   h->stage_ids = (int32_t*)(base + o_stage_ids); P.vcount = (int32_t*)(base + o_vorder); P.vorder = P.vcount + 2; P.dbg_stamps = (unsigned long long*)(base + o_stamps); P.clist = (int32_t*)(base + o_clist);
   P.carpoly = (float*)(base + o_carpoly);
   P.particles = cfg->skid_particles ? (uint32_t*)(base + o_particles) : nullptr;
@@ -232,21 +214,18 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
       // tail of the caller's stream for every LDS slot that frees up — makes no difference: high / normal / low 14.73 / 14.72 / 14.72 M)
       if (hipStreamCreateWithPriority(&h->s_defer, hipStreamNonBlocking, prio_hi) == hipSuccess) {
         const unsigned evf = hipEventDisableTiming;     // (hipEventReleaseToDevice changes nothing measurable: tools/ubench/event_gap.hip)
-        for (hipEvent_t* e : {&h->ev_fork, &h->ev_join, &h->ev_fork2, &h->ev_join2, &h->ev_col, &h->ev_chain}) (void)hipEventCreateWithFlags(e, evf);
-        if (const char* g = getenv("MCR_DEFER_AFTER")) { const int v = atoi(g); if (v >= 1 && v < 60) h->defer_after = v; }
-        if (const char* g = getenv("MCR_FLAGS_ON_CALLER")) h->flags_on_caller = atoi(g) != 0;
-        if (const char* g = getenv("MCR_FLAGS_IN_VIEW")) h->flags_in_view = atoi(g) != 0;
+        for (hipEvent_t* e : {&h->ev_fork, &h->ev_join, &h->ev_fork2, &h->ev_join2, &h->ev_col}) (void)hipEventCreateWithFlags(e, evf);
+        // (the switches of the environment — MCR_SOFT_SYNC=0, MCR_STOP_EVENTS=0, MCR_SEQUENTIAL_COLLIDE=1 — select paths that exist for
+        // environments where the default cannot run: profilers that serialise kernels, graph capture; the parity suite covers each)
         if (const char* g = getenv("MCR_STOP_EVENTS")) h->stop_events = atoi(g) != 0;
         h->soft_sync = kernels_overlap(h->s_defer, h->s_side);     // (a waiting kernel needs the kernels it waits for to run beside it)
-        if (const char* g = getenv("MCR_MERGE_FLAGS_VIEWPREP")) h->merge_flags_viewprep = atoi(g) != 0;
         if (const char* g = getenv("MCR_SOFT_SYNC")) h->soft_sync = h->soft_sync && atoi(g) != 0;
         // One handle per device and process at a time: the side stream's wait for "begin" is enqueued BEFORE the kernel that posts it.
         // With the streams of two handles multiplexed over the same hardware queues and their steps interleaved on one caller's stream,
         // handle A's waiting kernel can sit in front of the post handle B's join waits for, which in turn sits in front of A's dynamics:
         // a cycle that only the wait bound would break.  Further handles order their streams with events (every wait there is for work
         // enqueued earlier).
-        if (h->soft_sync) { if (g_soft_handles[cfg->device & 63].fetch_add(1) == 0) h->soft_token = true; else { g_soft_handles[cfg->device & 63].fetch_sub(1); h->soft_sync = false; } }
-        if (const char* g = getenv("MCR_MERGE_LIST_VIEWS")) h->merge_list_views = atoi(g) != 0;
+        if (h->soft_sync) { if (g_soft_handles[cfg->device & 63].fetch_add(1) == 0) h->soft_token = true; else { g_soft_handles[cfg->device & 63].fetch_sub(1); h->soft_sync = false; h->soft_denied = true; } }
         // (at 8 cars per env the one-step-ahead touch verdict — a second pass over up to 28 car pairs — costs more than the
         // contact pass gains by running beside the dynamics: measured at N = 8, round 2: 3.66 vs 4.28 M env-steps/s.  Round 3 tried a
         // CONSERVATIVE verdict there instead — bounding discs + car boxes, no narrowphase, the contact chain taking every env it
@@ -255,8 +234,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
         // contact chain itself — 585 us for its slowest wavefront, a sequential Gauss-Seidel over the contacts between the joint sweeps)
         // (round 3, phase-word path, contact pass beside / in front of the dynamics: N = 5 8.99 / 8.50 M env-steps/s, N = 6 7.87 / 7.49,
         // N = 7 7.16 / 6.80, N = 8 4.90 / 5.47 — up to seven cars per env it runs beside)
-        const int cc_max_agents = getenv("MCR_CC_MAX_AGENTS") ? atoi(getenv("MCR_CC_MAX_AGENTS")) : 7;
-        h->concurrent_collide = N <= cc_max_agents && !getenv("MCR_SEQUENTIAL_COLLIDE") && (B * G + 63) / 64 <= h->simd_count && kernels_overlap(h->s_defer, h->s_side);
+        h->concurrent_collide = N <= 7 && !getenv("MCR_SEQUENTIAL_COLLIDE") && (B * G + 63) / 64 <= h->simd_count && kernels_overlap(h->s_defer, h->s_side);
         h->split = true;
       } else (void)hipStreamDestroy(h->s_side);
     }
@@ -277,7 +255,7 @@ extern "C" int mcr_destroy(mcr_env* h) {
   for (auto e : h->free_events) (void)hipEventDestroy(e);
   if (h->split) {
     (void)hipStreamDestroy(h->s_side); (void)hipStreamDestroy(h->s_defer);
-    (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_fork2); (void)hipEventDestroy(h->ev_join2); (void)hipEventDestroy(h->ev_col); (void)hipEventDestroy(h->ev_chain);
+    (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_fork2); (void)hipEventDestroy(h->ev_join2); (void)hipEventDestroy(h->ev_col);
   }
   (void)hipFree(h->slab);
   (void)hipHostFree(h->consumed_host);
@@ -346,7 +324,7 @@ static void launch_view(mcr_env* h, int kid, int slots, hipStream_t st, const Mc
   if (tm) { tl.id = kid; tl.a = get_event(h); tl.b = get_event(h); (void)hipEventRecord(tl.a, st); }
   // (list launches: with more than two cars per env the contact list is long — N = 8: ~340 envs x 8 views per step — and 128
   // workgroups would draw ~20 views each, one after the other, at the end of the side stream's chain)
-  if (P.role >= 2) { McrParams Q = P; Q.split_views = h->split_views ? 1 : 0; mcr_view_launch(2, list_grid(slots * (Q.split_views ? P.N : 1), h->list_view_grid) + Q.flags_blocks, st, Q, h->view_stamps, only_just_reset, stop); }
+  if (P.role >= 2) { McrParams Q = P; Q.split_views = 1; mcr_view_launch(2, list_grid(slots * (Q.split_views ? P.N : 1), h->list_view_grid) + Q.flags_blocks, st, Q, h->view_stamps, only_just_reset, stop); }
   else mcr_view_launch((P.debug & 32) ? 1 : 0, slots, st, P, h->view_stamps, only_just_reset, stop);
   if (tm) { (void)hipEventRecord(tl.b, st); h->pending.push_back(tl); }
 }
@@ -368,6 +346,11 @@ static void launch_reset(mcr_env* h, McrParams P, hipStream_t st) {
 // Deferred envs: the few whose position loop is still iterating after 3 sweeps (a slow marginal crawl that would hold the whole
 // main launch for up to 60).  An env of either list that ended its episode in this step (rare) takes its reset pass inside its
 // own chain.
+// may a step launched on caller stream `st` order its streams with phase words?  (mcr_bind_stream checked it; an unbound stream: events)
+static bool stream_bound(const mcr_env* h, hipStream_t st) {
+  for (const auto& b : h->bound) if (b.first == st) return b.second;
+  return false;
+}
 static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags) {
   const int B = P.B, N = P.N;
   const int dyn_blocks = (B * P.G + 63) / 64;
@@ -412,7 +395,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   // few whose position loop is still iterating after 3 sweeps (a slow marginal crawl that would hold the whole main
   // launch for up to 60).  Re-spawned envs (auto-reset, ~B/1000 per step): their reset pass would hold the raster of
   // everybody else (they are not in the main raster's list, see k_dynamics).
-  P.defer_after = h->defer_after; P.respawn_list = P.auto_reset ? 1 : 0; P.list_envs_per_block = MCR_SIDE_ENVS_PER_WAVE;
+  P.defer_after = MCR_DEFER_AFTER; P.respawn_list = P.auto_reset ? 1 : 0; P.list_envs_per_block = MCR_SIDE_ENVS_PER_WAVE;
   // The contact pass runs on the side stream BESIDE the main dynamics (cc_mode, mcr_kernels.h): nothing the solver needs
   // comes from it (Car.step reads the wheels' tile bits of the PREVIOUS pass; which envs are the contact chain's follows
   // from the entry poses), only the step's bookkeeping at the end of the dynamics kernel does, and that waits for
@@ -429,7 +412,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   }
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(st, &capturing);
-  if (h->soft_sync && h->use_graph <= 0 && capturing == hipStreamCaptureStatusNone && h->resume_on_caller && (!draw || h->merge_list_views)) {
+  if (h->soft_sync && h->use_graph <= 0 && capturing == hipStreamCaptureStatusNone && stream_bound(h, st)) {
     // ---- the three chains ordered by phase words (mcr_kernels.h: soft_sync) — no marker / barrier packets on any stream:
     //   s_side  : await(BEGIN) -> [collide -> post(COL)] -> chain(contact envs) -> raster -> post(SIDE)
     //   st      : [posts BEGIN] dynamics(main envs) -> [posts DYN, awaits COL] chain(resume + re-spawned envs) -> raster -> await(SIDE, MAIN)
@@ -438,44 +421,40 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     // the step's last kernel instead of 20-32; the chains' bookkeeping: list launches behind the chains; N > 3: the main envs'
     // bookkeeping on the caller's stream)
     P.soft_sync = 1;
-    const int fuse_side = (view_flags && N <= 2 && h->fuse_side) ? 1 : 0, fuse_resume = (view_flags && N <= 2 && h->fuse_resume) ? 1 : 0;
     const int lg_flags = std::min(B * N, (N <= 2 ? 4 : 32) * MCR_LIST_GRID);
     if (!cc) LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), st, P, 0);
     hipLaunchKernelGGL(k_await, dim3(1), dim3(64), 0, h->s_side, P, (int)W_BEGIN, -1);
     if (cc) LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), h->s_side, P, 0);     // (W_COL: posted by the chain that follows)
     P.split = 0;
     P.role = 2;
-    LAUNCH_LDS(5, k_list_chain, lg_dyn, 64, col::lds_bytes(N), h->s_side, P, P, fuse_side, lg_dyn);
+    LAUNCH_LDS(5, k_list_chain, lg_dyn, 64, col::lds_bytes(N), h->s_side, P, P, 0, lg_dyn);
     // (the chains' bookkeeping: workgroups of its own inside the chain's raster launch when there is one, a list launch otherwise)
     // (beyond four cars per env the lists hold thousands of cars — ~315 contact envs x 8 at N = 8 — and a few 256-thread workgroups
     // would take them in many rounds at the end of the contact chain, the critical path there; measured N = 2 15.37 -> 15.65 M
     // env-steps/s, N = 4 11.00 -> 11.07, N = 8 5.47 -> 5.44)
-    const int fiv = (view_flags && draw && h->flags_in_view && N <= 4) ? (N <= 2 ? 8 : 64) : 0;
-    if (view_flags && !fuse_side && !fiv) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, h->s_side, P);
-    if (draw) { McrParams Pv = P; Pv.flags_blocks = fuse_side ? 0 : fiv; launch_view(h, 6, B, h->s_side, Pv, 0); }
+    const int fiv = (view_flags && draw && N <= 4) ? (N <= 2 ? 8 : 64) : 0;
+    if (view_flags && !fiv) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, h->s_side, P);
+    if (draw) { McrParams Pv = P; Pv.flags_blocks = fiv; launch_view(h, 6, B, h->s_side, Pv, 0); }
     hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, h->s_side, P, (int)W_SIDE);
     P.role = 1;
     P.viewprep_in_flags = (view_flags && draw && h->viewprep_in_flags) ? 1 : 0;
-    const bool flags_on_caller = view_flags && draw && !P.viewprep_in_flags && h->flags_on_caller && N <= 7;   // (N = 8: the contact chain is the critical one; no gain, and the raster would share the machine with the bookkeeping)
+    const bool flags_on_caller = view_flags && draw && !P.viewprep_in_flags && N <= 7;   // (N = 8: the contact chain is the critical one; no gain, and the raster would share the machine with the bookkeeping)
     LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 0);
     P.role = 3;
     {
       const int ga = std::min(lg_dyn, MCR_LIST_GRID / 2), gb = P.auto_reset ? lg_col : 0;
       McrParams Pr = P; Pr.role = 4; Pr.list_envs_per_block = 1;
-      LAUNCH_LDS(7, k_list_chain, ga + gb, 64, col::lds_bytes(N), st, P, Pr, fuse_resume, ga);
-      if (view_flags && !fuse_resume && !fiv) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, st, P);
+      LAUNCH_LDS(7, k_list_chain, ga + gb, 64, col::lds_bytes(N), st, P, Pr, 0, ga);
+      if (view_flags && !fiv) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, st, P);
       // Beyond three cars per env the third stream's chain (bookkeeping of B*N cars, then B*N views) is the longer one and the caller's
       // has slack: the main envs' bookkeeping — which the raster does not depend on — moves here, between the resume chain and its raster
       if (flags_on_caller) { McrParams Pm = P; Pm.role = 1; hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, st, Pm); }
-      if (draw) { McrParams Pv = P; Pv.role = P.auto_reset ? 5 : 3; Pv.await_tail = 1; Pv.flags_blocks = fuse_resume ? 0 : fiv; launch_view(h, 7, B, st, Pv, 0); }     // ... and the step's join
+      if (draw) { McrParams Pv = P; Pv.role = P.auto_reset ? 5 : 3; Pv.await_tail = 1; Pv.flags_blocks = fiv; launch_view(h, 7, B, st, Pv, 0); }     // ... and the step's join
     }
     P.role = 1;
     hipLaunchKernelGGL(k_await, dim3(1), dim3(64), 0, h->s_defer, P, (int)W_DYN, cc ? (int)W_COL : -1);
-    if (P.viewprep_in_flags && h->merge_flags_viewprep) hipLaunchKernelGGL(k_flags_viewprep, dim3(dyn_blocks + B * N), dim3(64), 0, h->s_defer, P, dyn_blocks);
-    else {
-      if (P.viewprep_in_flags) hipLaunchKernelGGL(k_viewprep, dim3(dyn_blocks), dim3(64), 0, h->s_defer, P);
-      if (view_flags && !flags_on_caller) hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, h->s_defer, P);
-    }
+    if (P.viewprep_in_flags) hipLaunchKernelGGL(k_flags_viewprep, dim3(dyn_blocks + B * N), dim3(64), 0, h->s_defer, P, dyn_blocks);      // view records + bookkeeping: one launch
+    else if (view_flags && !flags_on_caller) hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, h->s_defer, P);
     P.use_vorder = 1;
     if (draw) launch_view(h, 2, B, h->s_defer, P, 0);
     P.use_vorder = 0;
@@ -487,7 +466,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   // the dispatch packet's own completion signal).  A hipEventRecord is a marker packet BEHIND the kernel: +3 us before the next
   // kernel of the same stream, 11 instead of 7.5 us for a dependent kernel on another stream (tools/ubench/event_gap.hip), and the
   // step has four of them on its critical path.  Not inside a graph capture (plain records there).
-  const bool sev = h->stop_events && h->use_graph <= 0;
+  const bool sev = h->stop_events && h->use_graph <= 0 && capturing == hipStreamCaptureStatusNone;
 #define STOP(ev) (sev ? (ev) : (hipEvent_t) nullptr)
 #define RECORD_UNLESS_STOP(ev, stream) do { if (!sev) (void)hipEventRecord(ev, stream); } while (0)
   if (!cc) LAUNCH_LDS_STOP(0, k_collide, B, 64, col::lds_bytes(N), st, STOP(h->ev_col), P, 0);
@@ -498,46 +477,38 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   P.split = 0;
   // bookkeeping of a chain's cars: fused into the chain for N <= 2 (2 envs x N cars take their turns on one wavefront),
   // a list launch of its own beyond that
-  const int fuse_flags = (view_flags && N <= 2 && h->fuse_flags) ? 1 : 0;
+  const int fuse_flags = (view_flags && N <= 2) ? 1 : 0;
   const int lg_flags = std::min(B * N, (N <= 2 ? 4 : 32) * MCR_LIST_GRID);
-  const bool merged = draw && h->merge_list_views;     // the re-spawned envs' frames: with the deferred envs' (one launch), not on the side stream
   const bool flags_list = view_flags && !fuse_flags;
   P.role = 2;
   // (the side stream's last kernel completes ev_join; which one that is depends on the step's shape)
-  const bool side_ends_with_view = draw && (merged || !P.auto_reset);
   LAUNCH_LDS_STOP(5, k_list_chain, lg_dyn, 64, col::lds_bytes(N), h->s_side, STOP((!draw && !flags_list) ? h->ev_join : nullptr), P, P, fuse_flags, lg_dyn);
   if (flags_list) hipExtLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, h->s_side, nullptr, STOP(!draw ? h->ev_join : nullptr), 0, P);
-  if (draw) launch_view(h, 6, B, h->s_side, P, 0, STOP(side_ends_with_view ? h->ev_join : nullptr));
+  if (draw) launch_view(h, 6, B, h->s_side, P, 0, STOP(h->ev_join));
   P.role = 1;
   // the main envs' view records and car polygons: by k_viewprep on the side stream, beside the bookkeeping kernel, in a drawn step
   // with actions; otherwise by the dynamics' own epilogue
   P.viewprep_in_flags = (view_flags && draw && h->viewprep_in_flags) ? 1 : 0;
   LAUNCH_LDS_STOP(1, k_dynamics, dyn_blocks, 64, 0, st, STOP(h->ev_fork2), P, 0);
   RECORD_UNLESS_STOP(h->ev_fork2, st);
-  // Which of the two remaining chains stays on the caller's stream?  The kernel that follows the dynamics IN-STREAM starts ~2 us
-  // after it, one that has to hop to another stream ~8 us (kernel trace, round 3).  The longer chain is the resume chain (85-150
-  // us beside the raster + its own raster, 25-70 us) — not bookkeeping + main raster (40 + 100 us): it keeps the caller's stream, gets
-  // its wavefronts placed before the raster starts (a chain that starts beside a raster that fills every CU runs 2-3x slower),
-  // and the main envs' bookkeeping + raster take the hop.
-  hipStream_t s_resume = h->resume_on_caller ? st : h->s_defer, s_mainview = h->resume_on_caller ? h->s_defer : st;
+  // The chain that follows the dynamics IN-STREAM starts ~2 us after it, one that has to hop to another stream ~8 us (kernel trace,
+  // round 3).  The longer chain is the resume chain (85-150 us beside the raster + its own raster, 25-70 us) — not bookkeeping + main
+  // raster (40 + 100 us): it keeps the caller's stream and gets its wavefronts placed before the raster starts (a chain that starts
+  // beside a raster that fills every CU runs 2-3x slower); the main envs' bookkeeping + raster take the hop to the third stream.
+  hipStream_t s_resume = st, s_mainview = h->s_defer;
   (void)hipStreamWaitEvent(h->s_defer, h->ev_fork2, 0);
   (void)hipStreamWaitEvent(s_resume, h->ev_col, 0);              // the resume chain reads the contact pass's results of its envs (a deferred env never got to the main dynamics' in-kernel wait)
-  if (!merged) (void)hipStreamWaitEvent(h->s_side, h->ev_fork2, 0);
+  if (!draw) (void)hipStreamWaitEvent(h->s_side, h->ev_fork2, 0);
   P.role = 3;
-  hipEvent_t resume_done = s_resume == st ? (hipEvent_t) nullptr : h->ev_join2;     // the chain on the third stream ends with ev_join2
+  const hipEvent_t resume_done = nullptr;     // (the caller's stream needs no event for its own chain)
   {
     // the resume chain and — same launch, workgroups of their own — the reset pass (:408, ~50 us of serial solver work) of the
     // envs the main dynamics re-spawned; then, in one list launch, the deferred envs' frames and the re-spawned envs' first observations
     const int ga = std::min(lg_dyn, MCR_LIST_GRID / 2), gb = P.auto_reset ? lg_col : 0;
     McrParams Pr = P; Pr.role = 4; Pr.list_envs_per_block = 1;     // one re-spawned env per workgroup: they run side by side
     LAUNCH_LDS_STOP(7, k_list_chain, ga + gb, 64, col::lds_bytes(N), s_resume, STOP((!draw && !flags_list) ? resume_done : nullptr), P, Pr, fuse_flags, ga);
-    if (!merged && P.auto_reset && draw) (void)hipEventRecord(h->ev_chain, s_resume);
     if (flags_list) hipExtLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, s_resume, nullptr, STOP(!draw ? resume_done : nullptr), 0, P);
-    if (merged) { McrParams Pv = P; Pv.role = P.auto_reset ? 5 : 3; launch_view(h, 7, B, s_resume, Pv, 0, STOP(resume_done)); }
-    else {
-      if (draw) launch_view(h, 7, B, s_resume, P, 0, STOP(resume_done));
-      if (P.auto_reset && draw) { (void)hipStreamWaitEvent(h->s_side, h->ev_chain, 0); launch_view(h, 4, B, h->s_side, Pr, 0, STOP(h->ev_join)); }
-    }
+    if (draw) { McrParams Pv = P; Pv.role = P.auto_reset ? 5 : 3; launch_view(h, 7, B, s_resume, Pv, 0, STOP(resume_done)); }
   }
   P.role = 1;
   RECORD_UNLESS_STOP(h->ev_join, h->s_side);
@@ -545,7 +516,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   // before the raster, and those ~16 us are what the list chains — forked off at the same moment — need to get their
   // wavefronts placed: a chain that starts beside a raster that already fills every CU runs 2-3x slower (measured).
   // (k_viewprep in front of it, in-stream: the side stream may be held by a long contact chain, and a further stream slows every queue)
-  hipEvent_t main_done = s_mainview == st ? (hipEvent_t) nullptr : h->ev_join2;
+  const hipEvent_t main_done = h->ev_join2;
   if (P.viewprep_in_flags) hipLaunchKernelGGL(k_viewprep, dim3(dyn_blocks), dim3(64), 0, s_mainview, P);
   if (view_flags) hipExtLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, s_mainview, nullptr, STOP(!draw ? main_done : nullptr), 0, P);
   (void)hipStreamWaitEvent(s_mainview, h->ev_col, 0);              // the raster reads the tiles' recolour flags (long done)
@@ -566,9 +537,10 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
 static int check_status(mcr_env* h) {
   static const char* what[MCR_STATUS_WORDS] = {
       "a kernel gave up waiting for the kernels of another stream (three-chain step: the contact pass of an env, a phase word); the handle now runs the contact pass in front and orders its streams with events",
-      "the contact pass disagreed with the one-step-ahead touch verdict", "more touching car<->car fixture pairs than the manifold store holds",
-      "more tile begin events in one env-step than the replay buffer holds", "", "", "", ""};
-  for (int i = 0; i < MCR_STATUS_WORDS; ++i) {
+      "the contact pass disagreed with the one-step-ahead touch verdict", "", "", "", "", "", ""};
+  // FATAL: a wait that gave up, a verdict mismatch — results of that step are wrong.  The overflow words (ST_CC_OVERFLOW, ST_EVENT_OVERFLOW) are
+  // documented capacity deviations (the excess was dropped and flagged): the rollout goes on, mcr_status / VecMultiCarRacing.status_words show them.
+  for (int i : {(int)ST_SPIN_GIVEUP, (int)ST_VERDICT}) {
     const uint32_t v = ((volatile uint32_t*)h->status_host)[i];
     if (v != h->status_seen[i]) {
       h->status_seen[i] = v;
@@ -601,28 +573,23 @@ extern "C" int mcr_step(mcr_env* h, const float* d_actions, uint8_t* d_obs, doub
   if (!h->any_reset) { g_err = "step() before reset()"; return MCR_ERR_STATE; }
   if (int rc = check_status(h)) return rc;
   hipStream_t st = (hipStream_t)stream;
+  if (h->use_graph <= 0) {
+    // a step captured by the CALLER cannot be replayed: its launches carry this step's epoch and list parity as constants.  The supported
+    // way to replay a step is mcr_set_step_graph (the handle captures both parities itself and keeps the epoch in device memory).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) { g_err = "mcr_step inside a stream capture: use mcr_set_step_graph for graph replay"; return MCR_ERR_STATE; }
+  }
   McrParams P = h->P;
   P.actions = d_actions; P.obs = h->cfg.obs_enabled ? d_obs : nullptr;
   P.reward_out = d_reward; P.done_out = d_done; P.trunc_out = d_trunc;
   P.bp_fresh = h->bp_fresh ? 1 : 0; h->bp_fresh = false;
-  h->step_count += 1;
+  h->step_count = (int32_t)((uint32_t)h->step_count + 1u);      // (wraps: epochs are compared as 32-bit distances, mcr_kernels.h)
   // with auto_reset, finished envs are re-spawned on the device and take the action-less first step of their
   // new episode inside this call; the view kernel always runs (it also owns the backward/on-grass flags)
   const int vf = d_actions ? 1 : 0;
   if (cc_active(h) && !h->verdict_fresh) {   // after reset() / reset_envs() / a state restore / a step without actions: which envs hold a touching car<->car pair?
     McrParams Pt = P; Pt.role = 0; Pt.part = h->P.part + (size_t)h->step_parity * P.B;
     hipLaunchKernelGGL(k_touch, dim3(P.B), dim3(64), 0, st, Pt);
-  }
-  if (h->split && h->soft_sync && st != h->probed_stream && h->use_graph <= 0) {
-    // Phase words need the caller's stream and the two internal ones on hardware queues of their own: a waiting kernel at the head of
-    // a shared queue would hold back the very kernel it waits for (HIP multiplexes streams of one priority over a few queues; the
-    // internal streams are high-priority ones, so an ordinary caller's stream never shares theirs — checked once per stream, ~1 ms).
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(st, &cap);
-    if (cap == hipStreamCaptureStatusNone) {
-      h->probed_stream = st;
-      if (!(kernels_overlap(h->s_side, st) && kernels_overlap(h->s_defer, st))) h->soft_sync = false;
-    }
   }
   h->verdict_fresh = vf != 0;             // this step's bookkeeping evaluates the next step's
   if (h->use_graph > 0 && !h->timing) {
@@ -655,6 +622,27 @@ extern "C" int mcr_step(mcr_env* h, const float* d_actions, uint8_t* d_obs, doub
   }
   launch_step(h, P, st, vf);
   HIPCHK(hipGetLastError());
+  return MCR_OK;
+}
+
+// Phase words need the caller's stream and the two internal ones on hardware queues of their own: a waiting kernel at the head of a shared
+// queue would hold back the very kernel it waits for (HIP multiplexes streams of one priority over a few queues; the internal streams are
+// high-priority ones, so an ordinary caller's stream never shares theirs).  Checked HERE, once per stream, with two probe kernels and
+// device synchronisations (~1 ms) — never inside mcr_step, which launches and returns.
+extern "C" int mcr_bind_stream(mcr_env* h, void* stream) {
+  if (!h) { g_err = "null handle"; return MCR_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  for (const auto& b : h->bound) if (b.first == st) return MCR_OK;
+  bool ok = false;
+  if (h->split && h->soft_sync) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    if (cap != hipStreamCaptureStatusNone) { g_err = "mcr_bind_stream on a capturing stream"; return MCR_ERR_STATE; }
+    HIPCHK(hipSetDevice(h->cfg.device));
+    ok = kernels_overlap(h->s_side, st) && kernels_overlap(h->s_defer, st);
+  }
+  if (h->bound.size() >= 64) h->bound.erase(h->bound.begin());
+  h->bound.emplace_back(st, ok);
   return MCR_OK;
 }
 
@@ -930,7 +918,7 @@ extern "C" int mcr_debug_read_counters(mcr_env* h, uint64_t* out4) {
 extern "C" int mcr_concurrent_collide(const mcr_env* h) { return (h && h->split && h->concurrent_collide) ? 1 : 0; }
 extern "C" int mcr_step_ordering(const mcr_env* h) {
   if (!h || !h->split) return 0;
-  return ((h->soft_sync && h->use_graph <= 0 && h->resume_on_caller && h->merge_list_views) ? 1 : 0) | (h->stop_events ? 2 : 0);
+  return ((h->soft_sync && h->use_graph <= 0) ? 1 : 0) | (h->stop_events ? 2 : 0) | (h->soft_denied ? 4 : 0);
 }
 extern "C" int mcr_debug_read_verdict_mismatches(mcr_env* h, uint64_t* out) {
   if (!h || !out) return MCR_ERR_ARG;

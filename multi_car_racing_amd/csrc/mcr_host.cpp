@@ -16,6 +16,7 @@
 #include <condition_variable>
 #include <functional>
 #include <sys/prctl.h>
+#include <unistd.h>
 #include <string>
 
 // ============================================================================ MT19937 (numpy layout)
@@ -479,20 +480,27 @@ struct GenPool {
       if (++finished == want) cv_done.notify_all();
     }
   }
-  // runs fn on the caller and on `helpers` pool threads; returns when all of them are through
+  // runs fn on the caller and on `helpers` threads; returns when all of them are through (also when the caller's fn throws: the helpers
+  // hold a pointer to it).  A caller that finds the pool busy — reset() of a whole batch while the refill thread holds it, several
+  // VecEnvs in one process — starts threads of its own for the call, as round 2 did for every call.
   void run(int helpers, const std::function<void()>& fn) {
+    if (helpers <= 0) { fn(); return; }
     std::unique_lock<std::mutex> one(run_m, std::try_to_lock);
-    if (helpers <= 0 || !one.owns_lock()) { fn(); return; }
+    if (!one.owns_lock()) {
+      std::vector<std::thread> own;
+      for (int i = 0; i < helpers; ++i) own.emplace_back(fn);
+      struct Join { std::vector<std::thread>& t; ~Join() { for (auto& x : t) if (x.joinable()) x.join(); } } join{own};
+      fn();
+      return;
+    }
     {
       std::lock_guard<std::mutex> lk(m);
       while ((int)threads.size() < helpers) threads.emplace_back([this] { worker(); });
       job = &fn; ++seq; want = helpers; started = finished = 0;
     }
     cv_work.notify_all();
+    struct Wait { GenPool& p; ~Wait() { std::unique_lock<std::mutex> lk(p.m); p.cv_done.wait(lk, [&] { return p.finished == p.want; }); p.job = nullptr; } } wait{*this};
     fn();
-    std::unique_lock<std::mutex> lk(m);
-    cv_done.wait(lk, [&] { return finished == want; });
-    job = nullptr;
   }
   ~GenPool() {
     { std::lock_guard<std::mutex> lk(m); stop = true; }
@@ -500,7 +508,14 @@ struct GenPool {
     for (auto& t : threads) if (t.joinable()) t.join();
   }
 };
-GenPool& gen_pool() { static GenPool* p = new GenPool(); return *p; }   // (never destroyed: its threads may outlive main() in an embedding process)
+// (never destroyed: its threads may outlive main() in an embedding process.  Not inherited either: in a fork()ed child the pool object
+// says it has threads that do not exist there — run() would wait for them for ever —, so the child starts a pool of its own)
+GenPool& gen_pool() {
+  static std::mutex gm; static GenPool* p = nullptr; static pid_t owner = 0;
+  std::lock_guard<std::mutex> lk(gm);
+  if (!p || owner != getpid()) { p = new GenPool(); owner = getpid(); }     // (the parent's pool object is leaked in the child: its mutexes may be held by threads that are gone)
+  return *p;
+}
 }  // namespace
 
 extern "C" int mcr_episodes_generate(uint32_t* mt_track, uint32_t* mt_global, int n, int num_agents, int direction_mode,

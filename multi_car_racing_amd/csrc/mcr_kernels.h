@@ -17,7 +17,8 @@ struct McrParams {
   float* bpf;                   // [BP_COUNT][4 * BN] broadphase proxies of the wheels (fat AABBs; what the last contact pass saw)
   uint32_t* bp_stamp;           // [B][TILE_CAP][4 * N] batch label of the tile<->wheel contact: the contact pass that first saw the two fat AABBs overlap
   int32_t bp_fresh;             // the car proxies are re-created at the current poses by this step's contact pass (after mcr_set_bodies)
-  uint32_t* status;             // [MCR_STATUS_WORDS] mapped host memory: conditions that make results wrong (mcr_step checks them without synchronising)
+  uint32_t* status;             // [MCR_STATUS_WORDS] mapped host memory: conditions that make results wrong or degraded (mcr_step checks them without synchronising)
+  uint32_t* status_dev;         // [MCR_STATUS_WORDS] the same counts in device memory: where the kernels count (mcr_raise)
   const McrShapes* shapes;
   float* viewp;                 // [BN][MCR_VIEWP_FLOATS] per-car camera + HUD geometry, written by k_dynamics, read by k_view
   float* carpoly;               // [BN][MCR_CARPOLY_FLOATS] world-space vertices of the car's 12 draw polygons (Car.draw)
@@ -79,13 +80,21 @@ struct McrParams {
   double h_ratio;
 };
 
-// status words (mapped host memory; non-zero = the results are no longer trustworthy, mcr_step returns MCR_ERR_STATE)
+// status words (mapped host memory).  FATAL ones (give-up, verdict) make the next mcr_step return MCR_ERR_STATE; an OVERFLOW truncated a
+// capacity-bound list (documented deviation): the step goes on, mcr_status shows the count
 enum { ST_SPIN_GIVEUP = 0,     // a kernel gave up waiting for another stream's kernels (three-chain step: the contact pass of an env, a phase word)
        ST_VERDICT = 1,         // the contact pass disagreed with the one-step-ahead touch verdict
        ST_CC_OVERFLOW = 2,     // more touching car<->car fixture pairs than the manifold store / the LDS pool holds: the excess was dropped
        ST_EVENT_OVERFLOW = 3,  // more tile begin events in one env-step than the replay buffer holds
        MCR_STATUS_WORDS = 8 };
 __device__ __forceinline__ int mcr_epoch(const McrParams& p) { return p.epoch_ptr ? *p.epoch_ptr : p.epoch; }
+// Report condition `w` (ST_*): counted in device memory, the new count then STORED (system scope) into the mapped host word mcr_step polls —
+// no atomic on host memory, which needs PCIe atomics and is silently dropped where the platform lacks them.  (Two reports racing may land
+// out of order: the host word then holds the smaller of two non-zero counts until the next report; what mcr_step acts on is "it changed".)
+__device__ __forceinline__ void mcr_raise(const McrParams& p, int w) {
+  const uint32_t n = atomicAdd(&p.status_dev[w], 1u) + 1u;
+  __hip_atomic_store(&p.status[w], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // ---- soft_sync: ordering between the step's streams without command-processor packets (tools/ubench/event_gap.hip: a
 // hipEventRecord costs the next kernel of its stream 3 us; a hipStreamWaitEvent 3 us when its event completed long ago, 7.5-11 us
 // when it completes last, and 17 us when it completed a few microseconds before the packet's turn — the queue had been parked on it).
@@ -93,8 +102,12 @@ __device__ __forceinline__ int mcr_epoch(const McrParams& p) { return p.epoch_pt
 // one-thread kernel behind the kernels of the phase, in their stream, or by the first thread of the kernel that follows them in
 // their stream: both run after the end-of-kernel release of everything before them.  It is AWAITED by a one-wavefront kernel in
 // front of the dependent kernels, in their stream (the kernels behind it start with the usual acquire), or — k_list_chain — by a
-// kernel's prologue (poll, then one agent-scope acquire).  Waits are bounded (about a minute) and a give-up is reported like the contact
+// kernel's prologue (poll, then one agent-scope acquire).  Waits are bounded and a give-up is reported like the contact
 // pass's (ST_SPIN_GIVEUP: mcr_step fails, the handle goes back to events).
+// gfx950, not the HIP memory model: a post is a RELAXED agent-scope store (sc1: written through to the memory side, the device's
+// coherence point) behind the end-of-kernel write-back of the kernels it follows, a poll a RELAXED agent-scope load (sc1: served by the
+// memory side, not by an L2 of another XCD); the release / acquire pair the model asks for writes the XCD's dirty L2 back per post
+// (+12 us per step, measured).  include/mcr.h says so.
 enum { W_BEGIN = 0,    // the caller's stream reached this step's main dynamics (everything it held before is complete)
        W_COL = 1,      // the contact pass (k_collide pass 0, side stream) is complete
        W_DYN = 2,      // the main dynamics is complete
@@ -104,18 +117,24 @@ enum { W_BEGIN = 0,    // the caller's stream reached this step's main dynamics 
 __device__ __forceinline__ void mcr_post(const McrParams& p, int w) {
   __hip_atomic_store(&p.sync_words[w * 16], mcr_epoch(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// one lane polls; the caller adds the acquire if it reads the phase's data in the same kernel.  (epochs only grow: ">= 0" also
-// lets a waiter through that is late by a step, which cannot happen while every step awaits the one before)
-// The bound: 2^15 polls 0.2 us apart, then 2^24 more 3.4 us apart — about a minute.  The wait for *begin* is the one that depends on
-// the caller: whatever the caller's stream still holds in front of the step (a long inference kernel, an event wait) is waited out
-// here, and that must not be mistaken for a stalled stream.  debug bit 12 shortens it to a few milliseconds (tests).
+// one lane polls; the caller adds the acquire if it reads the phase's data in the same kernel.  Epochs are compared as a wrapping 32-bit
+// distance ("word - epoch >= 0" in unsigned arithmetic, reinterpreted: no signed overflow at the 2^31-st step, 6.5 days of stepping); it
+// also lets a waiter through that is late by a step, which cannot happen while every step awaits the one before.
+// The bound: 2^15 polls 0.2 us apart, then polls 3.4 us apart — 2^24 of them (about a minute) for the words whose wait is enqueued AHEAD
+// of the caller's stream (begin, dynamics done: whatever the caller's stream still holds in front of the step — a long inference kernel,
+// an event wait — is waited out there and must not be mistaken for a stalled stream), 2^20 (3.6 s) for the words that only the step's
+// own internal streams stand between (contact pass, side stream, third stream).  debug bit 12 shortens all of them to a few milliseconds.
+__device__ __forceinline__ bool mcr_behind(const McrParams& p, int w, uint32_t epoch) {
+  return (int32_t)((uint32_t)__hip_atomic_load(&p.sync_words[w * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0;
+}
 __device__ __forceinline__ bool mcr_await(const McrParams& p, int w) {
-  const int epoch = mcr_epoch(p), fast = (p.debug & 4096) ? (1 << 14) : (1 << 15), slow = (p.debug & 4096) ? 0 : (1 << 24);
+  const uint32_t epoch = (uint32_t)mcr_epoch(p);
+  const int fast = (p.debug & 4096) ? (1 << 14) : (1 << 15), slow = (p.debug & 4096) ? 0 : (w == W_BEGIN || w == W_DYN) ? (1 << 24) : (1 << 20);
   int spin = 0;
-  for (; spin < fast && (int)(__hip_atomic_load(&p.sync_words[w * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0; ++spin) __builtin_amdgcn_s_sleep(8);
+  for (; spin < fast && mcr_behind(p, w, epoch); ++spin) __builtin_amdgcn_s_sleep(8);
   if (spin < fast) return true;
-  for (spin = 0; spin < slow && (int)(__hip_atomic_load(&p.sync_words[w * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0; ++spin) __builtin_amdgcn_s_sleep(127);
-  if (spin == slow) { atomicAdd(&p.counters[5], 1ull); atomicAdd(&p.status[ST_SPIN_GIVEUP], 1u); return false; }
+  for (spin = 0; spin < slow && mcr_behind(p, w, epoch); ++spin) __builtin_amdgcn_s_sleep(127);
+  if (spin == slow) { atomicAdd(&p.counters[5], 1ull); mcr_raise(p, ST_SPIN_GIVEUP); return false; }
   return true;
 }
 #define MCR_VORDER_ENV_MASK 0xfffff

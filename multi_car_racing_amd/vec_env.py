@@ -86,6 +86,11 @@ class VecMultiCarRacing:
                           float(h_ratio), int(bool(skid_particles)), 0)
         self.h = ctypes.c_void_p()
         _lib.check(self.L.mcr_create(ctypes.byref(cfg), ctypes.byref(self.h)), "mcr_create")
+        self._bound_streams = set()   # caller streams already handed to mcr_bind_stream (the check synchronises the device: once per stream)
+        if int(self.L.mcr_step_ordering(self.h)) & 4:
+            import warnings
+            warnings.warn("another VecMultiCarRacing of this process holds this device's phase-word ordering: this one orders the streams "
+                          "of its step with events (same results, about 0.02 ms more per step)", _lib.McrWarning, stacklevel=2)
         if graph is None:             # hipGraph replay of the step: measured r02 at B=4096 — 0.433 vs 0.435 ms per step, i.e. the gaps
             graph = False             # between the step's dependent kernels are drain/start-up on the GPU, not host launch cost: off
         _lib.check(self.L.mcr_set_step_graph(self.h, int(bool(graph))), "mcr_set_step_graph")
@@ -285,7 +290,9 @@ class VecMultiCarRacing:
             t0 = time.perf_counter()
             self.wait_refills()               # the host fell behind: block instead of letting an env freeze
             self.blocked_s += time.perf_counter() - t0
-        self._step_idx += 1
+        if st.cuda_stream not in self._bound_streams:      # first step on this stream: may it use the phase-word ordering? (synchronises, once)
+            _lib.check(self.L.mcr_bind_stream(self.h, ctypes.c_void_p(st.cuda_stream)), "mcr_bind_stream")
+            self._bound_streams.add(st.cuda_stream)
         a_ptr = None
         if actions is not None:
             if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self.device:
@@ -296,6 +303,7 @@ class VecMultiCarRacing:
         _lib.check(self.L.mcr_step(self.h, a_ptr, ctypes.c_void_p(self.obs.data_ptr()) if self.obs_enabled else None,
                                    ctypes.c_void_p(self.reward.data_ptr()), ctypes.c_void_p(self.done.data_ptr()),
                                    ctypes.c_void_p(self.truncated.data_ptr()), ctypes.c_void_p(st.cuda_stream)), "mcr_step")
+        self._step_idx += 1                   # (only a step that was launched counts: a reported McrError leaves the accounting alone)
         if self.auto_reset:
             self._poll_and_refill()
         return self.obs, self.reward, self.done, {"TimeLimit.truncated": self.truncated, "episode_return": self.episode_return,

@@ -179,12 +179,11 @@ def test_benched_config_b4096_contacts_sample(torch_cuda, oracle):
     assert frozen == 0
 
 
-@pytest.mark.parametrize("knobs, ordering", [({}, 1), ({"MCR_SOFT_SYNC": "0"}, 2), ({"MCR_SOFT_SYNC": "0", "MCR_STOP_EVENTS": "0"}, 0),
-                                             ({"MCR_SOFT_SYNC": "0", "MCR_MERGE_LIST_VIEWS": "0"}, 2)])
+@pytest.mark.parametrize("knobs, ordering", [({}, 1), ({"MCR_SOFT_SYNC": "0"}, 2), ({"MCR_SOFT_SYNC": "0", "MCR_STOP_EVENTS": "0"}, 0)])
 def test_every_stream_ordering_of_the_step_matches_the_oracle(torch_cuda, oracle, monkeypatch, knobs, ordering):
     """The three-chain step orders its streams through phase words in device memory (default where kernels overlap) or through
-    events (profilers that serialise kernels, a wait that gave up, graph capture), with the deferred and re-spawned envs' frames in
-    one list launch or two: every variant is the same computation — rear-end collisions, TimeLimit resets and refills included."""
+    events (profilers that serialise kernels, a wait that gave up, graph capture) — completed by the launches they mark or recorded
+    behind them: every variant is the same computation — rear-end collisions, TimeLimit resets and refills included."""
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     import gc

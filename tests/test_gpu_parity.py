@@ -710,9 +710,12 @@ def test_status_word_reports_a_stalled_stream(torch_cuda, lib):
     for _ in range(3):
         env.step(a)
     torch.cuda.synchronize()
-    assert env.L.mcr_step_ordering(env.h) & 1                # (the per-stream check of the first step passed)
-    lib.check(env.L.mcr_debug_set(env.h, 4096 | 8192))     # short spin bound; the side stream's completion is never posted
+    assert env.L.mcr_step_ordering(env.h) & 1                # (mcr_bind_stream accepted the stream at the first step)
+    import time
+    lib.check(env.L.mcr_debug_set(env.h, 8192))            # the side stream's completion is never posted; the wait's REAL bound applies
+    t0 = time.perf_counter()
     env.step(a); torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 8.0, "a stalled INTERNAL stream must be given up on within seconds (only the waits for the caller's stream are long)"
     with pytest.raises(lib.McrError, match="gave up waiting"):
         env.step(a)
     lib.check(env.L.mcr_debug_set(env.h, 0))
@@ -735,10 +738,14 @@ def test_second_handle_on_a_device_orders_its_streams_with_events(torch_cuda, li
     import gc
     torch = torch_cuda
     gc.collect()
+    import warnings
     a_env = _make(256, 2, 9, contacts=True, streams=2)
-    b_env = _make(256, 2, 9, contacts=True, streams=2)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        b_env = _make(256, 2, 9, contacts=True, streams=2)
     if a_env.L.mcr_concurrent_collide(a_env.h):
         assert a_env.L.mcr_step_ordering(a_env.h) & 1 and not (b_env.L.mcr_step_ordering(b_env.h) & 1)
+        assert b_env.L.mcr_step_ordering(b_env.h) & 4 and any(issubclass(w.category, lib.McrWarning) for w in caught), "the second handle must SAY that it runs on events"
     oa, ob = a_env.reset().clone(), b_env.reset().clone()
     assert torch.equal(oa, ob)
     g = torch.Generator(device="cuda"); g.manual_seed(4)

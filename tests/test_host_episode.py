@@ -167,3 +167,48 @@ def test_generated_episodes_are_well_formed_over_many_seeds(lib):
         assert (dist < 8.0).all()                                                  # spawned within the road's half width + lateral offset
         dirs.add(ep["cw"])
     assert dirs == {True, False}                                                   # use_random_direction draws both
+
+
+def test_generator_pool_survives_fork_and_concurrent_callers(lib):
+    """the generator's helper threads live for the life of the process.  (a) a fork()ed child inherits the pool object but not
+    its threads: a generate call there must still return (it starts a pool of its own); (b) two callers at once — reset() of a batch while the
+    refill thread holds the pool — both get helper threads and the same blobs as a serial run."""
+    import ctypes
+    import os
+    import threading
+    L = lib.load()
+    N, n = 2, 24
+
+    def gen(seed0, threads):
+        mt_t = np.zeros((n, lib.MT_WORDS), np.uint32); mt_g = np.zeros((n, lib.MT_WORDS), np.uint32)
+        for e in range(n):
+            L.mcr_mt_seed(lib.ptr(mt_t[e]), ctypes.c_uint32(seed0 + e)); L.mcr_mt_seed(lib.ptr(mt_g[e]), ctypes.c_uint32(seed0 + e + 77777))
+        blobs = np.zeros((n, lib.episode_bytes()), np.uint8); info = np.zeros((n, 12), np.int32)
+        assert L.mcr_episodes_generate(lib.ptr(mt_t), lib.ptr(mt_g), n, N, 2, lib.ptr(blobs), lib.ptr(info), threads) == 0
+        return blobs
+    ref_a, ref_b = gen(300, 1), gen(900, 1)
+    assert np.array_equal(gen(300, 4), ref_a)                       # the pool exists now (helper threads started)
+    # (b) concurrent callers
+    out = {}
+    ts = [threading.Thread(target=lambda k=k, s=s: out.__setitem__(k, gen(s, 4))) for k, s in (("a", 300), ("b", 900))]
+    for t in ts: t.start()
+    for t in ts: t.join(60)
+    assert not any(t.is_alive() for t in ts)
+    assert np.array_equal(out["a"], ref_a) and np.array_equal(out["b"], ref_b)
+    # (a) fork: the child must not wait for threads it does not have
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        ok = b"0"
+        try:
+            ok = b"1" if np.array_equal(gen(300, 4), ref_a) else b"0"
+        finally:
+            os.write(w, ok); os._exit(0)
+    os.close(w)
+    import select
+    ready, _, _ = select.select([r], [], [], 60)
+    if not ready:
+        os.kill(pid, 9); os.waitpid(pid, 0)
+        raise AssertionError("mcr_episodes_generate hung in a forked child")
+    assert os.read(r, 1) == b"1"
+    os.waitpid(pid, 0)
