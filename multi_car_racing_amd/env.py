@@ -3,6 +3,11 @@ kwargs and defaults, `seed/reset/step/render/close`, obs (num_agents,96,96,3) ui
 (num_agents,), done bool, info {}.  It is a B=1 slice of the batched HIP engine — every step goes through
 the C-ABI; nothing is simulated on the host.
 
+One deviation from the reference's `reset(); reset()`: every episode here is the first episode of a fresh b2World (the reference
+keeps one world for the life of the env; from the second episode on Box2D's proxy ids — the tie-break between cars that reach a tile
+in the same step — come off the broadphase tree's free list).  vec_env.py's docstring has the measurement; poses, visits and frames
+do not depend on it.
+
 RNG parity with the reference: the track comes from `self.np_random` (a numpy RandomState, gym seeding), the
 direction and the car order from the *global* `np.random` stream, drawn in the reference's order
 (:351-357) — so `np.random.seed(s); env.seed(s)` reproduces the reference's episode setup.

@@ -6,6 +6,14 @@ TimeLimit(1000) of gym_multi_car_racing/__init__.py:8.  With `auto_reset=True` a
 on the device inside the same `step` call (its `obs` row is the first observation of the next episode,
 its `done` row is 1) — the convention of baselines-style VecEnvs.
 
+Every episode is the FIRST episode of a fresh b2World.  The reference reuses one world across reset() (multi_car_racing.py:138,
+341): Box2D's proxy ids — which order same-step tile events, i.e. which of two cars that reach a tile in the same step is its first
+visitor (`1000/T` vs `(1 - 1/N)·1000/T`, :113-120) — then come off the b2DynamicTree's free list in an order that depends on every
+proxy move of the episodes before.  Measured with the oracle's literal tree (tools/world_reuse_effect.py, 1,000 second episodes):
+the spawn-step reward of 58 % (N=2) of the (episode, car) pairs differs from the fresh-world order; which tiles are visited, when,
+and every pose are identical.  Reproducing it would put a serial 300-insert tree rebuild (~1 ms on one lane) into the auto-reset
+inside `step`, whose whole reset pass takes 25-48 us.
+
 Determinism: env with global index g uses two numpy-compatible MT19937 streams,
   track stream  RandomState(seed + g)                (the reference's `env.np_random`)
   draw stream   RandomState((seed + g + 2**31) % 2**32)   (stands in for the reference's *global* np.random:

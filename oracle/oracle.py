@@ -220,6 +220,10 @@ def lib():
         L.orc_render_size.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.orc_num_car_contacts.restype = ctypes.c_int
         L.orc_num_car_contacts.argtypes = [ctypes.c_void_p]
+        L.orc_set_world_mode.restype = None
+        L.orc_set_world_mode.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.orc_debug_proxy_ids.restype = ctypes.c_int
+        L.orc_debug_proxy_ids.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         _lib = L
     return _lib
 
@@ -314,6 +318,19 @@ class OracleEnv:
         if self.h:
             self.L.orc_destroy(self.h)
             self.h = None
+
+    def set_world_mode(self, mode):
+        """0 (default, what the kernels implement): every episode is the first episode of a fresh b2World; 1: one world for the life of
+        this env, as the reference keeps it across reset() (multi_car_racing.py:138, 341) — proxy ids come off the b2DynamicTree's free
+        list (mcr_oracle.cpp: DynTree).  Call before the first reset."""
+        self.L.orc_set_world_mode(self.h, int(mode))
+
+    def proxy_ids(self):
+        """world mode 1: (tile ids [T], car fixture ids [N, 8]) of the current episode"""
+        buf = np.zeros(self.T + self.N * 8, np.int32)
+        n = self.L.orc_debug_proxy_ids(self.h, _p(buf), len(buf))
+        assert n == len(buf), (n, len(buf))
+        return buf[:self.T].copy(), buf[self.T:].reshape(self.N, 8).copy()
 
     def set_episode(self, ep):
         tr = ep["track"]

@@ -274,3 +274,41 @@ def test_hud_flag_masks_follow_from_the_triangle():
     src = open(os.path.join(os.path.dirname(__file__), "..", "multi_car_racing_amd", "csrc", "k_view.h")).read()
     m = re.search(r"hud_flag_mask\(int cg, int r4\) \{(.*?)\n\}", src, re.S)
     assert m and "r4 < 2 ? 0xff000000u : 0u" in m.group(1) and "r4 == 0 ? 0x00ffffffu : r4 <= 2 ? 0x0000ffffu : 0x000000ffu" in m.group(1)
+
+
+# ----------------------------------------------------------------------------- b2DynamicTree: proxy ids across reset()
+def test_world_reuse_tree_ids(oracle):
+    """The oracle carries a literal b2DynamicTree (world mode 1) to answer what the reference's reuse of ONE b2World across reset()
+    (multi_car_racing.py:138, 341) does to proxy ids.  Pins: (a) DESIGN 4's claim for the first episode of a world — the k-th fixture
+    created gets leaf id 2k-1 (the first one 0) —, so mode 1 and mode 0 (what the kernels implement) are the same computation there;
+    (b) in a second episode the ids are the free list's: still one distinct id per proxy, no longer ascending in creation order;
+    (c) visits (which tile, which car, when) never depend on ids — only the order of same-step events does."""
+    N = 2
+    a, b = oracle.OracleEnv(N), oracle.OracleEnv(N)
+    b.set_world_mode(1)
+    ep = oracle_episode(oracle, N, 31, 0, use_random_direction=True)
+    a.reset(ep, render=False); b.reset(ep, render=False)
+    tid, fid = b.proxy_ids()
+    want = np.arange(b.T + N * 8) * 2 - 1; want[0] = 0
+    assert np.array_equal(np.concatenate([tid, fid.ravel()]), want)
+    assert np.array_equal(a.env_state()["reward"], b.env_state()["reward"])
+    rng = np.random.RandomState(3)
+    for k in range(160):
+        act = np.stack([rng.uniform(-0.4, 0.4, N), np.ones(N), np.zeros(N)], -1).astype(np.float32)
+        _, r1, d1, _ = a.step(act, render=False); _, r2, d2, _ = b.step(act, render=False)
+        assert np.array_equal(r1, r2) and d1 == d2, k
+    assert np.array_equal(a.state()["bodies"], b.state()["bodies"])
+    # second episode on the same world
+    ep2 = oracle_episode(oracle, N, 77, 0, use_random_direction=True)
+    a.reset(ep2, render=False); b.reset(ep2, render=False)
+    tid2, fid2 = b.proxy_ids()
+    ids = np.concatenate([tid2, fid2.ravel()])
+    assert len(set(ids.tolist())) == len(ids) and ids.min() >= 0
+    assert not np.all(np.diff(ids) > 0), "ids of a reused world come off the free list: not ascending in creation order"
+    for k in range(120):
+        act = np.stack([rng.uniform(-0.4, 0.4, N), np.ones(N), np.zeros(N)], -1).astype(np.float32)
+        a.step(act, render=False); b.step(act, render=False)
+    sa, sb = a.env_state(), b.env_state()
+    assert np.array_equal(sa["visited"], sb["visited"]) and np.array_equal(sa["tile_visited_count"], sb["tile_visited_count"])
+    assert np.array_equal(a.state()["bodies"], b.state()["bodies"])           # ids never reach the solver
+    a.close(); b.close()
