@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0, help="W > 1: ONE GPU, but the host side of a W-rank job on this node: the process is pinned to 1/W of the "
                     "cores the cgroup allows and its track generator takes the threads VecMultiCarRacing gives a rank of a W-rank job; reports "
                     "env-steps/s, the time step() was blocked on the refill thread and the env-steps frozen waiting for the host")
+    ap.add_argument("--rccl", action="store_true", help="with --gpus 1: initialise a 1-rank RCCL (\"nccl\") process group anyway, so that the metric all-reduce of "
+                    "sharded.reduce_metrics and the step's phase-word ordering run beside a live RCCL communicator on the one GPU a box has")
     ap.add_argument("--graph", type=int, default=0, help="1: mcr_step replays a hipGraph of the step (bypassed while kernels are timed; measured gain 0.4 %%); 0 (default): plain launches")
     args = ap.parse_args()
 
@@ -167,6 +169,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif args.rccl:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        warm = torch.ones(4, device=torch.device("cuda", local_rank)); dist.all_reduce(warm); torch.cuda.synchronize()    # the communicator and its streams exist
     dev = torch.device("cuda", local_rank)
 
     B, N, K, W = args.envs, args.agents, args.steps, args.warmup
@@ -321,6 +327,8 @@ def main():
         out["config"]["stream_ordering"] = {1: "phase words", 3: "phase words", 2: "events (stop events)", 0: "events"}.get(int(env.env.L.mcr_step_ordering(env.env.h)), "?") if args.streams != 1 else "single stream"
         if emu:
             out["config"]["emulated_host_share"] = emu
+        if args.rccl and world == 1:
+            out["config"]["process_group"] = "1-rank RCCL group (backend %s): metrics all-reduced over it" % dist.get_backend()
         if K < 200:
             out["config"]["note"] = ("short run: %d steps = %.0f ms of timed work; the default (1000 steps = one TimeLimit period, "
                                      "every env resets once) is the representative figure" % (K, m["elapsed_s"] * 1e3))
@@ -332,7 +340,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(N, bool(args.obs))
         print(json.dumps(out))
     env.close()
-    if world > 1:
+    if world > 1 or args.rccl:
         dist.destroy_process_group()
 
 

@@ -29,7 +29,7 @@ STREAMS=1 python tools/ablate_view.py 2>&1 | grep -v amdgpu.ids > gpurun_out/pro
 bash tools/pmc_view.sh 2>&1 | grep -v amdgpu.ids | tail -24 > gpurun_out/profiles_$R/${R}_view_counters.txt
 rm -rf gpurun_out/pmc_view
 # the other configurations of the DESIGN table (one bench line each)
-for cfg in "--streams 1" "--stagger 0" "--obs 0" "--agents 8" "--agents 1" "--agents 4" "--emulate-world 8"; do
+for cfg in "--streams 1" "--stagger 0" "--obs 0" "--agents 8" "--agents 1" "--agents 4" "--emulate-world 8" "--actions drive" "--envs 16384" "--envs 32768"; do
   tag=$(echo $cfg | tr -d ' -')
   timeout 400 python bench.py --no-cpu-baseline $cfg > gpurun_out/profiles_$R/bench_$tag.json 2> /dev/null
 done
