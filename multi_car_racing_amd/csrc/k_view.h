@@ -582,8 +582,14 @@ __global__ __launch_bounds__(VIEW_THREADS, LIST ? 3 : 4) void k_view(McrParams p
         const int nl = (int)(my_meta >> REC_NL_SHIFT);
         g4 = (nl + 3) >> 2;
         incl = g4;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (ll >= o) incl += t; }
+        // wave-wide inclusive scan by DPP: shifts within the rows of 16 lanes (zero fill), then the row totals broadcast to the rows behind
+        // (six v_add with a DPP operand; __shfl_up is six trips through the LDS crossbar with a wait each)
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
         if (ll == 63) wsum[wave] = incl;
       }
       if (rd == 0 && vrec_mine) vrec[buf ^ 1][tl - 64] = vrec_n;
@@ -670,7 +676,7 @@ __global__ __launch_bounds__(VIEW_THREADS, LIST ? 3 : 4) void k_view(McrParams p
     if (!(dbg & 8)) {
       uint32_t* __restrict__ out = (uint32_t*)(p.obs + (size_t)vw * (96 * 96 * 3));
       // 8 groups of 4 pixels per thread (the last trip: 224 of them): the winners' RGB bytes are packed with three byte permutes
-#pragma unroll 4
+#pragma unroll
       for (int g0 = 0; g0 < (ROWS * 24 + VIEW_THREADS - 1) / VIEW_THREADS; ++g0) {
         const int g = g0 * VIEW_THREADS + tl, r = g / 24, x4 = (g - r * 24) * 4;
         if (g < ROWS * 24) {
