@@ -675,19 +675,25 @@ __global__ __launch_bounds__(VIEW_THREADS, LIST ? 3 : 4) void k_view(McrParams p
     // ---- resolve + packed RGB write-out of the scene rows: 4 pixels -> 12 bytes per ll, rows top-down (arr[::-1], :602)
     if (!(dbg & 8)) {
       uint32_t* __restrict__ out = (uint32_t*)(p.obs + (size_t)vw * (96 * 96 * 3));
-      // 8 groups of 4 pixels per thread (the last trip: 224 of them): the winners' RGB bytes are packed with three byte permutes
+      // 240 threads x 9 trips of 10 rows: a thread keeps its 4-pixel group's column and walks down 10 rows per trip, so that key-buffer and
+      // frame addresses are one division per view plus constants (256 threads x 8 trips: a division and a bounds check per trip); the
+      // winners' RGB bytes are packed with three byte permutes
+      const int r0 = tl / 24, c4 = (tl - r0 * 24) * 4;
+      if (tl < 240) {
+        const uint32_t* kp0 = &keyb[(ROWS - 1 - r0) * KS + c4];
+        uint32_t* o0 = out + (size_t)tl * 3;
 #pragma unroll
-      for (int g0 = 0; g0 < (ROWS * 24 + VIEW_THREADS - 1) / VIEW_THREADS; ++g0) {
-        const int g = g0 * VIEW_THREADS + tl, r = g / 24, x4 = (g - r * 24) * 4;
-        if (g < ROWS * 24) {
-          const uint32_t* kp = &keyb[(ROWS - 1 - r) * KS + x4];
-          const uint32_t c0 = kp[0], c1 = kp[1], c2 = kp[2], c3 = kp[3];
-          // streaming store: the frames of a step (226 MB at B = 4096, N = 2) are written once and read by nobody on the
-          // device — they must not evict the state the step's latency-bound chains live on from L2 / MALL
-          typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-          u32x3 wv;
-          wv.x = __builtin_amdgcn_perm(c1, c0, 0x04020100u); wv.y = __builtin_amdgcn_perm(c2, c1, 0x05040201u); wv.z = __builtin_amdgcn_perm(c3, c2, 0x06050402u);
-          __builtin_nontemporal_store(wv, (u32x3*)(out + (size_t)g * 3));
+        for (int g0 = 0; g0 < (ROWS + 9) / 10; ++g0) {
+          if (g0 * 10 + 10 <= ROWS || r0 + g0 * 10 < ROWS) {               // (the last trip: rows 80..83)
+            const uint32_t* kp = kp0 - g0 * 10 * KS;
+            const uint32_t c0 = kp[0], c1 = kp[1], c2 = kp[2], c3 = kp[3];
+            // streaming store: the frames of a step (226 MB at B = 4096, N = 2) are written once and read by nobody on the
+            // device — they must not evict the state the step's latency-bound chains live on from L2 / MALL
+            typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+            u32x3 wv;
+            wv.x = __builtin_amdgcn_perm(c1, c0, 0x04020100u); wv.y = __builtin_amdgcn_perm(c2, c1, 0x05040201u); wv.z = __builtin_amdgcn_perm(c3, c2, 0x06050402u);
+            __builtin_nontemporal_store(wv, (u32x3*)(o0 + (size_t)g0 * 240 * 3));
+          }
         }
       }
     }
