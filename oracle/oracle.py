@@ -220,6 +220,10 @@ def lib():
         L.orc_render_size.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.orc_num_car_contacts.restype = ctypes.c_int
         L.orc_num_car_contacts.argtypes = [ctypes.c_void_p]
+        L.orc_set_island_order.restype = None
+        L.orc_set_island_order.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.orc_debug_island_diff.restype = ctypes.c_int
+        L.orc_debug_island_diff.argtypes = [ctypes.c_void_p]
         L.orc_set_world_mode.restype = None
         L.orc_set_world_mode.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.orc_debug_proxy_ids.restype = ctypes.c_int
@@ -324,6 +328,15 @@ class OracleEnv:
         this env, as the reference keeps it across reset() (multi_car_racing.py:138, 341) — proxy ids come off the b2DynamicTree's free
         list (mcr_oracle.cpp: DynTree).  Call before the first reset."""
         self.L.orc_set_world_mode(self.h, int(mode))
+
+    def set_island_order(self, mode):
+        """0 (default, what the kernels implement): car<->car contacts in ascending (carA, fixA, carB, fixB), joints 3,2,1,0 per car;
+        1: the order of b2World::Solve's island DFS (mcr_oracle_contacts.inc: island_dfs)."""
+        self.L.orc_set_island_order(self.h, int(mode))
+
+    def island_diff(self):
+        """last step: bit 0 — some car's joints in another order than 3,2,1,0; bit 1 — contacts in another order than ascending"""
+        return int(self.L.orc_debug_island_diff(self.h))
 
     def proxy_ids(self):
         """world mode 1: (tile ids [T], car fixture ids [N, 8]) of the current episode"""

@@ -312,3 +312,41 @@ def test_world_reuse_tree_ids(oracle):
     assert np.array_equal(sa["visited"], sb["visited"]) and np.array_equal(sa["tile_visited_count"], sb["tile_visited_count"])
     assert np.array_equal(a.state()["bodies"], b.state()["bodies"])           # ids never reach the solver
     a.close(); b.close()
+
+
+# ----------------------------------------------------------------------------- b2World::Solve's island order
+def test_island_dfs_order_in_the_oracle(oracle):
+    """The oracle can solve an island's joints and contacts in the order Box2D's depth-first island construction appends them (island
+    order 1) instead of the order the build DEFINES (0: contacts ascending, joints 3,2,1,0 — what the kernels implement).  Pins: without
+    car<->car contacts the two are the same computation (every car is a seed entered through its wheel 3); with contacts the DFS order
+    does differ — contact order and, when a car is entered through another wheel, that car's joint order — and so do the last bits."""
+    N = 2
+    ep = oracle_episode(oracle, N, 4002, 3, use_random_direction=True)
+    a, b = oracle.OracleEnv(N, car_contacts=False), oracle.OracleEnv(N, car_contacts=False)
+    b.set_island_order(1)
+    a.reset(ep, render=False); b.reset(ep, render=False)
+    rng = np.random.RandomState(0)
+    for k in range(80):
+        act = np.stack([rng.uniform(-1, 1, N), rng.uniform(0, 1, N), rng.uniform(0, 1, N)], -1).astype(np.float32)
+        a.step(act, render=False); b.step(act, render=False)
+        assert b.island_diff() == 0
+    assert np.array_equal(a.state()["bodies"], b.state()["bodies"])
+    a.close(); b.close()
+    # rear-end collisions: the car behind floors it
+    seen = 0
+    for e in range(12):
+        ep = oracle_episode(oracle, N, 4002, e, use_random_direction=True)
+        a, b = oracle.OracleEnv(N), oracle.OracleEnv(N)
+        b.set_island_order(1)
+        a.reset(ep, render=False); b.reset(ep, render=False)
+        rng = np.random.RandomState(e)
+        for k in range(160):
+            act = np.stack([rng.uniform(-0.3, 0.3, N), rng.uniform(0.2, 1.0, N), np.zeros(N)], -1).astype(np.float32)
+            act[N // 2:, 1] = 1.0
+            a.step(act, render=False); b.step(act, render=False)
+            if b.num_car_contacts() > 0:
+                seen |= b.island_diff()
+            else:
+                assert b.island_diff() == 0
+        a.close(); b.close()
+    assert seen == 3, f"expected both a permuted joint order and a permuted contact order among the contact steps (got {seen})"
