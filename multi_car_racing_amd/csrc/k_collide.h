@@ -111,11 +111,21 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   // order, then car by car the hull polygons and the wheels.
   __shared__ float4 wfat_new[MCR_MAX_AGENTS * 4], wfat_old[MCR_MAX_AGENTS * 4];
   __shared__ float cfat[MCR_MAX_AGENTS][4];                        // per car: union of its wheels' fat AABBs
-  __shared__ unsigned long long evq[EVQ_CAP];                       // begin events of this pass: stamp << 14 | tile << 5 | car * 4 + wheel
-  __shared__ uint16_t tfl16[MCR_TILE_CAP];                          // flags word of the tiles that take a begin event
+  __shared__ float cfat8[MCR_MAX_AGENTS][4];                       // per car: union of the fat AABBs of all 8 fixtures (which car pairs can hold contacts)
+  __shared__ __attribute__((aligned(16))) unsigned long long evq[EVQ_CAP];   // begin events of this pass: stamp << 14 | tile << 5 | car * 4 + wheel
+  __shared__ __attribute__((aligned(16))) uint16_t tfl16[MCR_TILE_CAP];      // flags word of the tiles that take a begin event
   __shared__ int evn;
+  // the fat AABB of EVERY car fixture (hull polygons as well): needed by the car<->car broadphase contacts, which are settled right
+  // after the proxies — before the tile phases first write the two arrays these alias
+  float4* const ffat_new = (float4*)evq;                           // [8N] (64 x 16 B = the event queue's 1 KB)
+  static_assert(sizeof(unsigned long long) * EVQ_CAP >= sizeof(float4) * MCR_MAX_AGENTS * 8, "ffat_new aliases evq");
   const uint32_t label = pass == 1 ? 0u : es.bp_step;
   const bool fresh = pass == 1 || p.bp_fresh != 0;
+  // car<->car broadphase contacts of the env (mcr_common.h: mcr_cc_stamp_words); the two words of car pairs that hold any are asked for
+  // here, with the proxies' loads, and used after the first barrier
+  uint32_t* const ccs = p.cc_stamp + (size_t)env * mcr_cc_stamp_words(N);
+  unsigned long long live_old = 0ull;
+  if (p.car_contacts && N > 1 && !fresh) live_old = (unsigned long long)ccs[0] | ((unsigned long long)ccs[1] << 32);
   unsigned long long moved_mask;                                    // bit car * 4 + wheel (in the low 32 bits)
   {
     const int c = lane >> 3, fi = lane & 7;
@@ -140,32 +150,39 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
       fbox[lane] = make_float4(lox - 0.05f, loy - 0.05f, hix + 0.05f, hiy + 0.05f);
     }
     bool moved = false;
-    float flx = MCR_MAXFLT, fly = MCR_MAXFLT, fhx = -MCR_MAXFLT, fhy = -MCR_MAXFLT;       // this wheel's fat AABB after the update
-    if (c < N && fi >= 4) {
-      const int wi = (env * N + c) * 4 + (fi - 4), WS = 4 * BN;
+    float flx = MCR_MAXFLT, fly = MCR_MAXFLT, fhx = -MCR_MAXFLT, fhy = -MCR_MAXFLT;       // this WHEEL's fat AABB after the update
+    float glx = MCR_MAXFLT, gly = MCR_MAXFLT, ghx = -MCR_MAXFLT, ghy = -MCR_MAXFLT;       // this fixture's (wheel or hull polygon)
+    if (c < N) {
+      const int wi = (env * N + c) * MCR_BP_FIX + fi, WS = MCR_BP_FIX * BN;
       const float4 xfq = fxf[lane];
       const float ax0 = lox - B2_POLYGON_RADIUS, ay0 = loy - B2_POLYGON_RADIUS, ax1 = hix + B2_POLYGON_RADIUS, ay1 = hiy + B2_POLYGON_RADIUS;   // b2PolygonShape::ComputeAABB
       float4 of = make_float4(MCR_MAXFLT, MCR_MAXFLT, -MCR_MAXFLT, -MCR_MAXFLT);           // "no old proxy": overlaps nothing
       float ux0 = ax0, uy0 = ay0, ux1 = ax1, uy1 = ay1, dx = 0.0f, dy = 0.0f;
       if (!fresh) {
-        of = make_float4(p.bpf[(BP_FAT + 0) * WS + wi], p.bpf[(BP_FAT + 1) * WS + wi], p.bpf[(BP_FAT + 2) * WS + wi], p.bpf[(BP_FAT + 3) * WS + wi]);
+        of = p.bpf[BP_FAT * WS + wi];
         // b2Fixture::Synchronize: union of the AABBs at the transforms the last step was entered and left with
-        ux0 = mcr_min(p.bpf[(BP_PREV + 0) * WS + wi], ax0); uy0 = mcr_min(p.bpf[(BP_PREV + 1) * WS + wi], ay0);
-        ux1 = mcr_max(p.bpf[(BP_PREV + 2) * WS + wi], ax1); uy1 = mcr_max(p.bpf[(BP_PREV + 3) * WS + wi], ay1);
-        dx = 2.0f * (xfq.x - p.bpf[(BP_PREVP + 0) * WS + wi]); dy = 2.0f * (xfq.y - p.bpf[(BP_PREVP + 1) * WS + wi]);   // b2_aabbMultiplier * displacement
+        const float4 pv = p.bpf[BP_PREV * WS + wi], pp = p.bpf[BP_PREVP * WS + wi];
+        ux0 = mcr_min(pv.x, ax0); uy0 = mcr_min(pv.y, ay0); ux1 = mcr_max(pv.z, ax1); uy1 = mcr_max(pv.w, ay1);
+        dx = 2.0f * (xfq.x - pp.x); dy = 2.0f * (xfq.y - pp.y);                              // b2_aabbMultiplier * displacement
       }
       float4 nf = of;
+      bool mv = false;
       if (fresh || !(of.x <= ux0 && of.y <= uy0 && ux1 <= of.z && uy1 <= of.w)) {          // b2DynamicTree::MoveProxy (b2AABB::Contains)
         nf = make_float4(ux0 - 0.1f, uy0 - 0.1f, ux1 + 0.1f, uy1 + 0.1f);                   // b2_aabbExtension
         if (dx < 0.0f) nf.x += dx; else nf.z += dx;
         if (dy < 0.0f) nf.y += dy; else nf.w += dy;
-        moved = true;
-        p.bpf[(BP_FAT + 0) * WS + wi] = nf.x; p.bpf[(BP_FAT + 1) * WS + wi] = nf.y; p.bpf[(BP_FAT + 2) * WS + wi] = nf.z; p.bpf[(BP_FAT + 3) * WS + wi] = nf.w;
+        mv = true;
+        p.bpf[BP_FAT * WS + wi] = nf;
       }
-      p.bpf[(BP_PREV + 0) * WS + wi] = ax0; p.bpf[(BP_PREV + 1) * WS + wi] = ay0; p.bpf[(BP_PREV + 2) * WS + wi] = ax1; p.bpf[(BP_PREV + 3) * WS + wi] = ay1;
-      p.bpf[(BP_PREVP + 0) * WS + wi] = xfq.x; p.bpf[(BP_PREVP + 1) * WS + wi] = xfq.y;
-      wfat_new[c * 4 + (fi - 4)] = nf; wfat_old[c * 4 + (fi - 4)] = of;
-      flx = nf.x; fly = nf.y; fhx = nf.z; fhy = nf.w;
+      p.bpf[BP_PREV * WS + wi] = make_float4(ax0, ay0, ax1, ay1);
+      p.bpf[BP_PREVP * WS + wi] = make_float4(xfq.x, xfq.y, 0.0f, 0.0f);
+      ffat_new[lane] = nf;
+      glx = nf.x; gly = nf.y; ghx = nf.z; ghy = nf.w;
+      if (fi >= 4) {
+        moved = mv;
+        wfat_new[c * 4 + (fi - 4)] = nf; wfat_old[c * 4 + (fi - 4)] = of;
+        flx = nf.x; fly = nf.y; fhx = nf.z; fhy = nf.w;
+      }
     }
     {
       const unsigned long long mm = __ballot(moved);                                         // lane = car * 8 + 4 + wheel -> bit car * 4 + wheel
@@ -178,6 +195,11 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
       fhx = mcr_max(fhx, __shfl_xor(fhx, o)); fhy = mcr_max(fhy, __shfl_xor(fhy, o));
     }
     if (fi == 0 && c < MCR_MAX_AGENTS) { cfat[c][0] = flx; cfat[c][1] = fly; cfat[c][2] = fhx; cfat[c][3] = fhy; }
+    for (int o = 1; o < 8; o <<= 1) {
+      glx = mcr_min(glx, __shfl_xor(glx, o)); gly = mcr_min(gly, __shfl_xor(gly, o));
+      ghx = mcr_max(ghx, __shfl_xor(ghx, o)); ghy = mcr_max(ghy, __shfl_xor(ghy, o));
+    }
+    if (fi == 0 && c < MCR_MAX_AGENTS) { cfat8[c][0] = glx; cfat8[c][1] = gly; cfat8[c][2] = ghx; cfat8[c][3] = ghy; }
     if (lane == 0) evn = 0;
     for (int o = 1; o < 8; o <<= 1) {
       lox = mcr_min(lox, __shfl_xor(lox, o)); loy = mcr_min(loy, __shfl_xor(loy, o));
@@ -186,6 +208,42 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
     if (fi == 0 && c < MCR_MAX_AGENTS) { cbox[c][0] = lox - 0.05f; cbox[c][1] = loy - 0.05f; cbox[c][2] = hix + 0.05f; cbox[c][3] = hiy + 0.05f; }
   }
   __syncthreads();
+
+  // ---- car<->car broadphase contacts (b2ContactManager: AddPair / Destroy for the dynamic fixture pairs).  A contact of fixtures
+  // (pa, pb) of two different cars (not wheel vs wheel: the fixtures' filters) exists exactly while their fat AABBs overlap: made by
+  // the FindNewContacts that first sees the overlap (label + 1 is remembered: contacts of a later batch, and inside a batch of a
+  // higher (pa, pb), sit nearer the heads of the bodies' contact-edge lists — what b2World::Solve's island DFS walks, below),
+  // destroyed by the Collide that sees it gone.  Only car pairs whose boxes of fat AABBs meet, or that held contacts, are looked at.
+  if (p.car_contacts && N > 1) {
+    unsigned long long live_new = 0ull;
+    const int Fq = 8 * N;
+    unsigned long long look;                                              // bit a * 8 + b: the pair's boxes meet
+    {
+      const int a = lane >> 3, b = lane & 7;
+      const bool near = a < b && b < N && !(cfat8[a][0] > cfat8[b][2] || cfat8[a][2] < cfat8[b][0] || cfat8[a][1] > cfat8[b][3] || cfat8[a][3] < cfat8[b][1]);
+      look = __ballot(near) | live_old;
+    }
+    while (look) {
+      const int ab = __builtin_ctzll(look); look &= look - 1ull;
+      const int a = ab >> 3, b = ab & 7;
+      const bool had = ((live_old >> ab) & 1ull) != 0ull;
+      const int fa = lane >> 3, fb = lane & 7, pa = a * 8 + fa, pb = b * 8 + fb;
+      const bool pairs = !(fa >= 4 && fb >= 4);                             // wheel vs wheel: filtered (b2ContactFilter::ShouldCollide)
+      uint32_t st = 0u, st0 = 0u;
+      if (pairs) {
+        if (had) st0 = ccs[2 + pa * Fq + pb];
+        const float4 A = ffat_new[pa], Bq = ffat_new[pb];
+        const bool ov = !(Bq.x - A.z > 0.0f || Bq.y - A.w > 0.0f || A.x - Bq.z > 0.0f || A.y - Bq.w > 0.0f);       // b2TestOverlap(b2AABB, b2AABB)
+        st = ov ? (st0 ? st0 : label + 1u) : 0u;
+      }
+      const bool any = __ballot(st != 0u) != 0ull;
+      // (a pair that held no contact has nothing valid in memory: its first contacts write all of its words)
+      if (pairs && (had ? st != st0 : any)) ccs[2 + pa * Fq + pb] = st;
+      if (any) live_new |= 1ull << (a * 8 + b);
+    }
+    if (lane == 0 && (fresh || live_new != live_old)) { ccs[0] = (uint32_t)live_new; ccs[1] = (uint32_t)(live_new >> 32); }
+  }
+  __syncthreads();                                                 // ffat_new (= evq) is free from here on
 
   // uniform per-car accumulators (every lane keeps the same values)
   double reward[MCR_MAX_AGENTS]; int tvc[MCR_MAX_AGENTS];
@@ -365,8 +423,8 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   }
 
   // ---- car<->car manifolds (b2Contact::Update for the dynamic pairs) at the same entry poses.
-  // Candidate fixture pairs are enumerated in the DEFINED contact order (carA, fixA, carB, fixB); touching
-  // ones are compacted in that order and inherit the stored impulses of the previous step by feature id.
+  // Candidate fixture pairs are enumerated in ascending (carA, fixA, carB, fixB); touching ones are compacted in that
+  // order, inherit the stored impulses of the previous step by feature id, and are STORED in island order (below).
   uint32_t* store = p.cc_store + (size_t)env * (MCR_CC_MAX * MCR_CC_WORDS + 4);
   // cheap exit: no pair of car boxes (tight AABB + 0.05) overlaps -> no fixture pair can touch
   bool any_pair = false;
@@ -446,7 +504,72 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
     }
     __syncthreads();
     const int nn = base < MCR_CC_MAX ? base : MCR_CC_MAX;
-    for (int i = lane; i < nn * 16; i += 64) store[4 + (i >> 4) * MCR_CC_WORDS + (i & 15)] = newrec[i >> 4][i & 15];
+    // ---- the order b2Island::Solve runs the touching contacts in (and, per car, its four joints): b2World::Solve builds an island by a
+    // depth-first search with an explicit stack — seeds from m_bodyList (its head is the body created LAST: car N-1's wheels 3, 2, 1, 0,
+    // its hull, car N-2's ..); for the body it pops it appends the body's touching contacts in contact-edge-list order (head = the
+    // contact created last: descending (batch, pa, pb), cc_stamp above) and pushes their other bodies, then appends the body's joints
+    // (hull: j3, j2, j1, j0; a wheel: its one joint) and pushes theirs.  Constraints of different islands, and joints of different
+    // cars, touch disjoint bodies and commute: what is left is ONE order of the contacts — the records are stored in it, the contact
+    // chain of k_dynamics takes them as they come — and an order of the 4 joints per car (store[2..3], 2 bits per position; a car
+    // that the search enters through its wheel k solves joint k first).  One lane; the scratch aliases the candidate list.
+    uint8_t* const dord = (uint8_t*)(cand + MCR_CC_MAX) + MCR_CC_MAX;     // island order: dord[i] = index of the i-th contact in newrec
+    uint32_t* const skey = cand; uint8_t* const sorted = (uint8_t*)(cand + MCR_CC_MAX); uint8_t* const stk = dord + MCR_CC_MAX;
+    if (lane < nn) {
+      const uint32_t k = newrec[lane][0];
+      const int pa = (int)(k & 15u) * 8 + (int)((k >> 4) & 15u), pb = (int)((k >> 8) & 15u) * 8 + (int)((k >> 12) & 15u);
+      skey[lane] = (ccs[2 + pa * 8 * N + pb] << 12) | ((uint32_t)pa << 6) | (uint32_t)pb;
+    }
+    __syncthreads();
+    uint32_t incars = 0u;                                                  // cars with a touching contact (the others: no contacts, joints 3,2,1,0)
+    if (lane < nn) {
+      const uint32_t mine = skey[lane];
+      int rank = 0;
+      for (int j2 = 0; j2 < nn; ++j2) rank += skey[j2] > mine ? 1 : 0;     // (keys are distinct) newest first
+      sorted[rank] = (uint8_t)lane;
+    }
+    for (int i = 0; i < nn; ++i) { const uint32_t k = newrec[i][0]; incars |= (1u << (k & 15u)) | (1u << ((k >> 8) & 15u)); }
+    __syncthreads();
+    if (lane == 0) {
+      unsigned long long bflag = 0ull, jo = 0ull; uint32_t cflag = 0u, jflag = 0u, jn = 0u; int no = 0;
+      for (int c = N - 1; c >= 0; --c) for (int kb = 4; kb >= 0; --kb) {
+        if (!((incars >> c) & 1u)) { jo |= 0x1bull << (c * 8); break; }       // (seeded at wheel 3: j3, then the hull's j2, j1, j0)
+        if ((bflag >> (c * 5 + kb)) & 1ull) continue;
+        int sp = 0; stk[sp++] = (uint8_t)(c * 5 + kb); bflag |= 1ull << (c * 5 + kb);
+        while (sp > 0) {
+          const int b = stk[--sp], bc = b / 5, bk = b - bc * 5;
+          for (int t = 0; t < nn; ++t) {
+            const int i = sorted[t];
+            if ((cflag >> i) & 1u) continue;
+            const uint32_t k = newrec[i][0];
+            const int fa = (int)((k >> 4) & 15u), fb = (int)((k >> 12) & 15u);
+            const int ba = (int)(k & 15u) * 5 + (fa < 4 ? 0 : fa - 3), bb = (int)((k >> 8) & 15u) * 5 + (fb < 4 ? 0 : fb - 3);
+            if (ba != b && bb != b) continue;
+            dord[no++] = (uint8_t)i; cflag |= 1u << i;
+            const int other = ba == b ? bb : ba;
+            if (!((bflag >> other) & 1ull)) { stk[sp++] = (uint8_t)other; bflag |= 1ull << other; }
+          }
+          if (bk == 0) {
+            for (int q = 3; q >= 0; --q) if (!((jflag >> (bc * 4 + q)) & 1u)) {
+              const uint32_t pos = (jn >> (bc * 4)) & 15u;
+              jo |= (unsigned long long)q << (bc * 8 + 2 * pos); jn += 1u << (bc * 4); jflag |= 1u << (bc * 4 + q);
+              const int w = bc * 5 + q + 1;
+              if (!((bflag >> w) & 1ull)) { stk[sp++] = (uint8_t)w; bflag |= 1ull << w; }
+            }
+          } else {
+            const int q = bk - 1;
+            if (!((jflag >> (bc * 4 + q)) & 1u)) {
+              const uint32_t pos = (jn >> (bc * 4)) & 15u;
+              jo |= (unsigned long long)q << (bc * 8 + 2 * pos); jn += 1u << (bc * 4); jflag |= 1u << (bc * 4 + q);
+              const int hb = bc * 5;
+              if (!((bflag >> hb) & 1ull)) { stk[sp++] = (uint8_t)hb; bflag |= 1ull << hb; }
+            }
+          }
+        }
+      }
+      store[2] = (uint32_t)jo; store[3] = (uint32_t)(jo >> 32);
+    }
+    __syncthreads();
+    for (int i = lane; i < nn * 16; i += 64) store[4 + (i >> 4) * MCR_CC_WORDS + (i & 15)] = newrec[dord[i >> 4]][i & 15];
     if (lane == 0) { store[0] = (uint32_t)nn; store[1] = base > MCR_CC_MAX ? 1u : 0u; if (base > MCR_CC_MAX) mcr_raise(p, ST_CC_OVERFLOW); }
     nn_final = nn;
   } else if (lane == 0 && pass == 1) store[0] = 0;

@@ -203,12 +203,36 @@ __device__ __forceinline__ void cc_masses(const CcMass& S, int body, float& m, f
   if (body == 0) { m = S.mH; i = S.iH; lc = v2(S.lcx, S.lcy); }
   else { m = S.mW; i = S.iW; lc = v2(0.0f, 0.0f); }
 }
+// ---- island order of a car's joints (k_collide.h: b2World::Solve's depth-first search; store[2..3], 2 bits per position).  The joint
+// code below is written for the order 3,2,1,0 with the state of joint q and of its wheel in registers J[q], b[q + 1]; a car whose
+// search entered through another wheel gets its (joint, wheel) register sets PERMUTED for the solve instead — slot 3 holds what is
+// solved first — and put back after it: a 5-comparator sorting network of per-lane selects, run only in waves that hold such a car.
+// What goes by wheel identity in between: the joint anchors (anchor_of) and the body rows of the contact exchange (xmap).
+__device__ __forceinline__ void cswapf(bool sw, float& a, float& b) { const float t = sw ? b : a; b = sw ? a : b; a = t; }
+__device__ __forceinline__ void cswapi(bool sw, int& a, int& b) { const int t = sw ? b : a; b = sw ? a : b; a = t; }
+__device__ __forceinline__ void slot_exchange(Joint* J, Body* b, int* key, int* tag, int i, int j) {
+  const bool sw = key[i] > key[j];
+  cswapi(sw, key[i], key[j]); cswapi(sw, tag[i], tag[j]);
+  cswapf(sw, J[i].ix, J[j].ix); cswapf(sw, J[i].iy, J[j].iy); cswapf(sw, J[i].iz, J[j].iz); cswapf(sw, J[i].im, J[j].im);
+  cswapf(sw, J[i].motorSpeed, J[j].motorSpeed); cswapi(sw, J[i].limit, J[j].limit);
+  Body& x = b[i + 1]; Body& y = b[j + 1];
+  cswapf(sw, x.cx, y.cx); cswapf(sw, x.cy, y.cy); cswapf(sw, x.a, y.a); cswapf(sw, x.vx, y.vx); cswapf(sw, x.vy, y.vy); cswapf(sw, x.w, y.w);
+}
+// sorts the four slots ascending by key; tag rides along
+__device__ __forceinline__ void slot_sort(Joint* J, Body* b, int* key, int* tag) {
+  slot_exchange(J, b, key, tag, 0, 1); slot_exchange(J, b, key, tag, 2, 3); slot_exchange(J, b, key, tag, 0, 2);
+  slot_exchange(J, b, key, tag, 1, 3); slot_exchange(J, b, key, tag, 1, 2);
+}
+__device__ __forceinline__ float pick4(int i, float a0, float a1, float a2, float a3) { return i == 0 ? a0 : i == 1 ? a1 : i == 2 ? a2 : a3; }
+// row of body `body` (0 hull, 1 + wheel) of the car in lane L of the exchange arrays: xmap[L] = slot of wheel w at bits 2w
+__device__ __forceinline__ int cc_row(const int* xmap, int L, int body) { return body == 0 ? 0 : 1 + ((xmap[L] >> (2 * (body - 1))) & 3); }
 // b2ContactSolver ctor + InitializeVelocityConstraints + WarmStart for one stored manifold
-__device__ inline void cc_init(const CcMass& S, const uint32_t* rec, int rec_index, int leader_lane, float (*xp)[64], float (*xv)[64], float* vc) {
+__device__ inline void cc_init(const CcMass& S, const uint32_t* rec, int rec_index, int leader_lane, float (*xp)[64], float (*xv)[64], const int* xmap, float* vc) {
   const uint32_t key = rec[0];
   const int carA = key & 15, fixA = (key >> 4) & 15, carB = (key >> 8) & 15, fixB = (key >> 12) & 15;
-  const int bA = cc::fixture_body(fixA), bB = cc::fixture_body(fixB);
   const int LA = leader_lane + carA, LB = leader_lane + carB;
+  // (rows of the exchange arrays; row 0 is the hull, so the masses below go by the row as well)
+  const int bA = cc_row(xmap, LA, cc::fixture_body(fixA)), bB = cc_row(xmap, LB, cc::fixture_body(fixB));
   const int type = rec[1] & 255; int n = (int)(rec[1] >> 8);
   float mA, iA, mB, iB; V2 lcA, lcB; cc_masses(S, bA, mA, iA, lcA); cc_masses(S, bB, mB, iB, lcB);
   const V2 cA = v2(xp[0 * 5 + bA][LA], xp[1 * 5 + bA][LA]); const float aA = xp[2 * 5 + bA][LA];
@@ -371,11 +395,11 @@ __device__ inline void cc_velocity(const CcMass& S, float* __restrict__ vcf, flo
 }
 
 // b2ContactSolver::SolvePositionConstraints for one contact; returns its min separation
-__device__ inline float cc_position(const CcMass& S, const uint32_t* rec, int leader_lane, float (*xp)[64]) {
+__device__ inline float cc_position(const CcMass& S, const uint32_t* rec, int leader_lane, float (*xp)[64], const int* xmap) {
   const uint32_t key = rec[0];
   const int carA = key & 15, fixA = (key >> 4) & 15, carB = (key >> 8) & 15, fixB = (key >> 12) & 15;
-  const int bA = cc::fixture_body(fixA), bB = cc::fixture_body(fixB);
   const int LA = leader_lane + carA, LB = leader_lane + carB;
+  const int bA = cc_row(xmap, LA, cc::fixture_body(fixA)), bB = cc_row(xmap, LB, cc::fixture_body(fixB));
   const int type = rec[1] & 255; const int n = (int)(rec[1] >> 8);
   float mA, iA, mB, iB; V2 lcA, lcB; cc_masses(S, bA, mA, iA, lcA); cc_masses(S, bB, mB, iB, lcB);
   V2 cA = v2(xp[0 * 5 + bA][LA], xp[1 * 5 + bA][LA]); float aA = xp[2 * 5 + bA][LA];
@@ -432,6 +456,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
   __shared__ uint32_t pcrec[DYN_VC_POOL][16];      // manifold records (key, type|n, local normal/point, 2 points) for the position sweeps
   __shared__ int xisl[64], xact[64], xjok[64], xcok[64];
   __shared__ float xms[64];
+  __shared__ int xmap[64];                            // per lane: slot of wheel w's registers at bits 2w (island order of the joints)
   const int g = blk * 64 + threadIdx.x;
   const int env = mcr_env_of_slot(p, mcr_dyn_slot(p, blk), true), agent = g % p.G;
   const int env_end = p.env0 + p.nenv;
@@ -578,6 +603,8 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
   // launch, finds none either; its store[0] is not read)
   if (run && p.car_contacts && p.N > 1 && !(p.cc_mode && mode == 0 && p.role == 1)) ccn = (int)store[0];
   const bool wave_cc = __any(ccn > 0) != 0;
+  int jord8 = 0x1b, wq[4] = {0, 1, 2, 3};      // island order of this car's joints (3,2,1,0 unless a contact says otherwise); wheel held by slot t
+  bool wave_perm = false;
   DYN_STAMP(1);
   int pool_base = 0;
   int isl = agent;                        // island id of this car = lowest car id linked to it by touching contacts
@@ -589,6 +616,25 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
     pool_base = incl - need;
     if (agent == 0 && pool_base + ccn > DYN_VC_POOL) { ccn = DYN_VC_POOL - pool_base; if (ccn < 0) ccn = 0; store[1] = 2u; mcr_raise(p, ST_CC_OVERFLOW); }
     ccn = __shfl(ccn, leader_lane); pool_base = __shfl(pool_base, leader_lane);
+    if (ccn > 0) jord8 = (int)((store[2 + (agent >> 2)] >> ((agent & 3) * 8)) & 255u);
+    wave_perm = __any(jord8 != 0x1b) != 0;
+    if (wave_perm) {
+      int key[4];                                       // joint q goes to slot 3 - (its position in the island order)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int pos = 0;
+#pragma unroll
+        for (int t = 1; t < 4; ++t) if (((jord8 >> (2 * t)) & 3) == q) pos = t;
+        key[q] = 3 - pos; wq[q] = q;
+      }
+      slot_sort(J, b, key, wq);
+    }
+    {
+      int m = 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) m |= t << (2 * wq[t]);
+      xmap[lane] = m;
+    }
     if (ccn > 0) {
 #pragma unroll
       for (int k = 0; k < 5; ++k) {
@@ -603,7 +649,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
       for (int c = 0; c < MCR_MAX_AGENTS; ++c) root[c] = c;
       for (int i = 0; i < ccn; ++i) {
         const uint32_t* rec = store + 4 + i * MCR_CC_WORDS;
-        cc_init(CM, rec, i, leader_lane, xp, xv, vcpool[pool_base + i]);
+        cc_init(CM, rec, i, leader_lane, xp, xv, xmap, vcpool[pool_base + i]);
 #pragma unroll
         for (int w = 0; w < 16; ++w) pcrec[pool_base + i][w] = rec[w];      // once per step instead of one HBM round trip per sweep
         // union-find over cars (b2World::Solve island DFS through touching contacts)
@@ -645,7 +691,11 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
   if (run && !resume) {
     // joints, island order 3,2,1,0
 #pragma unroll
-    for (int q = 3; q >= 0; --q) joint_init(J[q], b[0], b[q + 1], S.anchor_x[q], S.anchor_y[q], lcx, lcy, mH, iH, mW, iW);
+    for (int q = 3; q >= 0; --q) {
+      float ax = S.anchor_x[q], ay = S.anchor_y[q];
+      if (wave_perm) { ax = pick4(wq[q], S.anchor_x[0], S.anchor_x[1], S.anchor_x[2], S.anchor_x[3]); ay = pick4(wq[q], S.anchor_y[0], S.anchor_y[1], S.anchor_y[2], S.anchor_y[3]); }
+      joint_init(J[q], b[0], b[q + 1], ax, ay, lcx, lcy, mH, iH, mW, iW);
+    }
   }
   if (resume && run && agent == 0) atomicAdd(&p.counters[1], 1ull);
   if (resume) {   // the position solver needs nothing from InitVelocityConstraints but the motor mass (limit state is stored)
@@ -788,7 +838,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
           const int ca = rec[0] & 15;
           const int r = xisl[leader_lane + ca];
           if (!xact[leader_lane + r]) continue;
-          const float ms = cc_position(CM, rec, leader_lane, xp);
+          const float ms = cc_position(CM, rec, leader_lane, xp, xmap);
 #pragma unroll
           for (int c = 0; c < MCR_MAX_AGENTS; ++c) if (c == r) minSep[c] = mcr_min(minSep[c], ms);
         }
@@ -804,7 +854,9 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
         }
 #pragma unroll
         for (int q = 3; q >= 0; --q) {
-          bool jo = joint_position(J[q], b[0], b[q + 1], S.anchor_x[q], S.anchor_y[q], lcx, lcy, mH, iH, mW, iW, hull_rot);
+          float ax = S.anchor_x[q], ay = S.anchor_y[q];
+          if (wave_perm) { ax = pick4(wq[q], S.anchor_x[0], S.anchor_x[1], S.anchor_x[2], S.anchor_x[3]); ay = pick4(wq[q], S.anchor_y[0], S.anchor_y[1], S.anchor_y[2], S.anchor_y[3]); }
+          bool jo = joint_position(J[q], b[0], b[q + 1], ax, ay, lcx, lcy, mH, iH, mW, iW, hull_rot);
           jointsOk = jointsOk && jo;
         }
       }
@@ -825,6 +877,10 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
         else if (!mv) active = false;
       }
       __syncthreads();
+    }
+    if (wave_perm) {                                     // the (joint, wheel) register sets back where the rest of the step expects them
+      int tag[4] = {0, 0, 0, 0};
+      slot_sort(J, b, wq, tag);
     }
   }
   if (defer_cap > 0) {

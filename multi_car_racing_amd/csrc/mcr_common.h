@@ -111,13 +111,18 @@ enum {
   CU_ONROAD_NEW = 4,  // the same bits as this step's Collide found them (k_collide writes, the step's k_dynamics promotes them to CU_ONROAD)
   CU_COUNT = 5
 };
-// broadphase model of the wheels (k_collide.h): f32 fields  bpf[field][4 * BN]  (car * 4 + wheel)
+// broadphase model of the car fixtures (k_collide.h): float4 planes  bpf[plane][MCR_BP_FIX * BN]  (car * 8 + fixture: 0..3 hull polygons, 4..7 wheels)
+#define MCR_BP_FIX 8
 enum {
-  BP_FAT = 0,    // +0..3: fat AABB of the wheel's proxy (lo.x lo.y hi.x hi.y)
-  BP_PREV = 4,   // +0..3: the fixture's AABB at the transform the last contact pass saw (b2PolygonShape::ComputeAABB)
-  BP_PREVP = 8,  // +0..1: that transform's p
-  BP_COUNT = 10
+  BP_FAT = 0,    // fat AABB of the fixture's proxy (lo.x lo.y hi.x hi.y)
+  BP_PREV = 1,   // the fixture's AABB at the transform the last contact pass saw (b2PolygonShape::ComputeAABB)
+  BP_PREVP = 2,  // .xy: that transform's p
+  BP_COUNT = 3
 };
+// car<->car broadphase contacts of an env (k_collide.h): words [0,1] = which car pairs hold any (bit carA * 8 + carB), then per fixture
+// pair (pa, pb), pa = carA * 8 + fixA < pb: 0 = no contact (the fat AABBs do not overlap), else 1 + the label of the FindNewContacts
+// batch that made it
+MCR_HD size_t mcr_cc_stamp_words(int N) { return 2 + (size_t)64 * N * N; }
 // per-env state
 struct McrEnvState {
   double t;                // self.t

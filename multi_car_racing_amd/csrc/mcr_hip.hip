@@ -140,7 +140,8 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   const size_t o_touch = carve(sizeof(uint32_t) * MCR_TILE_CAP * (size_t)B);
   const size_t o_tflags = carve(sizeof(uint16_t) * MCR_TILE_CAP * (size_t)B);
   const size_t o_cc = carve(sizeof(uint32_t) * (size_t)B * (MCR_CC_MAX * MCR_CC_WORDS + 4));
-  const size_t o_bpf = carve(sizeof(float) * BP_COUNT * 4 * BN);
+  const size_t o_bpf = carve(sizeof(float4) * BP_COUNT * MCR_BP_FIX * BN);
+  const size_t o_ccstamp = carve(sizeof(uint32_t) * (size_t)B * mcr_cc_stamp_words(N));
   const size_t o_bpstamp = carve(sizeof(uint32_t) * (size_t)B * MCR_TILE_CAP * 4 * N);
   const size_t o_part = carve(2 * (size_t)B);                 // x2: the touch verdicts of a step live in the buffer of its parity
   const size_t o_dpart = carve(B);
@@ -173,7 +174,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   P.B = B; P.N = N; P.G = G; P.BN = (int)BN;
   P.carf = (float*)(base + o_carf); P.card = (double*)(base + o_card); P.caru = (uint32_t*)(base + o_caru);
   P.env = (McrEnvState*)(base + o_env); P.tile_touch = (uint32_t*)(base + o_touch); P.tile_flags = (uint16_t*)(base + o_tflags);
-  P.cc_store = (uint32_t*)(base + o_cc); P.bpf = (float*)(base + o_bpf); P.bp_stamp = (uint32_t*)(base + o_bpstamp); P.shapes = (const McrShapes*)(base + o_shapes); P.slots = base + o_slots;
+  P.cc_store = (uint32_t*)(base + o_cc); P.bpf = (float4*)(base + o_bpf); P.cc_stamp = (uint32_t*)(base + o_ccstamp); P.bp_stamp = (uint32_t*)(base + o_bpstamp); P.shapes = (const McrShapes*)(base + o_shapes); P.slots = base + o_slots;
   h->view_stamps = (unsigned long long*)(base + o_vscratch);
   P.viewp = (float*)(base + o_viewp);
   P.part = base + o_part; P.dpart = base + o_dpart; P.collide_epoch = (int32_t*)(base + o_epoch); h->dev_step_ctr = P.collide_epoch + B; P.sync_words = (int32_t*)(base + o_sync); P.dlist = (int32_t*)(base + o_dlist); P.rlist = (int32_t*)(base + o_rlist); P.defer_state = base + o_dstate; P.counters = (unsigned long long*)(base + o_counters); P.status_dev = (uint32_t*)(base + o_statusdev); P.stats = (double*)(base + o_stats);
@@ -789,7 +790,7 @@ extern "C" int mcr_get_env_state(mcr_env* h, double* reward, int32_t* tvc, uint8
 
 // ---------------------------------------------------------------------------- full state snapshot / restore
 namespace {
-struct BlobLayout { size_t carf, card, caru, es, touch, tflags, cc, viewp, carpoly, bpf, stamp, slot, particles, total; };
+struct BlobLayout { size_t carf, card, caru, es, touch, tflags, cc, viewp, carpoly, bpf, stamp, ccstamp, slot, particles, total; };
 BlobLayout blob_layout(int N, bool with_particles) {
   BlobLayout L; size_t o = 16;                                         // header: magic (carries the layout version), N, flags (bit 0: particles), total bytes
   L.carf = o; o += sizeof(float) * CF_COUNT * N;
@@ -801,14 +802,15 @@ BlobLayout blob_layout(int N, bool with_particles) {
   L.cc = o; o += sizeof(uint32_t) * (MCR_CC_MAX * MCR_CC_WORDS + 4);
   L.viewp = o; o += sizeof(float) * MCR_VIEWP_FLOATS * N;
   L.carpoly = o; o += sizeof(float) * MCR_CARPOLY_FLOATS * N;
-  L.bpf = o; o += sizeof(float) * BP_COUNT * 4 * N;
+  L.bpf = o; o += sizeof(float4) * BP_COUNT * MCR_BP_FIX * N;
   L.stamp = o; o += sizeof(uint32_t) * MCR_TILE_CAP * 4 * N;
+  L.ccstamp = o; o += sizeof(uint32_t) * mcr_cc_stamp_words(N);
   o = (o + 15) & ~(size_t)15; L.slot = o; o += MCR_SLOT_BYTES;
   L.particles = o; if (with_particles) o += sizeof(uint32_t) * MCR_PART_WORDS * N;
   L.total = o;
   return L;
 }
-const uint32_t BLOB_MAGIC = 0x3352434du;   // "MCR3": bumped whenever the layout of a blob (McrEnvState, slot image, field lists) changes
+const uint32_t BLOB_MAGIC = 0x3452434du;   // "MCR4": bumped whenever the layout of a blob (McrEnvState, slot image, field lists) changes
 }  // namespace
 
 extern "C" size_t mcr_state_blob_bytes(const mcr_env* h) { return h ? blob_layout(h->P.N, h->P.particles != nullptr).total : 0; }
@@ -835,7 +837,8 @@ extern "C" int mcr_get_state_blob(mcr_env* h, int env, void* blob_out) {
   HIPCHK(hipMemcpy(b + L.cc, P.cc_store + (size_t)env * ccw, sizeof(uint32_t) * ccw, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(b + L.viewp, P.viewp + (size_t)env * N * MCR_VIEWP_FLOATS, sizeof(float) * MCR_VIEWP_FLOATS * N, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(b + L.carpoly, P.carpoly + (size_t)env * N * MCR_CARPOLY_FLOATS, sizeof(float) * MCR_CARPOLY_FLOATS * N, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy2D(b + L.bpf, sizeof(float) * 4 * N, P.bpf + (size_t)env * 4 * N, sizeof(float) * 4 * BN, sizeof(float) * 4 * N, BP_COUNT, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy2D(b + L.bpf, sizeof(float4) * MCR_BP_FIX * N, P.bpf + (size_t)env * MCR_BP_FIX * N, sizeof(float4) * MCR_BP_FIX * BN, sizeof(float4) * MCR_BP_FIX * N, BP_COUNT, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(b + L.ccstamp, P.cc_stamp + (size_t)env * mcr_cc_stamp_words(N), sizeof(uint32_t) * mcr_cc_stamp_words(N), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(b + L.stamp, P.bp_stamp + (size_t)env * MCR_TILE_CAP * 4 * N, sizeof(uint32_t) * MCR_TILE_CAP * 4 * N, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(b + L.slot, P.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES, MCR_SLOT_BYTES, hipMemcpyDeviceToHost));
   if (P.particles) HIPCHK(hipMemcpy(b + L.particles, P.particles + (size_t)env * N * MCR_PART_WORDS, sizeof(uint32_t) * MCR_PART_WORDS * N, hipMemcpyDeviceToHost));
@@ -867,7 +870,8 @@ extern "C" int mcr_set_state_blob(mcr_env* h, int env, const void* blob) {
   HIPCHK(hipMemcpy(P.cc_store + (size_t)env * ccw, b + L.cc, sizeof(uint32_t) * ccw, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(P.viewp + (size_t)env * N * MCR_VIEWP_FLOATS, b + L.viewp, sizeof(float) * MCR_VIEWP_FLOATS * N, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(P.carpoly + (size_t)env * N * MCR_CARPOLY_FLOATS, b + L.carpoly, sizeof(float) * MCR_CARPOLY_FLOATS * N, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy2D(P.bpf + (size_t)env * 4 * N, sizeof(float) * 4 * BN, b + L.bpf, sizeof(float) * 4 * N, sizeof(float) * 4 * N, BP_COUNT, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy2D(P.bpf + (size_t)env * MCR_BP_FIX * N, sizeof(float4) * MCR_BP_FIX * BN, b + L.bpf, sizeof(float4) * MCR_BP_FIX * N, sizeof(float4) * MCR_BP_FIX * N, BP_COUNT, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(P.cc_stamp + (size_t)env * mcr_cc_stamp_words(N), b + L.ccstamp, sizeof(uint32_t) * mcr_cc_stamp_words(N), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(P.bp_stamp + (size_t)env * MCR_TILE_CAP * 4 * N, b + L.stamp, sizeof(uint32_t) * MCR_TILE_CAP * 4 * N, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(P.slots + ((size_t)env * 2 + cur.slot) * MCR_SLOT_BYTES, b + L.slot, MCR_SLOT_BYTES, hipMemcpyHostToDevice));
   if (P.particles) HIPCHK(hipMemcpy(P.particles + (size_t)env * N * MCR_PART_WORDS, b + L.particles, sizeof(uint32_t) * MCR_PART_WORDS * N, hipMemcpyHostToDevice));

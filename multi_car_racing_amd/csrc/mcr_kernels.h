@@ -14,7 +14,8 @@ struct McrParams {
   uint32_t* tile_touch;         // [B][TILE_CAP]  bit (car*4+wheel): wheel currently in contact with the tile
   uint16_t* tile_flags;         // [B][TILE_CAP]  bits 0..7 road_visited[car], bit 8 recoloured
   uint32_t* cc_store;           // [B][...] car<->car manifold store (warm starting)
-  float* bpf;                   // [BP_COUNT][4 * BN] broadphase proxies of the wheels (fat AABBs; what the last contact pass saw)
+  float4* bpf;                  // [BP_COUNT][8 * BN] broadphase proxies of the car fixtures (fat AABBs; what the last contact pass saw)
+  uint32_t* cc_stamp;           // [B][mcr_cc_stamp_words(N)] car<->car broadphase contacts: which FindNewContacts batch made the contact of a fixture pair (k_collide.h)
   uint32_t* bp_stamp;           // [B][TILE_CAP][4 * N] batch label of the tile<->wheel contact: the contact pass that first saw the two fat AABBs overlap
   int32_t bp_fresh;             // the car proxies are re-created at the current poses by this step's contact pass (after mcr_set_bodies)
   uint32_t* status;             // [MCR_STATUS_WORDS] mapped host memory: conditions that make results wrong or degraded (mcr_step checks them without synchronising)

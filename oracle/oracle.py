@@ -330,8 +330,9 @@ class OracleEnv:
         self.L.orc_set_world_mode(self.h, int(mode))
 
     def set_island_order(self, mode):
-        """0 (default, what the kernels implement): car<->car contacts in ascending (carA, fixA, carB, fixB), joints 3,2,1,0 per car;
-        1: the order of b2World::Solve's island DFS (mcr_oracle_contacts.inc: island_dfs)."""
+        """1 (default, what the kernels implement): the order of b2World::Solve's island DFS for the car<->car contacts and each car's
+        joints (mcr_oracle_contacts.inc: island_dfs); 0: rounds 1-3's DEFINED order (contacts ascending by (carA, fixA, carB, fixB),
+        joints 3,2,1,0 per car); 2: the DFS order of the contacts, joints 3,2,1,0."""
         self.L.orc_set_island_order(self.h, int(mode))
 
     def island_diff(self):

@@ -489,7 +489,7 @@ def test_car_car_contacts_bit_exact(torch_cuda, oracle, N, streams):
     orcs = _oracles(oracle, B, N, seed, contacts=True)
     _rear_end_setup(env, orcs)
     rng = np.random.RandomState(4)
-    touched = 0
+    touched = wheel_first = 0
     for k in range(160):
         a = random_actions(rng, B, N, 0.0)
         a[:, 0, 1] = 0.0; a[:, 0, 2] = 0.8 if k < 60 else 0.0          # car 0 brakes, then coasts
@@ -499,11 +499,45 @@ def test_car_car_contacts_bit_exact(torch_cuda, oracle, N, streams):
         for e, o in enumerate(orcs):
             _, r, d, _ = o.step(a[e], render=(k == 159 or k % 20 == 19))
             touched += o.num_car_contacts()
+            wheel_first += o.island_diff() & 1 if o.num_car_contacts() else 0
             assert np.array_equal(r, rw[e]), f"step {k} env {e}"
         if k % 20 == 19:
             _assert_state_equal(env, orcs, f"contacts step {k}"); _assert_pixels(obs.cpu().numpy(), orcs, budget=40)
     assert touched > 50, "scenario produced no car<->car contacts"
+    # the island search enters the car in front through the rear wheel that was hit: that car solves that wheel's joint first
+    assert wheel_first > 0, "no car was entered through a wheel (b2World::Solve's island order of the joints)"
     _assert_pixels(obs.cpu().numpy(), orcs, budget=40)
+    env.close()
+
+
+@pytest.mark.parametrize("N", [2, 4])
+def test_contacts_are_solved_in_island_dfs_order(torch_cuda, oracle, N):
+    """b2World::Solve's island search fixes the order the touching car<->car contacts (and a car's joints) are solved in (b2_world.cpp
+    Solve: seeds from m_bodyList, contact edges newest first).  The back rows floor it into the front rows: HIP == the oracle in the
+    kernels' island order bit for bit, on rollouts where that order is NOT the ascending (carA, fixA, carB, fixB) one of rounds 1-3
+    (an oracle kept in that order beside it sees a different contact order and ends up in a different state)."""
+    torch = torch_cuda
+    B, seed, steps = 8, 4000 + N, 140
+    env = _make(B, N, seed, contacts=True, use_random_direction=True); env.reset()
+    orcs = _oracles(oracle, B, N, seed, contacts=True, use_random_direction=True)
+    legacy = _oracles(oracle, B, N, seed, contacts=True, use_random_direction=True)
+    for o in legacy: o.set_island_order(0)
+    order_differs = joints_differ = 0
+    for k in range(steps):
+        rng = [np.random.RandomState(1000 * k + e) for e in range(B)]
+        a = np.stack([np.stack([r.uniform(-0.3, 0.3, N), r.uniform(0.2, 1.0, N), np.zeros(N)], -1) for r in rng]).astype(np.float32)
+        a[:, N // 2:, 1] = 1.0
+        _, rew, _, _ = env.step(torch.from_numpy(a).cuda())
+        rw = rew.cpu().numpy()
+        for e, (o, l) in enumerate(zip(orcs, legacy)):
+            _, r, _, _ = o.step(a[e], render=False); l.step(a[e], render=False)
+            assert np.array_equal(r, rw[e]), f"step {k} env {e}"
+            if o.num_car_contacts() > 0: order_differs += (o.island_diff() >> 1) & 1; joints_differ += o.island_diff() & 1
+        if k % 20 == 19: _assert_state_equal(env, orcs, f"island order step {k}")
+    _assert_state_equal(env, orcs, "island order, end")
+    assert order_differs > 10, "the scenario never left the ascending contact order"
+    assert joints_differ > 10, "no car was entered through a wheel other than 3 (joint order 3,2,1,0 throughout)"
+    assert any(not np.array_equal(o.state()["bodies"], l.state()["bodies"]) for o, l in zip(orcs, legacy)), "the order made no difference"
     env.close()
 
 

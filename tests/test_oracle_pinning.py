@@ -323,7 +323,7 @@ def test_island_dfs_order_in_the_oracle(oracle):
     N = 2
     ep = oracle_episode(oracle, N, 4002, 3, use_random_direction=True)
     a, b = oracle.OracleEnv(N, car_contacts=False), oracle.OracleEnv(N, car_contacts=False)
-    b.set_island_order(1)
+    a.set_island_order(0); b.set_island_order(1)
     a.reset(ep, render=False); b.reset(ep, render=False)
     rng = np.random.RandomState(0)
     for k in range(80):
@@ -337,7 +337,7 @@ def test_island_dfs_order_in_the_oracle(oracle):
     for e in range(12):
         ep = oracle_episode(oracle, N, 4002, e, use_random_direction=True)
         a, b = oracle.OracleEnv(N), oracle.OracleEnv(N)
-        b.set_island_order(1)
+        a.set_island_order(0); b.set_island_order(1)
         a.reset(ep, render=False); b.reset(ep, render=False)
         rng = np.random.RandomState(e)
         for k in range(160):

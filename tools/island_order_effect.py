@@ -16,7 +16,7 @@ for N in (2, 4, 8):
     first_div = []
     for e in range(episodes):
         ep = oracle_episode(O, N, 4000 + N, e, use_random_direction=True)
-        a, b = O.OracleEnv(N), O.OracleEnv(N); b.set_island_order(1)
+        a, b = O.OracleEnv(N), O.OracleEnv(N); a.set_island_order(0); b.set_island_order(1)
         a.reset(ep, render=False); b.reset(ep, render=False)
         rng = np.random.RandomState(e)
         div = None
