@@ -566,6 +566,10 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
           }
         }
       }
+      if (p.debug & 16384) {                                              // debug bit 14 (timing experiments): rounds 1-3's order — contacts ascending, joints 3,2,1,0
+        for (int i = 0; i < nn; ++i) dord[i] = (uint8_t)i;
+        jo = 0x1b1b1b1b1b1b1b1bull;
+      }
       store[2] = (uint32_t)jo; store[3] = (uint32_t)(jo >> 32);
     }
     __syncthreads();

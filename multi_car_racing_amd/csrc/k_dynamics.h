@@ -226,6 +226,11 @@ __device__ __forceinline__ void slot_sort(Joint* J, Body* b, int* key, int* tag)
 __device__ __forceinline__ float pick4(int i, float a0, float a1, float a2, float a3) { return i == 0 ? a0 : i == 1 ? a1 : i == 2 ? a2 : a3; }
 // row of body `body` (0 hull, 1 + wheel) of the car in lane L of the exchange arrays: xmap[L] = slot of wheel w at bits 2w
 __device__ __forceinline__ int cc_row(const int* xmap, int L, int body) { return body == 0 ? 0 : 1 + ((xmap[L] >> (2 * (body - 1))) & 3); }
+// exchange rows of a contact's two bodies, for bits 16.. / 20.. of the key of its LDS copy
+__device__ __forceinline__ uint32_t cc_rows_of(uint32_t key, int leader_lane, const int* xmap) {
+  const int LA = leader_lane + (int)(key & 15u), LB = leader_lane + (int)((key >> 8) & 15u);
+  return ((uint32_t)cc_row(xmap, LA, cc::fixture_body((int)((key >> 4) & 15u))) << 16) | ((uint32_t)cc_row(xmap, LB, cc::fixture_body((int)((key >> 12) & 15u))) << 20);
+}
 // b2ContactSolver ctor + InitializeVelocityConstraints + WarmStart for one stored manifold
 __device__ inline void cc_init(const CcMass& S, const uint32_t* rec, int rec_index, int leader_lane, float (*xp)[64], float (*xv)[64], const int* xmap, float* vc) {
   const uint32_t key = rec[0];
@@ -395,11 +400,12 @@ __device__ inline void cc_velocity(const CcMass& S, float* __restrict__ vcf, flo
 }
 
 // b2ContactSolver::SolvePositionConstraints for one contact; returns its min separation
-__device__ inline float cc_position(const CcMass& S, const uint32_t* rec, int leader_lane, float (*xp)[64], const int* xmap) {
+// (rec: the step's LDS copy of the record — its key carries the two bodies' exchange rows at bits 16 and 20, see cc_rows_of)
+__device__ inline float cc_position(const CcMass& S, const uint32_t* rec, int leader_lane, float (*xp)[64]) {
   const uint32_t key = rec[0];
-  const int carA = key & 15, fixA = (key >> 4) & 15, carB = (key >> 8) & 15, fixB = (key >> 12) & 15;
+  const int carA = key & 15, carB = (key >> 8) & 15;
   const int LA = leader_lane + carA, LB = leader_lane + carB;
-  const int bA = cc_row(xmap, LA, cc::fixture_body(fixA)), bB = cc_row(xmap, LB, cc::fixture_body(fixB));
+  const int bA = (key >> 16) & 7, bB = (key >> 20) & 7;
   const int type = rec[1] & 255; const int n = (int)(rec[1] >> 8);
   float mA, iA, mB, iB; V2 lcA, lcB; cc_masses(S, bA, mA, iA, lcA); cc_masses(S, bB, mB, iB, lcB);
   V2 cA = v2(xp[0 * 5 + bA][LA], xp[1 * 5 + bA][LA]); float aA = xp[2 * 5 + bA][LA];
@@ -447,6 +453,9 @@ __device__ inline float cc_position(const CcMass& S, const uint32_t* rec, int le
 // debug bit 8 (256): lane 0 of every wavefront stamps the clock per phase (0 start, 1 state loaded + Car.step +
 // velocity integration, 2 velocity sweeps done, 3 position loop done, 4 end) into p.dbg_stamps[block][8] (main launch, then the launches of roles 2, 3, 4)
 #define DYN_STAMP(i) do { if ((p.debug & 256) && mode == 0 && threadIdx.x == 0) p.dbg_stamps[((p.role >= 2 ? (p.B * p.G + 63) / 64 + (p.role - 2) * ((p.B + 1) / 2) : 0) + blk) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+// CC = false: a launch that cannot hold an env with touching car<->car contacts (the main launch of the three-chain step; contacts off;
+// N = 1) — none of the contact code is compiled in, and the contact-free loops keep the registers and the schedule they get alone
+template <bool CC>
 __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mode, const int blk) {
   using namespace dyn;
   DYN_STAMP(0);
@@ -601,10 +610,8 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
   // (cc_mode: the main launch's envs are those whose verdict — mcr_touch_verdict, evaluated by last step's bookkeeping on the
   // same poses with the same arithmetic — says that no car<->car fixture pair touches: k_collide, running beside this
   // launch, finds none either; its store[0] is not read)
-  if (run && p.car_contacts && p.N > 1 && !(p.cc_mode && mode == 0 && p.role == 1)) ccn = (int)store[0];
-  const bool wave_cc = __any(ccn > 0) != 0;
-  int jord8 = 0x1b, wq[4] = {0, 1, 2, 3};      // island order of this car's joints (3,2,1,0 unless a contact says otherwise); wheel held by slot t
-  bool wave_perm = false;
+  if (CC && run && p.car_contacts && p.N > 1 && !(p.cc_mode && mode == 0 && p.role == 1)) ccn = (int)store[0];
+  const bool wave_cc = CC && __any(ccn > 0) != 0;
   DYN_STAMP(1);
   int pool_base = 0;
   int isl = agent;                        // island id of this car = lowest car id linked to it by touching contacts
@@ -616,8 +623,11 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
     pool_base = incl - need;
     if (agent == 0 && pool_base + ccn > DYN_VC_POOL) { ccn = DYN_VC_POOL - pool_base; if (ccn < 0) ccn = 0; store[1] = 2u; mcr_raise(p, ST_CC_OVERFLOW); }
     ccn = __shfl(ccn, leader_lane); pool_base = __shfl(pool_base, leader_lane);
+    // island order of this car's joints (3,2,1,0 unless a contact says otherwise); wq[t] = the wheel slot t holds.  (Everything that
+    // knows about the permutation lives in the contact branches: the contact-free loops keep their registers.)
+    int jord8 = 0x1b, wq[4] = {0, 1, 2, 3};
     if (ccn > 0) jord8 = (int)((store[2 + (agent >> 2)] >> ((agent & 3) * 8)) & 255u);
-    wave_perm = __any(jord8 != 0x1b) != 0;
+    const bool wave_perm = __any(jord8 != 0x1b) != 0;
     if (wave_perm) {
       int key[4];                                       // joint q goes to slot 3 - (its position in the island order)
 #pragma unroll
@@ -652,6 +662,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
         cc_init(CM, rec, i, leader_lane, xp, xv, xmap, vcpool[pool_base + i]);
 #pragma unroll
         for (int w = 0; w < 16; ++w) pcrec[pool_base + i][w] = rec[w];      // once per step instead of one HBM round trip per sweep
+        pcrec[pool_base + i][0] |= cc_rows_of(rec[0], leader_lane, xmap);   // (looked up once, not in every position sweep)
         // union-find over cars (b2World::Solve island DFS through touching contacts)
         const int ca = rec[0] & 15, cb = (rec[0] >> 8) & 15;
         int ra = ca, rb = cb;
@@ -685,17 +696,22 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
 #pragma unroll
       for (int k = 0; k < 5; ++k) { b[k].vx = xv[0 * 5 + k][lane]; b[k].vy = xv[1 * 5 + k][lane]; b[k].w = xv[2 * 5 + k][lane]; }
     }
+    if (run && !resume) {
+      // joints, slot order 3,2,1,0 = the car's island order
+#pragma unroll
+      for (int q = 3; q >= 0; --q) {
+        float ax = S.anchor_x[q], ay = S.anchor_y[q];
+        if (wave_perm) { ax = pick4(wq[q], S.anchor_x[0], S.anchor_x[1], S.anchor_x[2], S.anchor_x[3]); ay = pick4(wq[q], S.anchor_y[0], S.anchor_y[1], S.anchor_y[2], S.anchor_y[3]); }
+        joint_init(J[q], b[0], b[q + 1], ax, ay, lcx, lcy, mH, iH, mW, iW);
+      }
+    }
   }
 
   bool positionSolved = false;
-  if (run && !resume) {
+  if (run && !resume && !wave_cc) {
     // joints, island order 3,2,1,0
 #pragma unroll
-    for (int q = 3; q >= 0; --q) {
-      float ax = S.anchor_x[q], ay = S.anchor_y[q];
-      if (wave_perm) { ax = pick4(wq[q], S.anchor_x[0], S.anchor_x[1], S.anchor_x[2], S.anchor_x[3]); ay = pick4(wq[q], S.anchor_y[0], S.anchor_y[1], S.anchor_y[2], S.anchor_y[3]); }
-      joint_init(J[q], b[0], b[q + 1], ax, ay, lcx, lcy, mH, iH, mW, iW);
-    }
+    for (int q = 3; q >= 0; --q) joint_init(J[q], b[0], b[q + 1], S.anchor_x[q], S.anchor_y[q], lcx, lcy, mH, iH, mW, iW);
   }
   if (resume && run && agent == 0) atomicAdd(&p.counters[1], 1ull);
   if (resume) {   // the position solver needs nothing from InitVelocityConstraints but the motor mass (limit state is stored)
@@ -815,6 +831,15 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
     }
   } else {
     bool active = run;
+    int wq[4];                                           // the wheel each slot holds (see the permutation above)
+    {
+      const int m = xmap[lane];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { wq[t] = 0;
+#pragma unroll
+        for (int w = 1; w < 4; ++w) if (((m >> (2 * w)) & 3) == t) wq[t] = w; }
+    }
+    const bool wave_perm = __any(xmap[lane] != 0xe4) != 0;
     const int pos_iters_cc = (p.debug & 64) ? 2 : 60;
     for (int it = 0; it < pos_iters_cc; ++it) {
       if (!__any(active)) break;
@@ -838,7 +863,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
           const int ca = rec[0] & 15;
           const int r = xisl[leader_lane + ca];
           if (!xact[leader_lane + r]) continue;
-          const float ms = cc_position(CM, rec, leader_lane, xp, xmap);
+          const float ms = cc_position(CM, rec, leader_lane, xp);
 #pragma unroll
           for (int c = 0; c < MCR_MAX_AGENTS; ++c) if (c == r) minSep[c] = mcr_min(minSep[c], ms);
         }
@@ -1247,13 +1272,17 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
 }
 
 // main launches (roles 0 / 1): 64 / G envs per wavefront (the list launches of roles >= 2 call dynamics_block from k_list_chain.h)
+template <bool CC>
 __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
+  // one wavefront per SIMD whose serial chain IS the step's critical path: it goes before the wavefronts of the kernels that run beside it
+  // on the same SIMDs (k_collide's 4096, the raster's tail) whenever both can issue
+  __builtin_amdgcn_s_setprio(3);
   if (mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) {         // the next step's lists: every reader of these buffers finished last step
     if (p.soft_sync && p.role == 1) mcr_post(p, W_BEGIN);         // the caller's stream is here: the side stream may start this step
     if (p.role == 1) p.clist_next[0] = 0;
     for (int i = 0; i < 4; ++i) if (p.next_counts[i]) *p.next_counts[i] = 0;
   }
-  dynamics_block(p, mode, (int)blockIdx.x);
+  dynamics_block<CC>(p, mode, (int)blockIdx.x);
 }
 
 __global__ void k_mark_staged(McrParams p, const int32_t* __restrict__ ids, int n) {

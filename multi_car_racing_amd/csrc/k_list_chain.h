@@ -17,7 +17,7 @@ __device__ __forceinline__ void list_reset_pass(const McrParams& p, const int bl
   for (int k = 0; k < p.list_envs_per_block; ++k) { collide_block(p, 1, blk * p.list_envs_per_block + k); __syncthreads(); }
   __threadfence();                                             // the dynamics lanes read what the collide lanes stored
   __syncthreads();
-  dynamics_block(p, 1, blk);
+  dynamics_block<true>(p, 1, blk);
   __syncthreads();
 }
 
@@ -25,6 +25,8 @@ __device__ __forceinline__ void list_reset_pass(const McrParams& p, const int bl
 // The launch can carry a SECOND list with its own parameter block: workgroups [ga, gridDim) run the reset pass of the envs the
 // main dynamics re-spawned (role 4, what k_reset_list does) beside the chain of the first list — one launch, so that neither
 // waits for the other in a stream (the re-spawned envs used to queue behind the contact chain, which is long in 1 step of 6).
+// CC = false: the first list holds no env with touching car<->car contacts (role 3: the deferred envs) — its dynamics are the contact-free build
+template <bool CC>
 __global__ __launch_bounds__(64) void k_list_chain(McrParams pa, McrParams pb, const int with_flags, const int ga) {
   __builtin_amdgcn_s_setprio(3);
   // soft_sync (mcr_kernels.h): the contact chain follows the contact pass in its stream — its start IS the contact pass's completion
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(64) void k_list_chain(McrParams pa, McrParams pb, c
     const McrParams& p = pa;
     const int nb = mcr_virtual_blocks(p, p.list_envs_per_block);
     for (int blk = blockIdx.x; blk < nb; blk += ga) {
-      dynamics_block(p, 0, blk);
+      dynamics_block<CC>(p, 0, blk);
       __syncthreads();
       if (p.auto_reset) list_reset_pass(p, blk);
       if (with_flags) {

@@ -315,6 +315,9 @@ static hipEvent_t get_event(mcr_env* h) {
     if (tm_) { (void)hipEventRecord(tl_.b, st); h->pending.push_back(tl_); }                   \
   } while (0)
 
+// a launch of the dynamics over all envs: with or without the contact code (k_dynamics.h)
+#define LAUNCH_DYN(kid_, cc_, grid, st, ...) do { if (cc_) LAUNCH(kid_, k_dynamics<true>, grid, 64, st, __VA_ARGS__); else LAUNCH(kid_, k_dynamics<false>, grid, 64, st, __VA_ARGS__); } while (0)
+
 void mcr_view_launch(int variant, int grid, hipStream_t st, const McrParams& P, unsigned long long* stamps, int only_just_reset, hipEvent_t stop);   // mcr_view.hip
 // raster launch (k_view.h).  Main launches: one workgroup per work slot.  List launches (role >= 2): MCR_LIST_GRID
 // persistent workgroups that walk the list (lane k of a wavefront holds a workgroup's k-th env, so never fewer than
@@ -337,7 +340,7 @@ static void launch_reset(mcr_env* h, McrParams P, hipStream_t st) {
   P.split = 0; P.role = 0; P.use_vorder = 0;
   hipLaunchKernelGGL(k_install, dim3(dyn_blocks), dim3(64), 0, st, P);
   LAUNCH_LDS(3, k_collide, B, 64, col::lds_bytes(N), st, P, 1);
-  LAUNCH(4, k_dynamics, dyn_blocks, 64, st, P, 1);
+  LAUNCH_DYN(4, P.car_contacts && N > 1, dyn_blocks, st, P, 1);
   if (P.obs) launch_view(h, 2, B, st, P, 1);
 }
 
@@ -376,10 +379,10 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   if (!h->split) {
     // single stream: collide -> dynamics -> reset pass of the re-spawned envs (:408) -> raster -> bookkeeping, all envs
     LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), st, P, 0);
-    LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 0);
+    LAUNCH_DYN(1, P.car_contacts && N > 1, dyn_blocks, st, P, 0);
     if (P.auto_reset) {
       LAUNCH_LDS(3, k_collide, B, 64, col::lds_bytes(N), st, P, 1);
-      LAUNCH(4, k_dynamics, dyn_blocks, 64, st, P, 1);
+      LAUNCH_DYN(4, P.car_contacts && N > 1, dyn_blocks, st, P, 1);
     }
     P.use_vorder = 1;
     if (draw) launch_view(h, 2, B, st, P, 0);
@@ -428,7 +431,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     if (cc) LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), h->s_side, P, 0);     // (W_COL: posted by the chain that follows)
     P.split = 0;
     P.role = 2;
-    LAUNCH_LDS(5, k_list_chain, lg_dyn, 64, col::lds_bytes(N), h->s_side, P, P, 0, lg_dyn);
+    LAUNCH_LDS(5, k_list_chain<true>, lg_dyn, 64, col::lds_bytes(N), h->s_side, P, P, 0, lg_dyn);
     // (the chains' bookkeeping: workgroups of its own inside the chain's raster launch when there is one, a list launch otherwise)
     // (beyond four cars per env the lists hold thousands of cars — ~315 contact envs x 8 at N = 8 — and a few 256-thread workgroups
     // would take them in many rounds at the end of the contact chain, the critical path there; measured N = 2 15.37 -> 15.65 M
@@ -440,12 +443,12 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     P.role = 1;
     P.viewprep_in_flags = (view_flags && draw && h->viewprep_in_flags) ? 1 : 0;
     const bool flags_on_caller = view_flags && draw && !P.viewprep_in_flags && N <= 7;   // (N = 8: the contact chain is the critical one; no gain, and the raster would share the machine with the bookkeeping)
-    LAUNCH(1, k_dynamics, dyn_blocks, 64, st, P, 0);
+    LAUNCH(1, k_dynamics<false>, dyn_blocks, 64, st, P, 0);          // (the main envs: no touching car<->car pair)
     P.role = 3;
     {
       const int ga = std::min(lg_dyn, MCR_LIST_GRID / 2), gb = P.auto_reset ? lg_col : 0;
       McrParams Pr = P; Pr.role = 4; Pr.list_envs_per_block = 1;
-      LAUNCH_LDS(7, k_list_chain, ga + gb, 64, col::lds_bytes(N), st, P, Pr, 0, ga);
+      LAUNCH_LDS(7, k_list_chain<false>, ga + gb, 64, col::lds_bytes(N), st, P, Pr, 0, ga);
       if (view_flags && !fiv) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, st, P);
       // Beyond three cars per env the third stream's chain (bookkeeping of B*N cars, then B*N views) is the longer one and the caller's
       // has slack: the main envs' bookkeeping — which the raster does not depend on — moves here, between the resume chain and its raster
@@ -483,14 +486,14 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   const bool flags_list = view_flags && !fuse_flags;
   P.role = 2;
   // (the side stream's last kernel completes ev_join; which one that is depends on the step's shape)
-  LAUNCH_LDS_STOP(5, k_list_chain, lg_dyn, 64, col::lds_bytes(N), h->s_side, STOP((!draw && !flags_list) ? h->ev_join : nullptr), P, P, fuse_flags, lg_dyn);
+  LAUNCH_LDS_STOP(5, k_list_chain<true>, lg_dyn, 64, col::lds_bytes(N), h->s_side, STOP((!draw && !flags_list) ? h->ev_join : nullptr), P, P, fuse_flags, lg_dyn);
   if (flags_list) hipExtLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, h->s_side, nullptr, STOP(!draw ? h->ev_join : nullptr), 0, P);
   if (draw) launch_view(h, 6, B, h->s_side, P, 0, STOP(h->ev_join));
   P.role = 1;
   // the main envs' view records and car polygons: by k_viewprep on the side stream, beside the bookkeeping kernel, in a drawn step
   // with actions; otherwise by the dynamics' own epilogue
   P.viewprep_in_flags = (view_flags && draw && h->viewprep_in_flags) ? 1 : 0;
-  LAUNCH_LDS_STOP(1, k_dynamics, dyn_blocks, 64, 0, st, STOP(h->ev_fork2), P, 0);
+  LAUNCH_LDS_STOP(1, k_dynamics<false>, dyn_blocks, 64, 0, st, STOP(h->ev_fork2), P, 0);
   RECORD_UNLESS_STOP(h->ev_fork2, st);
   // The chain that follows the dynamics IN-STREAM starts ~2 us after it, one that has to hop to another stream ~8 us (kernel trace,
   // round 3).  The longer chain is the resume chain (85-150 us beside the raster + its own raster, 25-70 us) — not bookkeeping + main
@@ -507,7 +510,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     // envs the main dynamics re-spawned; then, in one list launch, the deferred envs' frames and the re-spawned envs' first observations
     const int ga = std::min(lg_dyn, MCR_LIST_GRID / 2), gb = P.auto_reset ? lg_col : 0;
     McrParams Pr = P; Pr.role = 4; Pr.list_envs_per_block = 1;     // one re-spawned env per workgroup: they run side by side
-    LAUNCH_LDS_STOP(7, k_list_chain, ga + gb, 64, col::lds_bytes(N), s_resume, STOP((!draw && !flags_list) ? resume_done : nullptr), P, Pr, fuse_flags, ga);
+    LAUNCH_LDS_STOP(7, k_list_chain<false>, ga + gb, 64, col::lds_bytes(N), s_resume, STOP((!draw && !flags_list) ? resume_done : nullptr), P, Pr, fuse_flags, ga);
     if (flags_list) hipExtLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, s_resume, nullptr, STOP(!draw ? resume_done : nullptr), 0, P);
     if (draw) { McrParams Pv = P; Pv.role = P.auto_reset ? 5 : 3; launch_view(h, 7, B, s_resume, Pv, 0, STOP(resume_done)); }
   }
