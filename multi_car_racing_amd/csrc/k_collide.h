@@ -67,13 +67,46 @@ __device__ __forceinline__ bool overlap(const float* avx, const float* avy, cons
   return gjk::touching(va, vb, T.n, PB, xfB);
 }
 
+// cross-lane reductions by DPP (one VALU operation per level, no LDS round trip).  Groups of 8 lanes: lane ^ 1, lane ^ 2 inside the quad,
+// then the mirror image inside the 8 (the quads are uniform by then).
+#define GRP8_REDUCE(op, x) do { x = op(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xb1, 0xf, 0xf, true))); \
+                                x = op(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4e, 0xf, 0xf, true))); \
+                                x = op(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xf, 0xf, true))); } while (0)
+// OR over the wavefront, uniform result: rows of 16 by DPP (quad, half-row mirror, row mirror), then the four rows' lane 0
+__device__ __forceinline__ uint32_t wave_or(uint32_t x) {
+  x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xb1, 0xf, 0xf, true);
+  x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4e, 0xf, 0xf, true);
+  x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, true);
+  x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xf, true);
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, 0) | (uint32_t)__builtin_amdgcn_readlane((int)x, 16) | (uint32_t)__builtin_amdgcn_readlane((int)x, 32) | (uint32_t)__builtin_amdgcn_readlane((int)x, 48);
+}
+
 }  // namespace col
 
 // pass 0: every active env.  pass 1: only envs with `resetting` set (their per-tile state is cleared first).
+// debug bit 15: clock of lane 0 at the phase boundaries of the step's contact pass (tools/collide_phases.py)
+#define COL_STAMP(i) do { if ((p.debug & 32768) && pass == 0 && threadIdx.x == 0) p.dbg_stamps[(size_t)env * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 __device__ __forceinline__ void collide_block(const McrParams& p, const int pass, const int blk) {
   using namespace col;
   const int env = mcr_env_of_slot(p, blk), lane = threadIdx.x;
   if (env >= p.env0 + p.nenv) return;
+  COL_STAMP(0);
+  // Everything the pass reads that does not depend on the env's state word is asked for HERE, together with it: the wavefront is a
+  // chain of dependent memory round trips (env state -> slot -> tiles), and loads issued one after the other cost one trip, not one each.
+  const int pre_c = lane >> 3, pre_fi = lane & 7, pre_body = pre_fi < 4 ? 0 : pre_fi - 3;
+  const bool pre_on = pre_c < p.N;
+  float pre_cx = 0.0f, pre_cy = 0.0f, pre_a = 0.0f;
+  float4 pre_fat = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pre_prev = pre_fat, pre_prevp = pre_fat;
+  float pvx[8], pvy[8], pnx[8], pny[8]; int pre_pn = 0;
+  if (pre_on) {
+    const int ci = env * p.N + pre_c, wi = ci * MCR_BP_FIX + pre_fi, WS = MCR_BP_FIX * p.BN;
+    pre_cx = p.carf[(CF_CX + pre_body) * p.BN + ci]; pre_cy = p.carf[(CF_CY + pre_body) * p.BN + ci]; pre_a = p.carf[(CF_A + pre_body) * p.BN + ci];
+    pre_fat = p.bpf[BP_FAT * WS + wi]; pre_prev = p.bpf[BP_PREV * WS + wi]; pre_prevp = p.bpf[BP_PREVP * WS + wi];
+    const McrPoly& P = pre_fi < 4 ? p.shapes->hull[pre_fi] : p.shapes->wheel;
+    pre_pn = P.n;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { pvx[i] = P.vx[i]; pvy[i] = P.vy[i]; pnx[i] = P.nx[i]; pny[i] = P.ny[i]; }      // (all eight: no load waits for the count)
+  }
   const McrEnvState es = p.env[env];
   if (!es.active) {
     // contact pass in front (single stream, N > 4, serialised kernels): this pass owns the contact chain's marks — an env
@@ -85,6 +118,11 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   const int N = p.N, BN = p.BN;
   const uint8_t* slot = p.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES;
   const int T = ((const McrSlotHeader*)slot)->T;
+  // (asked for now, used after the fixtures are built: the boxes of the track's tile blocks; the cars' reward / visit-count accumulators)
+  float4 kb_pre = make_float4(1.0f, 1.0f, -1.0f, -1.0f);
+  if (lane < MCR_TILE_CAP / MCR_TBLK) kb_pre = ((const float4*)(slot + MCR_OFF_TBLK))[lane];
+  double reward_pre = 0.0; uint32_t tvc_pre = 0u;
+  if (lane < N) { reward_pre = p.card[CD_REWARD * BN + env * N + lane]; tvc_pre = p.caru[CU_TVC * BN + env * N + lane]; }
   uint32_t* touch = p.tile_touch + (size_t)env * MCR_TILE_CAP;
   uint16_t* tflags = p.tile_flags + (size_t)env * MCR_TILE_CAP;
   if (pass == 1) for (int t = lane; t < MCR_TILE_CAP; t += 64) { touch[t] = 0; tflags[t] = 0; }
@@ -131,21 +169,22 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
     const int c = lane >> 3, fi = lane & 7;
     float lox = MCR_MAXFLT, loy = MCR_MAXFLT, hix = -MCR_MAXFLT, hiy = -MCR_MAXFLT;
     if (c < N) {
-      const int ci = env * N + c;
-      const int body = fi < 4 ? 0 : fi - 3;
+      const int body = pre_body;
       const McrShapes& S = *p.shapes;
-      const McrPoly& P = fi < 4 ? S.hull[fi] : S.wheel;
-      V2 cc = v2(p.carf[(CF_CX + body) * BN + ci], p.carf[(CF_CY + body) * BN + ci]);
-      float a = p.carf[(CF_A + body) * BN + ci];
+      V2 cc = v2(pre_cx, pre_cy);
+      float a = pre_a;
       V2 lc = body == 0 ? v2(S.hull_lcx, S.hull_lcy) : v2(0.0f, 0.0f);
       Xf xf = xf_of(cc, a, lc);
-      fcnt[lane] = P.n;
+      fcnt[lane] = pre_pn;
       fxf[lane] = make_float4(xf.p.x, xf.p.y, xf.q.s, xf.q.c);
-      for (int i = 0; i < P.n; ++i) {
-        V2 w = xmul(xf, v2(P.vx[i], P.vy[i]));
-        V2 n = rmul(xf.q, v2(P.nx[i], P.ny[i]));
-        fvx[lane][i] = w.x; fvy[lane][i] = w.y; fnx[lane][i] = n.x; fny[lane][i] = n.y;
-        lox = mcr_min(lox, w.x); loy = mcr_min(loy, w.y); hix = mcr_max(hix, w.x); hiy = mcr_max(hiy, w.y);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (i < pre_pn) {
+          V2 w = xmul(xf, v2(pvx[i], pvy[i]));
+          V2 n = rmul(xf.q, v2(pnx[i], pny[i]));
+          fvx[lane][i] = w.x; fvy[lane][i] = w.y; fnx[lane][i] = n.x; fny[lane][i] = n.y;
+          lox = mcr_min(lox, w.x); loy = mcr_min(loy, w.y); hix = mcr_max(hix, w.x); hiy = mcr_max(hiy, w.y);
+        }
       }
       fbox[lane] = make_float4(lox - 0.05f, loy - 0.05f, hix + 0.05f, hiy + 0.05f);
     }
@@ -159,9 +198,9 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
       float4 of = make_float4(MCR_MAXFLT, MCR_MAXFLT, -MCR_MAXFLT, -MCR_MAXFLT);           // "no old proxy": overlaps nothing
       float ux0 = ax0, uy0 = ay0, ux1 = ax1, uy1 = ay1, dx = 0.0f, dy = 0.0f;
       if (!fresh) {
-        of = p.bpf[BP_FAT * WS + wi];
+        of = pre_fat;
         // b2Fixture::Synchronize: union of the AABBs at the transforms the last step was entered and left with
-        const float4 pv = p.bpf[BP_PREV * WS + wi], pp = p.bpf[BP_PREVP * WS + wi];
+        const float4 pv = pre_prev, pp = pre_prevp;
         ux0 = mcr_min(pv.x, ax0); uy0 = mcr_min(pv.y, ay0); ux1 = mcr_max(pv.z, ax1); uy1 = mcr_max(pv.w, ay1);
         dx = 2.0f * (xfq.x - pp.x); dy = 2.0f * (xfq.y - pp.y);                              // b2_aabbMultiplier * displacement
       }
@@ -190,24 +229,16 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
       for (int cc_ = 0; cc_ < N; ++cc_) packed |= ((mm >> (cc_ * 8 + 4)) & 0xfull) << (cc_ * 4);
       moved_mask = packed;
     }
-    for (int o = 1; o < 8; o <<= 1) {
-      flx = mcr_min(flx, __shfl_xor(flx, o)); fly = mcr_min(fly, __shfl_xor(fly, o));
-      fhx = mcr_max(fhx, __shfl_xor(fhx, o)); fhy = mcr_max(fhy, __shfl_xor(fhy, o));
-    }
+    GRP8_REDUCE(mcr_min, flx); GRP8_REDUCE(mcr_min, fly); GRP8_REDUCE(mcr_max, fhx); GRP8_REDUCE(mcr_max, fhy);
     if (fi == 0 && c < MCR_MAX_AGENTS) { cfat[c][0] = flx; cfat[c][1] = fly; cfat[c][2] = fhx; cfat[c][3] = fhy; }
-    for (int o = 1; o < 8; o <<= 1) {
-      glx = mcr_min(glx, __shfl_xor(glx, o)); gly = mcr_min(gly, __shfl_xor(gly, o));
-      ghx = mcr_max(ghx, __shfl_xor(ghx, o)); ghy = mcr_max(ghy, __shfl_xor(ghy, o));
-    }
+    GRP8_REDUCE(mcr_min, glx); GRP8_REDUCE(mcr_min, gly); GRP8_REDUCE(mcr_max, ghx); GRP8_REDUCE(mcr_max, ghy);
     if (fi == 0 && c < MCR_MAX_AGENTS) { cfat8[c][0] = glx; cfat8[c][1] = gly; cfat8[c][2] = ghx; cfat8[c][3] = ghy; }
     if (lane == 0) evn = 0;
-    for (int o = 1; o < 8; o <<= 1) {
-      lox = mcr_min(lox, __shfl_xor(lox, o)); loy = mcr_min(loy, __shfl_xor(loy, o));
-      hix = mcr_max(hix, __shfl_xor(hix, o)); hiy = mcr_max(hiy, __shfl_xor(hiy, o));
-    }
+    GRP8_REDUCE(mcr_min, lox); GRP8_REDUCE(mcr_min, loy); GRP8_REDUCE(mcr_max, hix); GRP8_REDUCE(mcr_max, hiy);
     if (fi == 0 && c < MCR_MAX_AGENTS) { cbox[c][0] = lox - 0.05f; cbox[c][1] = loy - 0.05f; cbox[c][2] = hix + 0.05f; cbox[c][3] = hiy + 0.05f; }
   }
   __syncthreads();
+  COL_STAMP(1);
 
   // ---- car<->car broadphase contacts (b2ContactManager: AddPair / Destroy for the dynamic fixture pairs).  A contact of fixtures
   // (pa, pb) of two different cars (not wheel vs wheel: the fixtures' filters) exists exactly while their fat AABBs overlap: made by
@@ -244,13 +275,14 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
     if (lane == 0 && (fresh || live_new != live_old)) { ccs[0] = (uint32_t)live_new; ccs[1] = (uint32_t)(live_new >> 32); }
   }
   __syncthreads();                                                 // ffat_new (= evq) is free from here on
+  COL_STAMP(2);
 
   // uniform per-car accumulators (every lane keeps the same values)
   double reward[MCR_MAX_AGENTS]; int tvc[MCR_MAX_AGENTS];
 #pragma unroll
   for (int c = 0; c < MCR_MAX_AGENTS; ++c) { reward[c] = 0.0; tvc[c] = 0; }
 #pragma unroll
-  for (int c = 0; c < MCR_MAX_AGENTS; ++c) if (c < N) { reward[c] = p.card[CD_REWARD * BN + env * N + c]; tvc[c] = (int)p.caru[CU_TVC * BN + env * N + c]; }
+  for (int c = 0; c < MCR_MAX_AGENTS; ++c) if (c < N) { reward[c] = __shfl(reward_pre, c); tvc[c] = (int)__shfl(tvc_pre, c); }      // (lane c loaded car c's)
 
   const float4* TAABB = (const float4*)(slot + MCR_OFF_TAABB);
   const float4* TVA = (const float4*)(slot + MCR_OFF_TVA); const float4* TVB = (const float4*)(slot + MCR_OFF_TVB);
@@ -292,8 +324,7 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   // (typically 1-3 of ~18 blocks) instead of every tile of the track.
   uint32_t visit;
   {
-    float4 kb = make_float4(1.0f, 1.0f, -1.0f, -1.0f);
-    if (lane < MCR_TILE_CAP / MCR_TBLK) kb = ((const float4*)(slot + MCR_OFF_TBLK))[lane];
+    const float4 kb = kb_pre;
     bool near = false;
     for (int c = 0; c < N; ++c) near = near || !(kb.x > cbox[c][2] || kb.z < cbox[c][0] || kb.y > cbox[c][3] || kb.w < cbox[c][1]);
     // ... and, where a wheel's proxy moved, the blocks whose tiles' fat AABBs (tight -+ 0.11) can meet the car's fat AABBs:
@@ -339,6 +370,7 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
     }
   }
   flush();
+  COL_STAMP(3);
 
   // ---- phase C: per-tile contact state (lane = tile); the begin events go to a queue ...
   uint32_t or_bits = 0, new_blocks = 0;
@@ -399,9 +431,10 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
     if (m0) { const int t = (int)((m0 >> 5) & 511ull); tflags[t] = tfl16[t]; }          // (lanes sharing a tile store the same word)
     if (m1) { const int t = (int)((m1 >> 5) & 511ull); tflags[t] = tfl16[t]; }
   }
-  for (int o = 1; o < 64; o <<= 1) new_blocks |= (uint32_t)__shfl_xor((int)new_blocks, o);
+  COL_STAMP(4);
+  new_blocks = wave_or(new_blocks);
   if (lane == 0) { p.env[env].touch_blocks = new_blocks; p.env[env].bp_step = label + 1u; }
-  for (int o = 1; o < 64; o <<= 1) or_bits |= (uint32_t)__shfl_xor((int)or_bits, o);
+  or_bits = wave_or(or_bits);
   if (lane < N) {
     const int ci = env * N + lane;
     const uint32_t onr = (or_bits >> (4 * lane)) & 0xFu;
@@ -422,6 +455,7 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
     }
   }
 
+  COL_STAMP(5);
   // ---- car<->car manifolds (b2Contact::Update for the dynamic pairs) at the same entry poses.
   // Candidate fixture pairs are enumerated in ascending (carA, fixA, carB, fixB); touching ones are compacted in that
   // order, inherit the stored impulses of the previous step by feature id, and are STORED in island order (below).
@@ -577,6 +611,7 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
     if (lane == 0) { store[0] = (uint32_t)nn; store[1] = base > MCR_CC_MAX ? 1u : 0u; if (base > MCR_CC_MAX) mcr_raise(p, ST_CC_OVERFLOW); }
     nn_final = nn;
   } else if (lane == 0 && pass == 1) store[0] = 0;
+  COL_STAMP(6);
   // side-stream partition: envs whose dynamics chain is going to be long (a touching car<->car pair).  cc_mode: the verdict
   // the main launches go by (p.part: mcr_touch_verdict, evaluated by last step's bookkeeping on the same poses) must
   // agree — counters[4] counts disagreements (tests and bench assert 0).

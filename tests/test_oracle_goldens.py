@@ -149,7 +149,7 @@ def test_trig_mode_deviation_over_full_episodes(oracle):
     """the build's correctly rounded sinf/cosf vs glibc's (what Box2D calls on x86) over FULL
     1000-step episodes (6 tracks, 2 cars, a driver that keeps moving).  The 1-ulp differences (1.3 % of the calls) are
     a chaotic perturbation, exactly as a different libm would be for the reference itself: measured here, positions
-    agree to < 0.06 units after 1000 steps in 4 of 6 episodes and decorrelate (tens of units) in the 2 episodes where a
+    agree to < 0.11 units after 1000 steps in 4 of 6 episodes and decorrelate (units to tens of units) in the 2 episodes where a
     spin / car<->car contact amplifies them; the tile-visit counts — the reward signal — end equal in all 6, and never
     differ at any step in 5 of 6.  DESIGN.md section 5 quotes these numbers."""
     devs60, devs1000, equal_end, equal_always = [], [], 0, 0
@@ -171,5 +171,5 @@ def test_trig_mode_deviation_over_full_episodes(oracle):
         equal_always += always
         a.close(); b.close()
     assert max(devs60) < 2e-2, devs60                       # short horizon: fp32 roundoff scale
-    assert sorted(devs1000)[3] < 0.1, devs1000              # 4 of 6 episodes stay together for the whole episode
+    assert sorted(devs1000)[3] < 0.2, devs1000              # 4 of 6 episodes stay together for the whole episode (r04, island order: 0.007 .. 0.109)
     assert equal_end >= 5 and equal_always >= 4, (equal_end, equal_always, devs1000)
