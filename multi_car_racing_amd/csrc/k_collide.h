@@ -149,12 +149,12 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   // order, then car by car the hull polygons and the wheels.
   __shared__ float4 wfat_new[MCR_MAX_AGENTS * 4], wfat_old[MCR_MAX_AGENTS * 4];
   __shared__ float cfat[MCR_MAX_AGENTS][4];                        // per car: union of its wheels' fat AABBs
-  __shared__ float cfat8[MCR_MAX_AGENTS][4];                       // per car: union of the fat AABBs of all 8 fixtures (which car pairs can hold contacts)
   __shared__ __attribute__((aligned(16))) unsigned long long evq[EVQ_CAP];   // begin events of this pass: stamp << 14 | tile << 5 | car * 4 + wheel
   __shared__ __attribute__((aligned(16))) uint16_t tfl16[MCR_TILE_CAP];      // flags word of the tiles that take a begin event
   __shared__ int evn;
   // the fat AABB of EVERY car fixture (hull polygons as well): needed by the car<->car broadphase contacts, which are settled right
   // after the proxies — before the tile phases first write the two arrays these alias
+  float (* const cfat8)[4] = (float (*)[4])cand;                  // per car: union of the fat AABBs of all 8 fixtures (which car pairs can hold contacts); dead before the candidate list is first written
   float4* const ffat_new = (float4*)evq;                           // [8N] (64 x 16 B = the event queue's 1 KB)
   static_assert(sizeof(unsigned long long) * EVQ_CAP >= sizeof(float4) * MCR_MAX_AGENTS * 8, "ffat_new aliases evq");
   const uint32_t label = pass == 1 ? 0u : es.bp_step;
@@ -277,12 +277,8 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   __syncthreads();                                                 // ffat_new (= evq) is free from here on
   COL_STAMP(2);
 
-  // uniform per-car accumulators (every lane keeps the same values)
-  double reward[MCR_MAX_AGENTS]; int tvc[MCR_MAX_AGENTS];
-#pragma unroll
-  for (int c = 0; c < MCR_MAX_AGENTS; ++c) { reward[c] = 0.0; tvc[c] = 0; }
-#pragma unroll
-  for (int c = 0; c < MCR_MAX_AGENTS; ++c) if (c < N) { reward[c] = __shfl(reward_pre, c); tvc[c] = (int)__shfl(tvc_pre, c); }      // (lane c loaded car c's)
+  // per-car accumulators: lane c keeps car c's (reward_pre, tvc_pre above)
+  double reward_acc = reward_pre; int tvc_acc = (int)tvc_pre;
 
   const float4* TAABB = (const float4*)(slot + MCR_OFF_TAABB);
   const float4* TVA = (const float4*)(slot + MCR_OFF_TVA); const float4* TVB = (const float4*)(slot + MCR_OFF_TVB);
@@ -351,12 +347,19 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
       // FindNewContacts: a moved wheel proxy gets a contact with every tile whose fat AABB its NEW fat AABB overlaps and its
       // old one did not (those already had one); all of them belong to this pass's batch
       const float tx0 = (bb.x - B2_POLYGON_RADIUS) - 0.1f, ty0 = (bb.y - B2_POLYGON_RADIUS) - 0.1f, tx1 = (bb.z + B2_POLYGON_RADIUS) + 0.1f, ty1 = (bb.w + B2_POLYGON_RADIUS) + 0.1f;
-      for (unsigned long long mm = moved_mask; mm; mm &= mm - 1ull) {
-        const int f = __builtin_ctzll(mm);
-        const float4 nf = wfat_new[f], of = wfat_old[f];
-        const bool on = !(nf.x > tx1 || tx0 > nf.z || nf.y > ty1 || ty0 > nf.w);         // b2TestOverlap(aabb, aabb)
-        const bool oo = !(of.x > tx1 || tx0 > of.z || of.y > ty1 || ty0 > of.w);
-        if (t >= 0 && on && !oo) p.bp_stamp[((size_t)env * MCR_TILE_CAP + t) * (4 * N) + f] = label;
+      for (int c = 0; c < N; ++c) {
+        unsigned mw = (unsigned)(moved_mask >> (4 * c)) & 0xfu;
+        if (!mw) continue;
+        // (a new fat AABB lies inside the box of its car's four: cars none of whose boxes meets a tile of this batch are skipped whole)
+        const bool nearc = t >= 0 && !(cfat[c][0] > tx1 || tx0 > cfat[c][2] || cfat[c][1] > ty1 || ty0 > cfat[c][3]);
+        if (!__any(nearc)) continue;
+        for (; mw; mw &= mw - 1u) {
+          const int f = c * 4 + __builtin_ctz(mw);
+          const float4 nf = wfat_new[f], of = wfat_old[f];
+          const bool on = !(nf.x > tx1 || tx0 > nf.z || nf.y > ty1 || ty0 > nf.w);         // b2TestOverlap(aabb, aabb)
+          const bool oo = !(of.x > tx1 || tx0 > of.z || of.y > ty1 || ty0 > of.w);
+          if (t >= 0 && on && !oo) p.bp_stamp[((size_t)env * MCR_TILE_CAP + t) * (4 * N) + f] = label;
+        }
       }
     }
     for (int c = 0; c < N; ++c) {
@@ -414,14 +417,11 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
       uint32_t fl = tfl16[t];
       if (!(fl & (1u << c))) {                                                          // FrictionDetector._contact (:113-120)
         fl |= 1u << c;
-#pragma unroll
-        for (int cc_ = 0; cc_ < MCR_MAX_AGENTS; ++cc_) {
-          if (cc_ == c) {
-            tvc[cc_] += 1;
-            const int past = __popc(fl & 0xffu) - 1;
-            const double factor = 1 - ((double)past / (double)N);
-            reward[cc_] += factor * 1000.0 / (double)T;
-          }
+        if (lane == c) {
+          tvc_acc += 1;
+          const int past = __popc(fl & 0xffu) - 1;
+          const double factor = 1 - ((double)past / (double)N);
+          reward_acc += factor * 1000.0 / (double)T;
         }
         __syncthreads();                                                                // every lane has read the word
         if (lane == 0) tfl16[t] = (uint16_t)fl;
@@ -438,9 +438,7 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   if (lane < N) {
     const int ci = env * N + lane;
     const uint32_t onr = (or_bits >> (4 * lane)) & 0xFu;
-    double r = 0.0; int tv = 0;
-#pragma unroll
-    for (int c = 0; c < MCR_MAX_AGENTS; ++c) if (c == lane) { r = reward[c]; tv = tvc[c]; }
+    const double r = reward_acc; const int tv = tvc_acc;
     if (pass == 0 && p.cc_mode) {
       // the main dynamics, running beside this launch (possibly on another XCD, behind another L2), reads these three words
       // of the car: device-scope stores and loads (write-through / L2-bypassing) instead of a release fence per workgroup —
@@ -638,6 +636,7 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
 }
 
 // one workgroup per env (the list launches of roles >= 2 call collide_block from k_list_chain.h)
-__global__ __launch_bounds__(64) void k_collide(McrParams p, int pass) {
+// (4 wavefronts per SIMD = 16 per CU: with one wavefront per env the 4096 envs of the bench are resident in ONE round; LDS: see lds_bytes)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_collide(McrParams p, int pass) {
   collide_block(p, pass, (int)blockIdx.x);
 }
