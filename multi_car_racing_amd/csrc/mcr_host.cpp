@@ -252,70 +252,70 @@ inline double sgn(double v) { return v > 0 ? 1.0 : (v < 0 ? -1.0 : 0.0); }
 // One attempt (multi_car_racing.py:183-291).  false == the reference's `return False`.
 bool track_attempt(uint32_t* mt, std::vector<TrackPt>& lap) {
   const double PI = M_PI;
-  double cp_a[kCheckpoints], cp_x[kCheckpoints], cp_y[kCheckpoints];
+  double gate_angle[kCheckpoints], gate_x[kCheckpoints], gate_y[kCheckpoints];
   for (int c = 0; c < kCheckpoints; ++c) {
     double noise = mt_uniform(mt, 0, 2 * PI * 1 / kCheckpoints);
     double rad = mt_uniform(mt, kTrackRad / 3, kTrackRad);
     double alpha = 2 * PI * c / kCheckpoints + noise;
     if (c == 0) { alpha = 0; rad = 1.5 * kTrackRad; }
     if (c == kCheckpoints - 1) { alpha = 2 * PI * c / kCheckpoints; rad = 1.5 * kTrackRad; }
-    cp_a[c] = alpha; cp_x[c] = rad * cos(alpha); cp_y[c] = rad * sin(alpha);
+    gate_angle[c] = alpha; gate_x[c] = rad * cos(alpha); gate_y[c] = rad * sin(alpha);
   }
   const double start_alpha = 2 * PI * (-0.5) / kCheckpoints;
 
   std::vector<TrackPt> path; path.reserve(2600);
   double x = 1.5 * kTrackRad, y = 0, beta = 0;
-  long dest = 0; int laps = 0; int guard = 2500; bool other_side = false;
+  long gate = 0; int laps = 0; int budget = 2500; bool below_axis = false;
   for (;;) {
     double alpha = atan2(y, x);
-    if (other_side && alpha > 0) { ++laps; other_side = false; }
-    if (alpha < 0) { other_side = true; alpha += 2 * PI; }
-    double da, dx, dy;
+    if (below_axis && alpha > 0) { ++laps; below_axis = false; }
+    if (alpha < 0) { below_axis = true; alpha += 2 * PI; }
+    double gate_a, gate_px, gate_py;
     for (;;) {
-      bool failed = true;
+      bool wrapped = true;
       for (;;) {
-        int k = (int)(dest % kCheckpoints);
-        da = cp_a[k]; dx = cp_x[k]; dy = cp_y[k];
-        if (alpha <= da) { failed = false; break; }
-        ++dest;
-        if (dest % kCheckpoints == 0) break;
+        int k = (int)(gate % kCheckpoints);
+        gate_a = gate_angle[k]; gate_px = gate_x[k]; gate_py = gate_y[k];
+        if (alpha <= gate_a) { wrapped = false; break; }
+        ++gate;
+        if (gate % kCheckpoints == 0) break;
       }
-      if (!failed) break;
+      if (!wrapped) break;
       alpha -= 2 * PI;
     }
-    double r1x = cos(beta), r1y = sin(beta);
-    double p1x = -r1y, p1y = r1x;
-    double ddx = dx - x, ddy = dy - y;
-    double proj = r1x * ddx + r1y * ddy;
+    double head_x = cos(beta), head_y = sin(beta);
+    double fwd_x = -head_y, fwd_y = head_x;
+    double to_cp_x = gate_px - x, to_cp_y = gate_py - y;
+    double lateral = head_x * to_cp_x + head_y * to_cp_y;
     while (beta - alpha > 1.5 * PI) beta -= 2 * PI;
     while (beta - alpha < -1.5 * PI) beta += 2 * PI;
-    double prev_beta = beta;
-    proj *= MCR_SCALE;
-    if (proj > 0.3) beta -= fmin(kTurnRate, fabs(0.001 * proj));
-    if (proj < -0.3) beta += fmin(kTurnRate, fabs(0.001 * proj));
-    x += p1x * kDetailStep;
-    y += p1y * kDetailStep;
-    TrackPt tp = {alpha, prev_beta * 0.5 + beta * 0.5, x, y};
+    double heading_before = beta;
+    lateral *= MCR_SCALE;
+    if (lateral > 0.3) beta -= fmin(kTurnRate, fabs(0.001 * lateral));
+    if (lateral < -0.3) beta += fmin(kTurnRate, fabs(0.001 * lateral));
+    x += fwd_x * kDetailStep;
+    y += fwd_y * kDetailStep;
+    TrackPt tp = {alpha, heading_before * 0.5 + beta * 0.5, x, y};
     path.push_back(tp);
     if (laps > 4) break;
-    if (--guard == 0) break;
+    if (--budget == 0) break;
   }
   // closed loop between the last two start-line crossings
-  int i1 = -1, i2 = -1;
+  int cross_first = -1, cross_last = -1;
   int i = (int)path.size();
   for (;;) {
     --i;
     if (i == 0) return false;
     bool pass = path[i].alpha > start_alpha && path[i - 1].alpha <= start_alpha;
-    if (pass && i2 == -1) i2 = i;
-    else if (pass && i1 == -1) { i1 = i; break; }
+    if (pass && cross_last == -1) cross_last = i;
+    else if (pass && cross_first == -1) { cross_first = i; break; }
   }
-  if (i2 - 1 <= i1) return false;   // python would produce an empty slice and raise on track[0]
-  lap.assign(path.begin() + i1, path.begin() + (i2 - 1));
-  double fb = lap[0].beta;
-  double px = cos(fb) * (lap[0].x - lap.back().x), py = sin(fb) * (lap[0].y - lap.back().y);
-  double glue = sqrt(px * px + py * py);
-  if (glue > kDetailStep) return false;
+  if (cross_last - 1 <= cross_first) return false;   // python would produce an empty slice and raise on track[0]
+  lap.assign(path.begin() + cross_first, path.begin() + (cross_last - 1));
+  double first_heading = lap[0].beta;
+  double seam_x = cos(first_heading) * (lap[0].x - lap.back().x), seam_y = sin(first_heading) * (lap[0].y - lap.back().y);
+  double seam = sqrt(seam_x * seam_x + seam_y * seam_y);
+  if (seam > kDetailStep) return false;
   return true;
 }
 
