@@ -15,7 +15,7 @@ def nxt():
     _k[0] += 1; return pool[_k[0] % 64]
 for _ in range(80): env.step(nxt())
 torch.cuda.synchronize()
-names = {0: "full", (1 << 20): "stagger"} if int(os.environ.get("QUICK", 0)) else {0: "full", 1: "-flags", 2: "-road shade", 4: "-cars", 8: "-writeout", 16: "-cull", 31: "-all", 18: "-cull-road", 26: "-cull-road-writeout"}
+names = {0: "full", 31: "-all"} if int(os.environ.get("QUICK", 0)) else {0: "full", 1: "-flags", 2: "-road shade", 4: "-cars", 8: "-writeout", 16: "-cull", 31: "-all", 18: "-cull-road", 26: "-cull-road-writeout"}
 res = {}
 for rnd in range(3):
     for mask in names:
