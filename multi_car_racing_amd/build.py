@@ -18,7 +18,7 @@ def deps():
     return out + [os.path.join(HERE, "..", "include", "mcr.h"), os.path.abspath(__file__)]      # (this file: the per-file flags)
 
 # -ffp-contract=off: host (x86-64) and gfx950 must round identically (numerics)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value"] + os.environ.get("MCR_EXTRA_CFLAGS", "").split()   # (build-time diagnostics only)
 
 
 def needs_build():

@@ -463,7 +463,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
   __shared__ float xv[15][64], xp[15][64];            // body exchange: (vx,vy,w) / (cx,cy,a) x 5 bodies per lane
   __shared__ __attribute__((aligned(16))) float vcpool[DYN_VC_POOL][cc::VC_SIZE];
   __shared__ uint32_t pcrec[DYN_VC_POOL][16];      // manifold records (key, type|n, local normal/point, 2 points) for the position sweeps
-  __shared__ int xisl[64], xact[64], xjok[64], xcok[64];
+  __shared__ int xisl[64], xjok[64];
   __shared__ float xms[64];
   __shared__ int xmap[64];                            // per lane: slot of wheel w's registers at bits 2w (island order of the joints)
   const int g = blk * 64 + threadIdx.x;
@@ -840,9 +840,29 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
         for (int w = 1; w < 4; ++w) if (((m >> (2 * w)) & 3) == t) wq[t] = w; }
     }
     const bool wave_perm = __any(xmap[lane] != 0xe4) != 0;
+    // Island bookkeeping of the sweeps in registers: imask = the lanes of this car's island (constant over the loop); who is still
+    // iterating, whose joints are within tolerance and who moved travel as ballots, the leader's per-island contact verdicts as one
+    // shuffle — no LDS round trips (they were a quarter of a sweep: 8 dependent reads per lane at N = 8).
+    unsigned long long imask = 1ull << lane;
+    if (ccn > 0) {
+      imask = 0ull;
+      for (int c = 0; c < p.N; ++c) if (xisl[leader_lane + c] == isl) imask |= 1ull << (leader_lane + c);
+      if (agent == 0) for (int i = 0; i < ccn; ++i) pcrec[pool_base + i][0] |= (uint32_t)xisl[leader_lane + (int)(pcrec[pool_base + i][0] & 15u)] << 24;   // the contact's island
+    }
+    __syncthreads();
     const int pos_iters_cc = (p.debug & 64) ? 2 : 60;
+#ifdef MCR_POSLOOP_PROFILE        // build-time diagnostic (MCR_EXTRA_CFLAGS=-DMCR_POSLOOP_PROFILE, tools/posloop_profile.py): where a contact position sweep goes
+    unsigned long long pt[5] = {0, 0, 0, 0, 0}, pt0 = 0; int pn = 0;
+#define PP_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); pt[i] += now_ - pt0; pt0 = now_; } while (0)
+#define PP_BEGIN() do { pt0 = __builtin_readcyclecounter(); ++pn; } while (0)
+#else
+#define PP_MARK(i) do {} while (0)
+#define PP_BEGIN() do {} while (0)
+#endif
     for (int it = 0; it < pos_iters_cc; ++it) {
-      if (!__any(active)) break;
+      const unsigned long long actm = __ballot(active);
+      if (!actm) break;
+      PP_BEGIN();
       const bool in_cc = active && ccn > 0;
       float ox[5], oy[5], oa[5];
 #pragma unroll
@@ -851,8 +871,9 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
 #pragma unroll
         for (int k = 0; k < 5; ++k) { xp[0 * 5 + k][lane] = b[k].cx; xp[1 * 5 + k][lane] = b[k].cy; xp[2 * 5 + k][lane] = b[k].a; }
       }
-      xact[lane] = active ? 1 : 0;
       __syncthreads();
+      PP_MARK(0);
+      int cok = 0xff;                                    // leader: bit r = the contacts of island r are within tolerance
       if (ccn > 0 && agent == 0) {
         // contacts of the still-iterating islands, in contact order; min separation per island
         float minSep[MCR_MAX_AGENTS];
@@ -860,17 +881,18 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
         for (int c = 0; c < MCR_MAX_AGENTS; ++c) minSep[c] = 0.0f;
         for (int i = 0; i < ccn; ++i) {
           const uint32_t* rec = pcrec[pool_base + i];
-          const int ca = rec[0] & 15;
-          const int r = xisl[leader_lane + ca];
-          if (!xact[leader_lane + r]) continue;
+          const int r = (int)((rec[0] >> 24) & 15u);
+          if (!((actm >> (leader_lane + r)) & 1ull)) continue;
           const float ms = cc_position(CM, rec, leader_lane, xp);
 #pragma unroll
           for (int c = 0; c < MCR_MAX_AGENTS; ++c) if (c == r) minSep[c] = mcr_min(minSep[c], ms);
         }
+        cok = 0;
 #pragma unroll
-        for (int c = 0; c < MCR_MAX_AGENTS; ++c) if (c < p.N) xcok[leader_lane + c] = (minSep[c] >= -3.0f * B2_LINEAR_SLOP) ? 1 : 0;
+        for (int c = 0; c < MCR_MAX_AGENTS; ++c) cok |= (minSep[c] >= -3.0f * B2_LINEAR_SLOP) ? (1 << c) : 0;
       }
       __syncthreads();
+      PP_MARK(1);
       bool jointsOk = true;
       if (active) {
         if (in_cc) {
@@ -887,22 +909,29 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
       }
       // fixed point: an island whose sweep failed without moving any of its bodies would repeat that sweep
       // identically up to iteration 60 — it stops here with the same outcome (see the contact-free loop above)
+      PP_MARK(2);
       bool moved = false;
 #pragma unroll
       for (int k = 0; k < 5; ++k) moved = moved || ox[k] != b[k].cx || oy[k] != b[k].cy || oa[k] != b[k].a;
-      xjok[lane] = (jointsOk ? 1 : 0) | (moved ? 2 : 0);
-      __syncthreads();
-      if (active) {
-        bool ok = jointsOk, mv = moved;
-        if (ccn > 0) {
-          ok = xcok[leader_lane + isl] != 0;
-          for (int c = 0; c < p.N; ++c) if (xisl[leader_lane + c] == isl) { ok = ok && ((xjok[leader_lane + c] & 1) != 0); mv = mv || ((xjok[leader_lane + c] & 2) != 0); }
+      {
+        const unsigned long long okm = __ballot(jointsOk), mvm = __ballot(moved);
+        const int cokl = __shfl(cok, leader_lane);
+        if (active) {
+          bool ok = jointsOk, mv = moved;
+          if (ccn > 0) { ok = ((cokl >> isl) & 1) != 0 && (okm & imask) == imask; mv = (mvm & imask) != 0ull; }
+          if (ok) { positionSolved = true; active = false; }
+          else if (!mv) active = false;
         }
-        if (ok) { positionSolved = true; active = false; }
-        else if (!mv) active = false;
       }
       __syncthreads();
+      PP_MARK(3);
     }
+#ifdef MCR_POSLOOP_PROFILE
+    if ((p.debug & 256) && mode == 0 && threadIdx.x == 0 && p.role == 2) {
+      unsigned long long* o = p.dbg_stamps + ((size_t)((p.B * p.G + 63) / 64) + blk) * 8;
+      o[5] = pt[0] | ((unsigned long long)pn << 48); o[6] = pt[1] | (pt[2] << 32); o[7] = pt[3];
+    }
+#endif
     if (wave_perm) {                                     // the (joint, wheel) register sets back where the rest of the step expects them
       int tag[4] = {0, 0, 0, 0};
       slot_sort(J, b, wq, tag);

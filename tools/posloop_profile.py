@@ -1,0 +1,33 @@
+"""Where a position sweep of the contact chain goes (build with MCR_EXTRA_CFLAGS=-DMCR_POSLOOP_PROFILE python -m multi_car_racing_amd.build --force):
+clock of lane 0 per segment, summed over the sweeps of a wavefront.  GPU only, diagnostics.   N=8 python tools/posloop_profile.py"""
+import sys, os, torch, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multi_car_racing_amd.vec_env import VecMultiCarRacing
+from multi_car_racing_amd import _lib
+B, N = 4096, int(os.environ.get("N", "8"))
+env = VecMultiCarRacing(B, N, seed=0, auto_reset=True, streams=2)
+env.reset()
+g = torch.Generator(device="cuda"); g.manual_seed(1)
+pool = torch.rand((64, B, N, 3), device="cuda", generator=g); pool[..., 0] = pool[..., 0] * 2 - 1
+G = 1
+while G < N: G *= 2
+nb = (B * G + 63) // 64
+ns = (B + 1) // 2
+buf = np.zeros((nb + 2 * ns) * 8, np.uint64)
+_lib.check(env.L.mcr_debug_set(env.h, 256))
+rows = []
+for k in range(600):
+    env.step(pool[k % 64])
+    if k >= 200 and k % 10 == 0:
+        _lib.check(env.L.mcr_debug_read_dynamics_stamps(env.h, _lib.ptr(buf), len(buf)))
+        st = buf.reshape(nb + 2 * ns, 8)[nb:nb + ns]
+        ok = (st[:, 0] > 0) & ((st[:, 5] >> np.uint64(48)) > 0)
+        for r in st[ok]:
+            n = int(r[5] >> np.uint64(48))
+            rows.append((n, int(r[5] & np.uint64((1 << 48) - 1)), int(r[6] & np.uint64(0xffffffff)), int(r[6] >> np.uint64(32)), int(r[7])))
+d = np.array(rows, np.float64)
+print(f"N={N}: {len(d)} contact wavefronts, sweeps per wavefront mean {d[:, 0].mean():.1f}; ticks per sweep (2.1 GHz: 1000 ticks = 0.48 us)")
+for i, n in enumerate(["exchange out + barrier", "leader: contacts (cc_position)", "exchange in + 4 joint corrections", "island bookkeeping + 2 barriers"]):
+    per = d[:, 1 + i] / d[:, 0]
+    print(f"   {n:36s} mean {per.mean():8.0f}  median {np.median(per):8.0f}")
+print(f"   {'total':36s} mean {(d[:, 1:].sum(1) / d[:, 0]).mean():8.0f}")
