@@ -459,37 +459,25 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   // order, inherit the stored impulses of the previous step by feature id, and are STORED in island order (below).
   uint32_t* store = p.cc_store + (size_t)env * (MCR_CC_MAX * MCR_CC_WORDS + 4);
   // cheap exit: no pair of car boxes (tight AABB + 0.05) overlaps -> no fixture pair can touch
-  bool any_pair = false;
-  uint32_t amask = 0u;                                         // bit a: car a's box overlaps the box of some car b > a
+  unsigned long long pairs = 0ull;                             // bit a * 8 + b (a < b): the two cars' boxes overlap
   if (p.car_contacts && N > 1) {
-    for (int a = 0; a < N - 1; ++a) for (int b = a + 1; b < N; ++b)
-      if (!(cbox[a][0] > cbox[b][2] || cbox[a][2] < cbox[b][0] || cbox[a][1] > cbox[b][3] || cbox[a][3] < cbox[b][1])) { any_pair = true; amask |= 1u << a; }
+    const int a = lane >> 3, b = lane & 7;
+    pairs = __ballot(a < b && b < N && !(cbox[a][0] > cbox[b][2] || cbox[a][2] < cbox[b][0] || cbox[a][1] > cbox[b][3] || cbox[a][3] < cbox[b][1]));
   }
+  const bool any_pair = pairs != 0ull;
   int nn_final = 0;                                            // touching car<->car pairs of this env (wave-uniform)
   if (p.car_contacts && N > 1 && !any_pair) {
     if (lane == 0) { store[0] = 0; store[1] = 0; }
   } else if (p.car_contacts && N > 1) {
     const int old_n = (pass == 1) ? 0 : (int)store[0];
     const McrShapes& S = *p.shapes;
-    int total = 0;
-    for (int a = 0; a < N - 1; ++a) total += 64 * (N - 1 - a);
     int base = 0;
-    for (int r0 = 0, a_of = 0, a_end = 64 * (N - 1); r0 < total; r0 += 64) {
-      // (the 64 x (N-1-a) pair slots of car a are whole 64-lane chunks: a chunk whose car a has no partner b > a with an overlapping
-      // box cannot hold a touching pair — at N = 8 that skips most of the 28 chunks)
-      while (r0 >= a_end) { ++a_of; a_end += 64 * (N - 1 - a_of); }
-      if (!((amask >> a_of) & 1u)) continue;
-      const int idx = r0 + lane;
-      bool valid = idx < total;
-      int a = 0, fa = 0, b = 1, fb = 0;
-      if (valid) {
-        int r = idx;
-        for (a = 0; a < N - 1; ++a) { const int cnt = 64 * (N - 1 - a); if (r < cnt) break; r -= cnt; }
-        const int per_fa = (N - 1 - a) * 8;
-        fa = r / per_fa; const int r2 = r - fa * per_fa;
-        b = a + 1 + (r2 >> 3); fb = r2 & 7;
-        if (fa >= 4 && fb >= 4) valid = false;                            // wheel (0x20, mask 1) vs wheel: filtered
-      }
+    // one trip per pair of cars whose boxes overlap: its 8 x 8 fixture pairs on the 64 lanes (the records are sorted into island
+    // order below: the order they are found in does not matter)
+    for (unsigned long long pm = pairs; pm; pm &= pm - 1ull) {
+      const int ab = __builtin_ctzll(pm), a = ab >> 3, b = ab & 7;
+      const int fa = lane >> 3, fb = lane & 7;
+      const bool valid = !(fa >= 4 && fb >= 4);                              // wheel (0x20, mask 1) vs wheel: filtered
       cc::Manifold M; M.n = 0; M.type = 0; M.pl[0] = M.pl[1] = v2(0.0f, 0.0f); M.id[0] = M.id[1] = 0; M.localNormal = M.localPoint = v2(0.0f, 0.0f);
       if (valid) {
         const int ia = a * 8 + fa, ib = b * 8 + fb;

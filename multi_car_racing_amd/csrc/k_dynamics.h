@@ -752,23 +752,42 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
     }
   } else {
     const int vel_iters = (p.debug & 128) ? 2 : 180;          // debug bit 7: timing experiments only
+#ifdef MCR_POSLOOP_PROFILE
+    unsigned long long vt[4] = {0, 0, 0, 0}, vt0 = 0;
+#define VP_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); vt[i] += now_ - vt0; vt0 = now_; } while (0)
+#define VP_BEGIN() do { vt0 = __builtin_readcyclecounter(); } while (0)
+#else
+#define VP_MARK(i) do {} while (0)
+#define VP_BEGIN() do {} while (0)
+#endif
     for (int it = 0; it < vel_iters; ++it) {
+      VP_BEGIN();
       if (run) {
 #pragma unroll
         for (int q = 3; q >= 0; --q) joint_velocity(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);
       }
+      VP_MARK(0);
       if (ccn > 0 && !(p.debug & 1024)) {
 #pragma unroll
         for (int k = 0; k < 5; ++k) { xv[0 * 5 + k][lane] = b[k].vx; xv[1 * 5 + k][lane] = b[k].vy; xv[2 * 5 + k][lane] = b[k].w; }
       }
       __syncthreads();
+      VP_MARK(1);
       if (ccn > 0 && agent == 0 && !(p.debug & 512)) for (int i = 0; i < ccn; ++i) cc_velocity(CM, vcpool[pool_base + i], xv);
       __syncthreads();
+      VP_MARK(2);
       if (ccn > 0 && !(p.debug & 1024)) {
 #pragma unroll
         for (int k = 0; k < 5; ++k) { b[k].vx = xv[0 * 5 + k][lane]; b[k].vy = xv[1 * 5 + k][lane]; b[k].w = xv[2 * 5 + k][lane]; }
       }
+      VP_MARK(3);
     }
+#ifdef MCR_POSLOOP_PROFILE
+    if ((p.debug & 256) && (p.debug & 65536) && mode == 0 && threadIdx.x == 0 && p.role == 2) {
+      unsigned long long* o = p.dbg_stamps + ((size_t)((p.B * p.G + 63) / 64) + blk) * 8;
+      o[5] = vt[0] | (vt[1] << 32); o[6] = vt[2] | (vt[3] << 32);
+    }
+#endif
   }
   if (wave_cc && ccn > 0 && agent == 0) {            // StoreImpulses
     for (int i = 0; i < ccn; ++i) {
@@ -927,7 +946,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
       PP_MARK(3);
     }
 #ifdef MCR_POSLOOP_PROFILE
-    if ((p.debug & 256) && mode == 0 && threadIdx.x == 0 && p.role == 2) {
+    if ((p.debug & 256) && !(p.debug & 65536) && mode == 0 && threadIdx.x == 0 && p.role == 2) {
       unsigned long long* o = p.dbg_stamps + ((size_t)((p.B * p.G + 63) / 64) + blk) * 8;
       o[5] = pt[0] | ((unsigned long long)pn << 48); o[6] = pt[1] | (pt[2] << 32); o[7] = pt[3];
     }

@@ -14,20 +14,26 @@ while G < N: G *= 2
 nb = (B * G + 63) // 64
 ns = (B + 1) // 2
 buf = np.zeros((nb + 2 * ns) * 8, np.uint64)
-_lib.check(env.L.mcr_debug_set(env.h, 256))
+VEL = int(os.environ.get("VEL", "0"))          # 1: the velocity sweeps instead (debug bit 16)
+_lib.check(env.L.mcr_debug_set(env.h, 256 | (65536 if VEL else 0)))
 rows = []
 for k in range(600):
     env.step(pool[k % 64])
     if k >= 200 and k % 10 == 0:
         _lib.check(env.L.mcr_debug_read_dynamics_stamps(env.h, _lib.ptr(buf), len(buf)))
         st = buf.reshape(nb + 2 * ns, 8)[nb:nb + ns]
+        if VEL:
+            for r in st[(st[:, 0] > 0) & (st[:, 5] > 0)]:
+                rows.append((180, int(r[5] & np.uint64(0xffffffff)), int(r[5] >> np.uint64(32)), int(r[6] & np.uint64(0xffffffff)), int(r[6] >> np.uint64(32))))
+            continue
         ok = (st[:, 0] > 0) & ((st[:, 5] >> np.uint64(48)) > 0)
         for r in st[ok]:
             n = int(r[5] >> np.uint64(48))
             rows.append((n, int(r[5] & np.uint64((1 << 48) - 1)), int(r[6] & np.uint64(0xffffffff)), int(r[6] >> np.uint64(32)), int(r[7])))
 d = np.array(rows, np.float64)
 print(f"N={N}: {len(d)} contact wavefronts, sweeps per wavefront mean {d[:, 0].mean():.1f}; ticks per sweep (2.1 GHz: 1000 ticks = 0.48 us)")
-for i, n in enumerate(["exchange out + barrier", "leader: contacts (cc_position)", "exchange in + 4 joint corrections", "island bookkeeping + 2 barriers"]):
+names = ["4 joints", "exchange out + barrier", "leader: contacts (cc_velocity)", "exchange in"] if VEL else ["exchange out + barrier", "leader: contacts (cc_position)", "exchange in + 4 joint corrections", "island bookkeeping + 2 barriers"]
+for i, n in enumerate(names):
     per = d[:, 1 + i] / d[:, 0]
     print(f"   {n:36s} mean {per.mean():8.0f}  median {np.median(per):8.0f}")
 print(f"   {'total':36s} mean {(d[:, 1:].sum(1) / d[:, 0]).mean():8.0f}")
