@@ -15,7 +15,15 @@
 #include "k_touch.h"
 
 // (env_of_list >= 0: the env was looked up by the caller — the list rasters' bookkeeping workgroups, k_view.h — and blk is the agent)
-__device__ __forceinline__ void flags_block(const McrParams& p, const int blk, const int env_of_list = -1) {
+// the touch verdict of a listed env on a wavefront of its own (the list rasters' bookkeeping workgroups: beside the env's flag scans, not behind one)
+__device__ __forceinline__ void verdict_block(const McrParams& p, const int env) {
+  if (p.part_next == nullptr || env >= p.env0 + p.nenv) return;
+  const bool active = p.env[env].active != 0;
+  const bool v = mcr_touch_verdict(p, env);
+  if ((threadIdx.x & 63) == 0) p.part_next[env] = (active && v) ? 1 : 0;
+}
+// (env_of_list >= 0 ...; verdict_elsewhere: another wavefront settles the env's touch verdict)
+__device__ __forceinline__ void flags_block(const McrParams& p, const int blk, const int env_of_list = -1, const bool verdict_elsewhere = false) {
   const int lane = threadIdx.x & 63;
   const int N = p.N, BN = p.BN;
   // roles as in the other step kernels: 0 every env, 1 the main launch's envs, 2 / 3 the contact / deferred lists
@@ -27,7 +35,7 @@ __device__ __forceinline__ void flags_block(const McrParams& p, const int blk, c
   // step ended with are the ones the next contact pass sees.  Main launch: the main dynamics has written 0 for every env
   // whose hulls are far apart (nearly all) and 2 where the exact test is needed; list launches: always the exact test.
   // The mark is requested here and looked at when the scan below is done (its latency is off the wavefront's chain).
-  const bool vwave = p.part_next != nullptr && (env_of_list >= 0 ? blk : blk % N) == 0;
+  const bool vwave = p.part_next != nullptr && !verdict_elsewhere && (env_of_list >= 0 ? blk : blk % N) == 0;
   uint32_t vmark = 0;
   if (vwave) vmark = p.role == 1 ? (uint32_t)p.part_next[env] : 2u;
   auto settle_verdict = [&]() {

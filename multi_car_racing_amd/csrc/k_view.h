@@ -229,7 +229,12 @@ __global__ __launch_bounds__(VIEW_THREADS, LIST ? 3 : 4) void k_view(McrParams p
     // per car.  Contact list for the contact chain's raster, deferred list otherwise (the re-spawned envs' cars take none in this step).
     const int32_t* __restrict__ L = p.role == 2 ? p.clist : p.dlist;
     const int ncars = L[0] * N, per_round = p.flags_blocks * (VIEW_THREADS / 64);
-    for (int c = ((int)blockIdx.x - vgrid) * (VIEW_THREADS / 64) + (int)(threadIdx.x >> 6); c < ncars; c += per_round) flags_block(p, c % N, L[1 + c / N]);
+    // (work items: the cars' flag scans, then one touch verdict per env — on different wavefronts, side by side)
+    const int nverd = (p.part_next != nullptr && N > 1) ? L[0] : 0;
+    for (int c = ((int)blockIdx.x - vgrid) * (VIEW_THREADS / 64) + (int)(threadIdx.x >> 6); c < ncars + nverd; c += per_round) {
+      if (c < ncars) flags_block(p, c % N, L[1 + c / N], nverd != 0);
+      else verdict_block(p, L[1 + c - ncars]);
+    }
     return;
   }
   int my_env = -1, my_slot = 0, my_P = -1, my_agent = 0;
