@@ -171,7 +171,9 @@ int mcr_timing_enable(mcr_env* h, int mask);
  *   raster: 0 skip flags block, 1 skip road shading, 2 skip cars, 3 skip write-out, 4 skip binning/cull;
  *   dynamics: 6 cap the position loops at 2 sweeps, 7 cap the velocity sweeps of contact waves at 2,
  *             9 skip the contact velocity solve, 10 skip the LDS body exchange of contact waves.
- * Bits 5 and 8 only add clock stamps (raster / dynamics phases) and leave the results untouched. */
+ *             14 solve car<->car contacts and joints in rounds 1-3's defined order instead of b2World::Solve's island order.
+ * Bits 5, 8 and 15 only add clock stamps (raster / dynamics / contact-pass phases; 16 with 8: the velocity sweeps in a build with
+ * MCR_POSLOOP_PROFILE) and leave the results untouched.  11-13: memory-ordering / starvation experiments of the tests (mcr_kernels.h). */
 int mcr_debug_set(mcr_env* h, int value);
 /* debug bit 5 (32): the raster kernel stamps s_memtime per phase; read the 64-float tail of a view's scratch */
 int mcr_debug_read_view_scratch(mcr_env* h, int view, void* out, int nbytes);
