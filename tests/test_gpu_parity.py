@@ -538,6 +538,33 @@ def test_contacts_are_solved_in_island_dfs_order(torch_cuda, oracle, N):
     env.close()
 
 
+@pytest.mark.parametrize("N", [2, 4])
+def test_driving_policy_pile_ups_bit_exact(torch_cuda, oracle, N):
+    """A policy that DRIVES (bench.py --actions drive: full gas, a little steering noise) with every other car braking for a while:
+    the cars behind run into them — several manifolds per env, islands of more than two cars at N = 4, warm-started impulses over hundreds
+    of steps, contact chain and main launch side by side (streams=2).  State and rewards bit-exact, every step."""
+    torch = torch_cuda
+    B, seed, steps = 24, 7000 + N, 360
+    env = _make(B, N, seed, contacts=True, use_random_direction=True, streams=2); env.reset()
+    orcs = _oracles(oracle, B, N, seed, contacts=True, use_random_direction=True)
+    rng = np.random.RandomState(N)
+    most = 0; contact_steps = 0
+    for k in range(steps):
+        a = np.zeros((B, N, 3), np.float32)
+        a[..., 0] = rng.uniform(-0.1, 0.1, (B, N)); a[..., 1] = 1.0
+        if 50 <= k < 130: a[:, ::2, 1] = 0.0; a[:, ::2, 2] = 0.9                    # every other car brakes for a while, then the others:
+        if 200 <= k < 280: a[:, 1::2, 1] = 0.0; a[:, 1::2, 2] = 0.9                 # whoever is behind runs into them
+        _, rew, _, _ = env.step(torch.from_numpy(a).cuda())
+        _, _, orw, _ = oracle.step_batch(orcs, a, None, threads=8)
+        assert np.array_equal(orw, rew.cpu().numpy()), f"step {k}: envs {np.nonzero((orw != rew.cpu().numpy()).any(1))[0][:8]}"
+        nc = [o.num_car_contacts() for o in orcs]
+        most = max(most, max(nc)); contact_steps += sum(1 for c in nc if c > 0)
+        if k % 40 == 39: _assert_state_equal(env, orcs, f"pile-up step {k}")
+    _assert_state_equal(env, orcs, "pile-up, end")
+    assert contact_steps > 40 and most >= 3, (contact_steps, most)
+    env.close()
+
+
 @pytest.mark.parametrize("streams", [1, 2])
 def test_random_rollout_with_contacts_enabled(torch_cuda, oracle, streams):
     """Default configuration (contacts on), N=8 crowded start: whatever happens, HIP == oracle."""
