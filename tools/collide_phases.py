@@ -9,6 +9,7 @@ env = VecMultiCarRacing(B, N, seed=0, auto_reset=True, streams=2)
 env.reset()
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 pool = torch.rand((64, B, N, 3), device="cuda", generator=g); pool[..., 0] = pool[..., 0] * 2 - 1
+if int(os.environ.get("DRIVE", "0")): pool[..., 0] *= 0.1; pool[..., 1] = 1.0; pool[..., 2] = 0.0      # bench.py --actions drive
 buf = np.zeros(B * 8, np.uint64)
 _lib.check(env.L.mcr_debug_set(env.h, 32768))
 names = ["fixtures + proxies (all 8 per car)", "car<->car broadphase contacts", "tile candidates + overlap tests", "tile contact state + event replay",

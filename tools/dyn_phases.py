@@ -9,6 +9,7 @@ env = VecMultiCarRacing(B, N, seed=0, auto_reset=True, streams=2)
 env.reset()
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 pool = torch.rand((64, B, N, 3), device="cuda", generator=g); pool[..., 0] = pool[..., 0] * 2 - 1
+if int(os.environ.get("DRIVE", "0")): pool[..., 0] *= 0.1; pool[..., 1] = 1.0; pool[..., 2] = 0.0      # bench.py --actions drive
 G = 1
 while G < N: G *= 2
 nb = (B * G + 63) // 64
