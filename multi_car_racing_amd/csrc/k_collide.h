@@ -8,7 +8,10 @@
 //  * begin events are replayed in the order Box2D's Collide fires them — contacts of a later FindNewContacts first, then
 //    tile descending, then car / wheel descending (the broadphase model below) — so that "who visited the
 //    tile first" and the f64 reward accumulation are the reference's (:113-120);
-//  * the per-wheel "touches any tile" mask (friction_limit, Car.step) is a wave-wide OR.
+//  * the per-wheel "touches any tile" mask (friction_limit, Car.step) is a wave-wide OR;
+//  * car<->car: proxies for all 8 fixtures of a car (b2DynamicTree::MoveProxy semantics) and a creation stamp per pair of fixtures of two
+//    cars whose fat AABBs overlap (= Box2D's contact exists) — what orders the contact edges b2World::Solve's island search walks; the
+//    touching pairs' manifolds (b2CollidePolygons), stored in the order of that search together with each car's joint order.
 //
 // Overlap predicate == b2TestOverlap itself (GJK b2Distance with radii, touching iff distance < 10*FLT_EPSILON: k_gjk.h),
 // behind a SAT far-field filter that never changes its result (col::overlap).

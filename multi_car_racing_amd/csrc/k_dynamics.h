@@ -12,6 +12,9 @@
 // one coalesced 4- or 8-byte access per SoA field per lane.  The launch lasts as long as its slowest wavefront,
 // which is why envs with car<->car contacts (role 2) and envs with a crawling position loop (deferral, role 3)
 // run in launches of their own on other streams (mcr_hip.hip: launch_step).
+// dynamics_block<CC>: CC = false is the build without any car<->car contact code (main launch of the three-chain step, resume chain);
+// CC = true adds the contact solver (sequential Gauss-Seidel over the env's manifolds by its leader lane, bodies exchanged through LDS,
+// constraints in the order of b2World::Solve's island search: the records arrive in it, a car's joints are permuted into it).
 #pragma once
 #include "mcr_kernels.h"
 #include "k_carcontacts.h"
