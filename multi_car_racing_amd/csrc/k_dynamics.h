@@ -179,7 +179,10 @@ __device__ __forceinline__ bool joint_position(const Joint& J, Body& A, Body& B,
     const Rot qA = rc.q;
     V2 rA = rmul(qA, v2(anchx, anchy) - v2(lcx, lcy));
     float Cx = (cBx - cAx) - rA.x, Cy = (cBy - cAy) - rA.y;
-    positionError = sqrtf(Cx * Cx + Cy * Cy);
+    // positionError = sqrtf(Cx Cx + Cy Cy) is only ever compared with b2_linearSlop: sqrtf is monotonic and correctly rounded, so
+    // "sqrtf(x) <= 0.005f" is "x <= T" with T the largest float whose root rounds to 0.005f or below (0x37d1b718: the next float's root
+    // is 0.0050000004f; tests/test_oracle_pinning.py checks it against sqrtf) — the square root (12 instructions of every correction) goes
+    positionError = Cx * Cx + Cy * Cy;
     float k11 = mA + mB + iA * rA.y * rA.y;
     float k12 = -iA * rA.x * rA.y;
     float k22 = mA + mB + iA * rA.x * rA.x;
@@ -190,7 +193,7 @@ __device__ __forceinline__ bool joint_position(const Joint& J, Body& A, Body& B,
     cBx = cBx + mB * ix; cBy = cBy + mB * iy;
   }
   A.cx = cAx; A.cy = cAy; A.a = aA; B.cx = cBx; B.cy = cBy; B.a = aB;
-  return positionError <= B2_LINEAR_SLOP && angularError <= B2_ANGULAR_SLOP;
+  return positionError <= __int_as_float(0x37d1b718) && angularError <= B2_ANGULAR_SLOP;
 }
 
 __device__ __forceinline__ double np_sign(double x) { return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : 0.0); }

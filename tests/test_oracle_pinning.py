@@ -350,3 +350,22 @@ def test_island_dfs_order_in_the_oracle(oracle):
                 assert b.island_diff() == 0
         a.close(); b.close()
     assert seen == 3, f"expected both a permuted joint order and a permuted contact order among the contact steps (got {seen})"
+
+
+def test_squared_slop_threshold_of_the_joint_position_verdict():
+    """k_dynamics.h: joint_position compares the SQUARED position error with T = 0x37d1b718 instead of its square root with b2_linearSlop
+    (b2RevoluteJoint::SolvePositionConstraints returns positionError <= b2_linearSlop): equivalent because sqrtf is monotonic and correctly
+    rounded and T is the largest float whose root does not exceed 0.005f."""
+    s = np.float32(0.005)
+    T = np.array([0x37d1b718], np.uint32).view(np.float32)[0]
+    assert np.sqrt(T, dtype=np.float32) <= s and np.sqrt(np.nextafter(T, np.float32(np.inf)), dtype=np.float32) > s
+    x = np.float32(2.5e-05)
+    lo = x
+    for _ in range(2000): lo = np.nextafter(lo, np.float32(0))
+    xs = [lo]
+    for _ in range(4000): xs.append(np.nextafter(xs[-1], np.float32(np.inf)))
+    xs = np.array(xs, np.float32)
+    assert np.array_equal(np.sqrt(xs, dtype=np.float32) <= s, xs <= T)
+    rng = np.random.RandomState(0)
+    xs = np.abs(rng.standard_normal(200000).astype(np.float32)) * np.float32(1e-4)
+    assert np.array_equal(np.sqrt(xs, dtype=np.float32) <= s, xs <= T)
