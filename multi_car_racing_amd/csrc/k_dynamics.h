@@ -836,7 +836,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
         // (the fixed-point test below costs 50 of a sweep's 720 instructions: it runs on every fourth sweep — the main launch's last one
         // among them — since a fixed point, once reached, is still there three sweeps later, with the same poses)
         const bool probe = (it & 3) == 2;
-        float ox[5] = {0, 0, 0, 0, 0}, oy[5] = {0, 0, 0, 0, 0}, oa[5] = {0, 0, 0, 0, 0};
+        float ox[5], oy[5], oa[5];                              // (written and read on probing sweeps only)
         if (probe) {
 #pragma unroll
           for (int k = 0; k < 5; ++k) { ox[k] = b[k].cx; oy[k] = b[k].cy; oa[k] = b[k].a; }

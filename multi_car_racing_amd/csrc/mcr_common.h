@@ -205,10 +205,24 @@ MCR_HD void mcr_sincos_core(double x, double* s, double* c) {
   }
 }
 // sinf/cosf spec of the build: the core above rounded once to f32 — bit-identical on host (x86-64) and gfx950.
+// (the quadrant's swap and signs are applied AFTER the rounding — rounding is symmetric, so (float)(-x) == -(float)x —: two selects and
+// two sign flips on f32 values instead of masked swaps of f64 pairs; this function sits on the serial chain of the position sweeps)
 MCR_HD void mcr_sincosf(float a, float* s, float* c) {
-  double ss, cc;
-  mcr_sincos_core((double)a, &ss, &cc);
-  *s = (float)ss; *c = (float)cc;
+  const double x = (double)a;
+  const double fn = rint(x * 6.36619772367581382433e-01);
+  const int n = (int)fn;
+  const double r = (x - fn * 1.57079632673412561417e+00) - fn * 6.07710050650619224932e-11;
+  const double z = r * r;
+  const double ps = r + r * z * (-1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                    z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)))));
+  const double pc = 1.0 - 0.5 * z + z * z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                    z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  const float fs = (float)ps, fc = (float)pc;
+  const bool odd = (n & 1) != 0;
+  const float ms = odd ? fc : fs, mc = odd ? fs : fc;                 // |sin|-side and |cos|-side magnitudes with their own signs
+  // quadrant 0: (s, c); 1: (c, -s); 2: (-s, -c); 3: (-c, s)
+  *s = (n & 2) ? -ms : ms;
+  *c = ((n + 1) & 2) ? -mc : mc;
 }
 struct Rot { float s, c; };
 MCR_HD Rot rot_of(float a) { Rot q; mcr_sincosf(a, &q.s, &q.c); return q; }
