@@ -104,7 +104,10 @@ __device__ __forceinline__ void joint_init(Joint& J, Body& A, Body& B, float anc
   B.w += iB * (J.im + J.iz);
 }
 
-// b2RevoluteJoint::SolveVelocityConstraints
+// b2RevoluteJoint::SolveVelocityConstraints.  LIMITS = false: for joints whose limit is known to be inactive in every lane of the wavefront
+// (the caller checked: J.limit == 0 — the state is a constant of the step) — the same operations as the !lim path below, without the
+// selects and masks that carry the other path's results along.
+template <bool LIMITS = true>
 __device__ __forceinline__ void joint_velocity(Joint& J, Body& A, Body& B, float mA, float iA, float mB, float iB, float maxImpulse) {
   float vAx = A.vx, vAy = A.vy, wA = A.w, vBx = B.vx, vBy = B.vy, wB = B.w;
   {
@@ -122,7 +125,7 @@ __device__ __forceinline__ void joint_velocity(Joint& J, Body& A, Body& B, float
   // inactive: 2x2 solve) share the 2x2 solve and the application of the impulse here — same expressions and operand
   // order per lane, but a wavefront whose lanes disagree about the limit state (front wheels of a batch of cars with
   // random steering: nearly always) no longer runs both copies of them.
-  const bool lim = J.limit != 0;
+  const bool lim = LIMITS && J.limit != 0;
   float impx = 0.0f, impy = 0.0f, impz = 0.0f;
   float rhsx = -c1x, rhsy = -c1y;
   bool two = !lim;
@@ -751,9 +754,20 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
         if (!__any(changed)) break;
       }
     } else if (run) {
-      for (int it = 0; it < 180; ++it) {
+      // The rear wheels (joints 2, 3: not steered, a motor holds them straight) reach their limits in crashes only: a wavefront none of
+      // whose cars has one there runs its 180 sweeps with the limit-free form of those two joints (36 instructions less per sweep).
+      if (!__any(J[2].limit != 0 || J[3].limit != 0)) {
+        for (int it = 0; it < 180; ++it) {
+          joint_velocity<false>(J[3], b[0], b[4], mH, iH, mW, iW, maxImpulse);
+          joint_velocity<false>(J[2], b[0], b[3], mH, iH, mW, iW, maxImpulse);
+          joint_velocity<true>(J[1], b[0], b[2], mH, iH, mW, iW, maxImpulse);
+          joint_velocity<true>(J[0], b[0], b[1], mH, iH, mW, iW, maxImpulse);
+        }
+      } else {
+        for (int it = 0; it < 180; ++it) {
 #pragma unroll
-        for (int q = 3; q >= 0; --q) joint_velocity(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);
+          for (int q = 3; q >= 0; --q) joint_velocity(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);
+        }
       }
     }
   } else {
