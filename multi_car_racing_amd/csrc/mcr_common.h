@@ -185,29 +185,6 @@ MCR_HD float mcr_max(float a, float b) { return a < b ? b : a; }   // std::max s
 MCR_HD float mcr_clamp(float a, float lo, float hi) { return mcr_max(lo, mcr_min(a, hi)); }
 MCR_HD float length(V2 a) { return sqrtf(a.x * a.x + a.y * a.y); }
 
-// f64 sin/cos core: 2-constant Cody-Waite reduction (exact products for |x| < ~1.6e6) + fdlibm minimax kernels;
-// absolute error ~1e-16.  Branch-free and ~45 f64 operations: also used where the device would otherwise call the
-// general-purpose libm sin/cos (camera rotation, wheel stripe phases), whose results only reach pixels.
-MCR_HD void mcr_sincos_core(double x, double* s, double* c) {
-  double fn = rint(x * 6.36619772367581382433e-01);
-  int n = (int)fn;
-  double r = (x - fn * 1.57079632673412561417e+00) - fn * 6.07710050650619224932e-11;
-  double z = r * r;
-  double ps = r + r * z * (-1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
-              z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)))));
-  double pc = 1.0 - 0.5 * z + z * z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
-              z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
-  switch (n & 3) {
-    case 0: *s = ps; *c = pc; break;
-    case 1: *s = pc; *c = -ps; break;
-    case 2: *s = -ps; *c = -pc; break;
-    default: *s = -pc; *c = ps; break;
-  }
-}
-// sinf/cosf spec of the build: f64 Cody-Waite reduction + fdlibm's kernel polynomials in Horner form with fused multiply-adds, rounded
-// once to f32 — bit-identical on host (x86-64: fma() is exact whether the machine has the instruction or libm emulates it) and gfx950.
-// (the quadrant's swap and signs are applied AFTER the rounding — rounding is symmetric, so (float)(-x) == -(float)x —: two selects and
-// two sign flips on f32 values instead of masked swaps of f64 pairs; this function sits on the serial chain of the position sweeps)
 // The coefficients: literals on the host; on the device words of constant memory (not `const`: the compiler must not fold them back into
 // literals) — scalar loads, hoisted out of the sweeps' loops, whose SGPR pairs v_fma_f64 takes as its addend directly.  A 64-bit literal
 // cannot be an operand: each Horner step was a v_mov_b64 of its coefficient plus a v_fmac_f64 — 40 moves per position sweep.
@@ -219,6 +196,30 @@ static __constant__ double MCR_SINCOS_K[14] = MCR_SINCOS_COEFFS;
 #else
 static const double MCR_SINCOS_K[14] = MCR_SINCOS_COEFFS;
 #endif
+// f64 sin/cos core: 2-constant Cody-Waite reduction + fdlibm minimax kernels, Horner with fused multiply-adds (as mcr_sincosf below);
+// absolute error ~1e-16.  Branch-free and ~25 f64 operations: also used where the device would otherwise call the
+// general-purpose libm sin/cos (camera rotation, wheel stripe phases), whose results only reach pixels.
+MCR_HD void mcr_sincos_core(double x, double* s, double* c) {
+  const double* K = MCR_SINCOS_K;
+  const double fn = rint(x * 6.36619772367581382433e-01);
+  const int n = (int)fn;
+  const double r = fma(-fn, K[12], fma(-fn, K[13], x));
+  const double z = r * r;
+  const double S = fma(z, fma(z, fma(z, fma(z, fma(z, K[0], K[1]), K[2]), K[3]), K[4]), K[5]);
+  const double C = fma(z, fma(z, fma(z, fma(z, fma(z, K[6], K[7]), K[8]), K[9]), K[10]), K[11]);
+  const double ps = fma(r * z, S, r);
+  const double pc = fma(z * z, C, fma(-0.5, z, 1.0));
+  switch (n & 3) {
+    case 0: *s = ps; *c = pc; break;
+    case 1: *s = pc; *c = -ps; break;
+    case 2: *s = -ps; *c = -pc; break;
+    default: *s = -pc; *c = ps; break;
+  }
+}
+// sinf/cosf spec of the build: f64 Cody-Waite reduction + fdlibm's kernel polynomials in Horner form with fused multiply-adds, rounded
+// once to f32 — bit-identical on host (x86-64: fma() is exact whether the machine has the instruction or libm emulates it) and gfx950.
+// (the quadrant's swap and signs are applied AFTER the rounding — rounding is symmetric, so (float)(-x) == -(float)x —: two selects and
+// two sign flips on f32 values instead of masked swaps of f64 pairs; this function sits on the serial chain of the position sweeps)
 MCR_HD void mcr_sincosf(float a, float* s, float* c) {
   const double* K = MCR_SINCOS_K;
   const double x = (double)a;
