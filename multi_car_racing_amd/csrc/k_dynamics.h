@@ -455,17 +455,166 @@ __device__ inline float cc_position(const CcMass& S, const uint32_t* rec, int le
   return minSep;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// The contact chain's form of the two solvers above (UNI): ONE env per wavefront (k_list_chain, role 2), so everything about a manifold —
+// which bodies touch, the constraint record — is wave-uniform, and the wavefront's idle lanes are put to use: for the contact phase of a
+// sweep the env's bodies are laid out ONE BODY PER LANE (lane car * 5 + row holds that body's three values; the car lanes transpose their
+// registers through LDS once per sweep, in and out).  A manifold's two bodies are then read with v_readlane at a SCALAR lane index — the
+// register file is the crossbar: no leader lane, no LDS round trip or barrier on the dependent chain of the contacts, no branches —, every
+// lane runs the manifold's arithmetic on the same values, and the two owner lanes keep their body's result with a select.
+// cmeta (lane i holds manifold i's): vc n [0,2) | body lane A [2,8) | body lane B [8,14) | A is a hull [14] | B is a hull [15] | island [16,20) |
+// manifold n [20,22) | type [22,24)
+__device__ __forceinline__ float rl(float v, int L) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), L)); }
+// b2ContactSolver::SolveVelocityConstraints for one manifold — the arithmetic of cc_velocity, statement for statement; (cx, cy, cw): this
+// lane's body (vx, vy, w)
+__device__ __forceinline__ void cc_velocity_bl(const CcMass& S, float* __restrict__ vcf, const int meta, const int lane, float& cx, float& cy, float& cw) {
+  const float4* __restrict__ v4 = (const float4*)vcf;
+  const float4 r0 = v4[0], r1 = v4[1], r2 = v4[2], r3 = v4[3], r4 = v4[4], r5 = v4[5], r6 = v4[6];
+  const int n = meta & 3;
+  const int ia = (meta >> 2) & 63, ib = (meta >> 8) & 63;
+  const bool hA = (meta >> 14) & 1, hB = (meta >> 15) & 1;
+  const float mA = hA ? S.mH : S.mW, iA = hA ? S.iH : S.iW, mB = hB ? S.mH : S.mW, iB = hB ? S.iH : S.iW;
+  V2 vA = v2(rl(cx, ia), rl(cy, ia)); float wA = rl(cw, ia);
+  V2 vB = v2(rl(cx, ib), rl(cy, ib)); float wB = rl(cw, ib);
+  const V2 normal = v2(r0.x, r0.y); const V2 tangent = cross(normal, 1.0f);
+  const float friction = sqrtf(0.2f * 0.2f);
+  const V2 r1A = v2(r1.y, r1.z), r1B = v2(r1.w, r2.x); float n1 = r2.y, t1 = r2.z; const float nm1 = r2.w, tm1 = r3.x;
+  const V2 r2A = v2(r3.y, r3.z), r2B = v2(r3.w, r4.x); float n2 = r4.y, t2 = r4.z; const float nm2 = r4.w, tm2 = r5.x;
+  {
+    const V2 dv = vB + cross(wB, r1B) - vA - cross(wA, r1A);
+    const float vt = dot(dv, tangent) - 0.0f;
+    float lambda = tm1 * (-vt);
+    const float maxF = friction * n1;
+    const float newImp = mcr_clamp(t1 + lambda, -maxF, maxF);
+    lambda = newImp - t1; t1 = newImp;
+    const V2 P = lambda * tangent;
+    vA = vA - mA * P; wA -= iA * cross(r1A, P);
+    vB = vB + mB * P; wB += iB * cross(r1B, P);
+  }
+  if (n == 2) {
+    const V2 dv = vB + cross(wB, r2B) - vA - cross(wA, r2A);
+    const float vt = dot(dv, tangent) - 0.0f;
+    float lambda = tm2 * (-vt);
+    const float maxF = friction * n2;
+    const float newImp = mcr_clamp(t2 + lambda, -maxF, maxF);
+    lambda = newImp - t2; t2 = newImp;
+    const V2 P = lambda * tangent;
+    vA = vA - mA * P; wA -= iA * cross(r2A, P);
+    vB = vB + mB * P; wB += iB * cross(r2B, P);
+  }
+  if (n == 1) {
+    const V2 dv = vB + cross(wB, r1B) - vA - cross(wA, r1A);
+    const float vn = dot(dv, normal);
+    float lambda = -nm1 * (vn - 0.0f);
+    const float newImp = mcr_max(n1 + lambda, 0.0f);
+    lambda = newImp - n1; n1 = newImp;
+    const V2 P = lambda * normal;
+    vA = vA - mA * P; wA -= iA * cross(r1A, P);
+    vB = vB + mB * P; wB += iB * cross(r1B, P);
+  } else {
+    const V2 a = v2(n1, n2);
+    const V2 dv1 = vB + cross(wB, r1B) - vA - cross(wA, r1A);
+    const V2 dv2 = vB + cross(wB, r2B) - vA - cross(wA, r2A);
+    float vn1 = dot(dv1, normal), vn2 = dot(dv2, normal);
+    const float k11 = r5.y, k12 = r5.z, k22 = r5.w, nm11 = r6.x, nm12 = r6.y, nm22 = r6.z;
+    V2 bb = v2(vn1 - 0.0f, vn2 - 0.0f);
+    bb = bb - v2(k11 * a.x + k12 * a.y, k12 * a.x + k22 * a.y);
+    V2 x; bool ok = false;
+    for (;;) {
+      x = -v2(nm11 * bb.x + nm12 * bb.y, nm12 * bb.x + nm22 * bb.y);
+      if (x.x >= 0.0f && x.y >= 0.0f) { ok = true; break; }
+      x.x = -nm1 * bb.x; x.y = 0.0f; vn1 = 0.0f; vn2 = k12 * x.x + bb.y;
+      if (x.x >= 0.0f && vn2 >= 0.0f) { ok = true; break; }
+      x.x = 0.0f; x.y = -nm2 * bb.y; vn1 = k12 * x.y + bb.x; vn2 = 0.0f;
+      if (x.y >= 0.0f && vn1 >= 0.0f) { ok = true; break; }
+      x.x = 0.0f; x.y = 0.0f; vn1 = bb.x; vn2 = bb.y;
+      if (vn1 >= 0.0f && vn2 >= 0.0f) { ok = true; break; }
+      break;
+    }
+    if (ok) {
+      const V2 d = x - a;
+      const V2 P1 = d.x * normal, P2 = d.y * normal;
+      vA = vA - mA * (P1 + P2); wA -= iA * (cross(r1A, P1) + cross(r2A, P2));
+      vB = vB + mB * (P1 + P2); wB += iB * (cross(r1B, P1) + cross(r2B, P2));
+      n1 = x.x; n2 = x.y;
+    }
+  }
+  vcf[cc::VC_P0 + 4] = n1; vcf[cc::VC_P0 + 5] = t1; vcf[cc::VC_P1 + 4] = n2; vcf[cc::VC_P1 + 5] = t2;      // (every lane, the same values)
+  const bool isA = lane == ia, isB = lane == ib;
+  cx = isA ? vA.x : (isB ? vB.x : cx); cy = isA ? vA.y : (isB ? vB.y : cy); cw = isA ? wA : (isB ? wB : cw);
+}
+
+// b2ContactSolver::SolvePositionConstraints for one manifold (rec: the step's LDS copy of the stored record); returns its min separation.
+// (px, py, pa): this lane's body (c.x, c.y, angle).  Every body lane evaluates the rotation of ITS OWN angle: one f64 sincos on the chain per
+// point instead of two, read out of the two owner lanes.
+__device__ __forceinline__ float cc_position_bl(const CcMass& S, const uint32_t* __restrict__ rec, const int meta, const int lane, float& px, float& py, float& pa) {
+  const uint4* __restrict__ q4 = (const uint4*)rec;
+  const uint4 w0 = q4[0], w1 = q4[1], w2 = q4[2], w3 = q4[3];
+  const int ia = (meta >> 2) & 63, ib = (meta >> 8) & 63;
+  const bool hA = (meta >> 14) & 1, hB = (meta >> 15) & 1;
+  const int n = (meta >> 20) & 3, type = (meta >> 22) & 3;
+  const float mA = hA ? S.mH : S.mW, iA = hA ? S.iH : S.iW, mB = hB ? S.mH : S.mW, iB = hB ? S.iH : S.iW;
+  const V2 lcA = hA ? v2(S.lcx, S.lcy) : v2(0.0f, 0.0f), lcB = hB ? v2(S.lcx, S.lcy) : v2(0.0f, 0.0f);
+  V2 cA = v2(rl(px, ia), rl(py, ia)); float aA = rl(pa, ia);
+  V2 cB = v2(rl(px, ib), rl(py, ib)); float aB = rl(pa, ib);
+  (void)w0.x; (void)w0.y;
+  const V2 localNormal = v2(__uint_as_float(w0.z), __uint_as_float(w0.w)), localPoint = v2(__uint_as_float(w1.x), __uint_as_float(w1.y));
+  const V2 lp0 = v2(__uint_as_float(w1.z), __uint_as_float(w1.w)), lp1 = v2(__uint_as_float(w2.w), __uint_as_float(w3.x));   // words 6,7 and 11,12
+  const bool isA = lane == ia, isB = lane == ib;
+  float minSep = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if (j < n) {
+      const Rot qm = rot_of(isA ? aA : (isB ? aB : pa));
+      Xf xfA, xfB;
+      xfA.q.s = rl(qm.s, ia); xfA.q.c = rl(qm.c, ia); xfB.q.s = rl(qm.s, ib); xfB.q.c = rl(qm.c, ib);
+      xfA.p = cA - rmul(xfA.q, lcA); xfB.p = cB - rmul(xfB.q, lcB);
+      const V2 lp = j == 0 ? lp0 : lp1;
+      V2 normal, point; float separation;
+      if (type == 1) {
+        normal = rmul(xfA.q, localNormal);
+        const V2 planePoint = xmul(xfA, localPoint);
+        const V2 clip = xmul(xfB, lp);
+        separation = dot(clip - planePoint, normal) - B2_POLYGON_RADIUS - B2_POLYGON_RADIUS;
+        point = clip;
+      } else {
+        normal = rmul(xfB.q, localNormal);
+        const V2 planePoint = xmul(xfB, localPoint);
+        const V2 clip = xmul(xfA, lp);
+        separation = dot(clip - planePoint, normal) - B2_POLYGON_RADIUS - B2_POLYGON_RADIUS;
+        point = clip;
+        normal = -normal;
+      }
+      const V2 rA = point - cA, rB = point - cB;
+      minSep = mcr_min(minSep, separation);
+      const float C = mcr_clamp(B2_BAUMGARTE * (separation + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
+      const float rnA = cross(rA, normal), rnB = cross(rB, normal);
+      const float K = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+      const float impulse = K > 0.0f ? -C / K : 0.0f;
+      const V2 P = impulse * normal;
+      cA = cA - mA * P; aA -= iA * cross(rA, P);
+      cB = cB + mB * P; aB += iB * cross(rB, P);
+    }
+  }
+  px = isA ? cA.x : (isB ? cB.x : px); py = isA ? cA.y : (isB ? cB.y : py); pa = isA ? aA : (isB ? aB : pa);
+  return minSep;
+}
+
 }  // namespace dyn
 
 // mode 0: regular step (bookkeeping, TimeLimit, auto-reset install)
 // mode 1: the action-less step of reset() (:408) for envs whose `resetting` flag is set
 // debug bit 8 (256): lane 0 of every wavefront stamps the clock per phase (0 start, 1 state loaded + Car.step +
 // velocity integration, 2 velocity sweeps done, 3 position loop done, 4 end) into p.dbg_stamps[block][8] (main launch, then the launches of roles 2, 3, 4)
+#define UNI_I(x) __builtin_amdgcn_readfirstlane(x)
 #define DYN_STAMP(i) do { if ((p.debug & 256) && mode == 0 && threadIdx.x == 0) p.dbg_stamps[((p.role >= 2 ? (p.B * p.G + 63) / 64 + (p.role - 2) * ((p.B + 1) / 2) : 0) + blk) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 // CC = false: a launch that cannot hold an env with touching car<->car contacts (the main launch of the three-chain step; contacts off;
 // N = 1) — none of the contact code is compiled in, and the contact-free loops keep the registers and the schedule they get alone
-template <bool CC>
+// UNI (with CC): the launch holds ONE env per wavefront (the contact chain, role 2): the contact sweeps run in the uniform form above
+template <bool CC, bool UNI = false>
 __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mode, const int blk) {
+  static_assert(CC || !UNI, "the uniform contact sweeps are part of the contact build");
   using namespace dyn;
   DYN_STAMP(0);
   // LDS used only by waves that contain a touching car<->car pair
@@ -624,6 +773,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
   DYN_STAMP(1);
   int pool_base = 0;
   int isl = agent;                        // island id of this car = lowest car id linked to it by touching contacts
+  int cmeta = 0;                          // UNI: lane i holds the description of manifold i
   if (wave_cc) {
     // LDS pool of velocity-constraint records: exclusive prefix sum of the leaders' needs across the wave
     int need = (agent == 0) ? ccn : 0;
@@ -705,6 +855,18 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
 #pragma unroll
       for (int k = 0; k < 5; ++k) { b[k].vx = xv[0 * 5 + k][lane]; b[k].vy = xv[1 * 5 + k][lane]; b[k].w = xv[2 * 5 + k][lane]; }
     }
+    if constexpr (UNI) {
+      // lane i keeps the description of manifold i (cmeta, see cc_velocity_bl); body lane of (car c, exchange row r) = 5 c + r
+      // (the env's cars sit in lanes 0 .. N - 1, its leader is lane 0 and its pool starts at 0: the lanes beyond the env hold manifolds too)
+      if (lane < UNI_I(ccn)) {
+        const float* vc = vcpool[lane];
+        const int sa = ((const int*)vc)[cc::VC_LA], sb = ((const int*)vc)[cc::VC_LB];
+        const uint32_t* rec = pcrec[lane];
+        const int ra = sa & 7, rb = sb & 7;
+        cmeta = ((const int*)vc)[cc::VC_N] | (((sa >> 3) * 5 + ra) << 2) | (((sb >> 3) * 5 + rb) << 8) | ((ra == 0 ? 1 : 0) << 14) | ((rb == 0 ? 1 : 0) << 15) |
+                (xisl[(int)(rec[0] & 15u)] << 16) | ((int)((rec[1] >> 8) & 3u) << 20) | ((int)(rec[1] & 3u) << 22);
+      }
+    }
     if (run && !resume) {
       // joints, slot order 3,2,1,0 = the car's island order
 #pragma unroll
@@ -780,6 +942,32 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
 #define VP_MARK(i) do {} while (0)
 #define VP_BEGIN() do {} while (0)
 #endif
+    if constexpr (UNI) {
+      const int ccnu = UNI_I(ccn);
+      float* const xt = &xv[0][0];                        // the transposition buffer: xt[comp * 64 + body lane]
+      for (int it = 0; it < vel_iters; ++it) {
+        VP_BEGIN();
+        if (run) {
+#pragma unroll
+          for (int q = 3; q >= 0; --q) joint_velocity(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);
+        }
+        VP_MARK(0);
+        if (run) {
+#pragma unroll
+          for (int k = 0; k < 5; ++k) { xt[0 * 64 + agent * 5 + k] = b[k].vx; xt[1 * 64 + agent * 5 + k] = b[k].vy; xt[2 * 64 + agent * 5 + k] = b[k].w; }
+        }
+        float cx = xt[0 * 64 + lane], cy = xt[1 * 64 + lane], cw = xt[2 * 64 + lane];
+        VP_MARK(1);
+        for (int i = 0; i < ccnu; ++i) cc_velocity_bl(CM, vcpool[i], __builtin_amdgcn_readlane(cmeta, i), lane, cx, cy, cw);
+        VP_MARK(2);
+        xt[0 * 64 + lane] = cx; xt[1 * 64 + lane] = cy; xt[2 * 64 + lane] = cw;
+        if (run) {
+#pragma unroll
+          for (int k = 0; k < 5; ++k) { b[k].vx = xt[0 * 64 + agent * 5 + k]; b[k].vy = xt[1 * 64 + agent * 5 + k]; b[k].w = xt[2 * 64 + agent * 5 + k]; }
+        }
+        VP_MARK(3);
+      }
+    } else
     for (int it = 0; it < vel_iters; ++it) {
       VP_BEGIN();
       if (run) {
@@ -905,6 +1093,64 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
 #define PP_MARK(i) do {} while (0)
 #define PP_BEGIN() do {} while (0)
 #endif
+    if constexpr (UNI) {
+      // the uniform form: contacts (every lane, on the owners' registers), then the joints, island verdicts by ballots — no LDS traffic but
+      // the constants of the manifolds
+      const int ccnu = UNI_I(ccn);
+      float* const xt = &xp[0][0];                        // the transposition buffer: xt[comp * 64 + body lane]
+      for (int it = 0; it < pos_iters_cc; ++it) {
+        const unsigned long long actm = __ballot(active);
+        if (!actm) break;
+        PP_BEGIN();
+        float ox[5], oy[5], oa[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { ox[k] = b[k].cx; oy[k] = b[k].cy; oa[k] = b[k].a; }
+        PP_MARK(0);
+        float myMin = 0.0f;                               // min separation over the contacts of this car's island
+        {
+          if (run) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { xt[0 * 64 + agent * 5 + k] = b[k].cx; xt[1 * 64 + agent * 5 + k] = b[k].cy; xt[2 * 64 + agent * 5 + k] = b[k].a; }
+          }
+          float px = xt[0 * 64 + lane], py = xt[1 * 64 + lane], pa = xt[2 * 64 + lane];
+          for (int i = 0; i < ccnu; ++i) {
+            const int meta = __builtin_amdgcn_readlane(cmeta, i);
+            const int r = (meta >> 16) & 15;
+            if (!((actm >> r) & 1ull)) continue;
+            const float ms = cc_position_bl(CM, pcrec[i], meta, lane, px, py, pa);
+            myMin = (isl == r) ? mcr_min(myMin, ms) : myMin;
+          }
+          xt[0 * 64 + lane] = px; xt[1 * 64 + lane] = py; xt[2 * 64 + lane] = pa;
+          if (active) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { b[k].cx = xt[0 * 64 + agent * 5 + k]; b[k].cy = xt[1 * 64 + agent * 5 + k]; b[k].a = xt[2 * 64 + agent * 5 + k]; }
+          }
+        }
+        PP_MARK(1);
+        bool jointsOk = true;
+        if (active) {
+#pragma unroll
+          for (int q = 3; q >= 0; --q) {
+            float ax = S.anchor_x[q], ay = S.anchor_y[q];
+            if (wave_perm) { ax = pick4(wq[q], S.anchor_x[0], S.anchor_x[1], S.anchor_x[2], S.anchor_x[3]); ay = pick4(wq[q], S.anchor_y[0], S.anchor_y[1], S.anchor_y[2], S.anchor_y[3]); }
+            bool jo = joint_position(J[q], b[0], b[q + 1], ax, ay, lcx, lcy, mH, iH, mW, iW, hull_rot);
+            jointsOk = jointsOk && jo;
+          }
+        }
+        PP_MARK(2);
+        bool moved = false;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) moved = moved || ox[k] != b[k].cx || oy[k] != b[k].cy || oa[k] != b[k].a;
+        const unsigned long long okm = __ballot(jointsOk), mvm = __ballot(moved);
+        if (active) {
+          bool ok = jointsOk, mv = moved;
+          if (ccn > 0) { ok = myMin >= -3.0f * B2_LINEAR_SLOP && (okm & imask) == imask; mv = (mvm & imask) != 0ull; }
+          if (ok) { positionSolved = true; active = false; }
+          else if (!mv) active = false;
+        }
+        PP_MARK(3);
+      }
+    } else {
     for (int it = 0; it < pos_iters_cc; ++it) {
       const unsigned long long actm = __ballot(active);
       if (!actm) break;
@@ -972,6 +1218,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
       __syncthreads();
       PP_MARK(3);
     }
+    }   // !UNI
 #ifdef MCR_POSLOOP_PROFILE
     if ((p.debug & 256) && !(p.debug & 65536) && mode == 0 && threadIdx.x == 0 && p.role == 2) {
       unsigned long long* o = p.dbg_stamps + ((size_t)((p.B * p.G + 63) / 64) + blk) * 8;

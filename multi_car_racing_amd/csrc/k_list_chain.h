@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64) void k_list_chain(McrParams pa, McrParams pb, c
     const McrParams& p = pa;
     const int nb = mcr_virtual_blocks(p, p.list_envs_per_block);
     for (int blk = blockIdx.x; blk < nb; blk += ga) {
-      dynamics_block<CC>(p, 0, blk);
+      dynamics_block<CC, CC>(p, 0, blk);                          // (CC: the contact chain, one env per wavefront — the uniform contact sweeps)
       __syncthreads();
       if (p.auto_reset) list_reset_pass(p, blk);
       if (with_flags) {

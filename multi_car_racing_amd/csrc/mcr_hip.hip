@@ -360,6 +360,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   const int dyn_blocks = (B * P.G + 63) / 64;
   // list launches (contact / deferred / re-spawned envs): small grids whose workgroups walk the device-side lists
   const int lg_col = std::min(B, MCR_LIST_GRID), lg_dyn = std::min((B + MCR_SIDE_ENVS_PER_WAVE - 1) / MCR_SIDE_ENVS_PER_WAVE, h->chain_grid);
+  const int lg_con = std::min(B, 2 * h->chain_grid);             // the contact chain: one env per wavefront
   const bool draw = P.obs != nullptr;
   // (the raster workgroups reset the raster order entries they consume; a step that filled the list of its parity without
   // drawing — mcr_step without an observation buffer on a handle that has one — left it unconsumed: wipe it before its next use)
@@ -431,7 +432,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     if (cc) LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), h->s_side, P, 0);     // (W_COL: posted by the chain that follows)
     P.split = 0;
     P.role = 2;
-    LAUNCH_LDS(5, k_list_chain<true>, lg_dyn, 64, col::lds_bytes(N), h->s_side, P, P, 0, lg_dyn);
+    { McrParams Pc = P; Pc.list_envs_per_block = 1; LAUNCH_LDS(5, k_list_chain<true>, lg_con, 64, col::lds_bytes(N), h->s_side, Pc, Pc, 0, lg_con); }   // ONE contact env per wavefront: the uniform contact sweeps (k_dynamics.h)
     // (the chains' bookkeeping: workgroups of its own inside the chain's raster launch when there is one, a list launch otherwise)
     // (beyond four cars per env the lists hold thousands of cars — ~315 contact envs x 8 at N = 8 — and a few 256-thread workgroups
     // would take them in many rounds at the end of the contact chain, the critical path there; measured N = 2 15.37 -> 15.65 M
@@ -486,7 +487,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   const bool flags_list = view_flags && !fuse_flags;
   P.role = 2;
   // (the side stream's last kernel completes ev_join; which one that is depends on the step's shape)
-  LAUNCH_LDS_STOP(5, k_list_chain<true>, lg_dyn, 64, col::lds_bytes(N), h->s_side, STOP((!draw && !flags_list) ? h->ev_join : nullptr), P, P, fuse_flags, lg_dyn);
+  { McrParams Pc = P; Pc.list_envs_per_block = 1; LAUNCH_LDS_STOP(5, k_list_chain<true>, lg_con, 64, col::lds_bytes(N), h->s_side, STOP((!draw && !flags_list) ? h->ev_join : nullptr), Pc, Pc, fuse_flags, lg_con); }
   if (flags_list) hipExtLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, h->s_side, nullptr, STOP(!draw ? h->ev_join : nullptr), 0, P);
   if (draw) launch_view(h, 6, B, h->s_side, P, 0, STOP(h->ev_join));
   P.role = 1;
