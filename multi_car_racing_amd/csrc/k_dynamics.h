@@ -18,6 +18,7 @@
 #pragma once
 #include "mcr_kernels.h"
 #include "k_carcontacts.h"
+#include <type_traits>
 
 namespace dyn {
 
@@ -466,21 +467,31 @@ __device__ inline float cc_position(const CcMass& S, const uint32_t* rec, int le
 // cmeta (lane i holds manifold i's): vc n [0,2) | body lane A [2,8) | body lane B [8,14) | A is a hull [14] | B is a hull [15] | island [16,20) |
 // manifold n [20,22) | type [22,24)
 __device__ __forceinline__ float rl(float v, int L) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), L)); }
-// b2ContactSolver::SolveVelocityConstraints for one manifold — the arithmetic of cc_velocity, statement for statement; (cx, cy, cw): this
-// lane's body (vx, vy, w)
-__device__ __forceinline__ void cc_velocity_bl(const CcMass& S, float* __restrict__ vcf, const int meta, const int lane, float& cx, float& cy, float& cw) {
+// b2ContactSolver::SolveVelocityConstraints for manifold i — the arithmetic of cc_velocity, statement for statement.  (cx, cy, cw): this
+// lane's body (vx, vy, w).  R: the step's constants of the constraint (the LDS record is never written during the sweeps: the caller loads
+// it a manifold ahead); imp: lane i holds the accumulated impulses of manifold i.  Every lane holds the same values, so the solver's
+// case analysis branches on the scalar unit (ANYL: "some lane", which is "every lane").
+struct VcRec { float4 r0, r1, r2, r3, r4, r5, r6; };
+struct CcImp { float n1, t1, n2, t2; };
+__device__ __forceinline__ VcRec vc_load(const float* __restrict__ vcf) {
   const float4* __restrict__ v4 = (const float4*)vcf;
-  const float4 r0 = v4[0], r1 = v4[1], r2 = v4[2], r3 = v4[3], r4 = v4[4], r5 = v4[5], r6 = v4[6];
+  VcRec R; R.r0 = v4[0]; R.r1 = v4[1]; R.r2 = v4[2]; R.r3 = v4[3]; R.r4 = v4[4]; R.r5 = v4[5]; R.r6 = v4[6];
+  return R;
+}
+#define ANYL(c) (__ballot(c) != 0ull)
+__device__ __forceinline__ void cc_velocity_bl(const CcMass& S, const VcRec& R, const int meta, CcImp& imp, const int i, const int lane, float& cx, float& cy, float& cw) {
+  const float4 r0 = R.r0, r1 = R.r1, r2 = R.r2, r3 = R.r3, r4 = R.r4, r5 = R.r5, r6 = R.r6;
   const int n = meta & 3;
   const int ia = (meta >> 2) & 63, ib = (meta >> 8) & 63;
   const bool hA = (meta >> 14) & 1, hB = (meta >> 15) & 1;
   const float mA = hA ? S.mH : S.mW, iA = hA ? S.iH : S.iW, mB = hB ? S.mH : S.mW, iB = hB ? S.iH : S.iW;
   V2 vA = v2(rl(cx, ia), rl(cy, ia)); float wA = rl(cw, ia);
   V2 vB = v2(rl(cx, ib), rl(cy, ib)); float wB = rl(cw, ib);
+  float n1 = rl(imp.n1, i), t1 = rl(imp.t1, i), n2 = rl(imp.n2, i), t2 = rl(imp.t2, i);
   const V2 normal = v2(r0.x, r0.y); const V2 tangent = cross(normal, 1.0f);
   const float friction = sqrtf(0.2f * 0.2f);
-  const V2 r1A = v2(r1.y, r1.z), r1B = v2(r1.w, r2.x); float n1 = r2.y, t1 = r2.z; const float nm1 = r2.w, tm1 = r3.x;
-  const V2 r2A = v2(r3.y, r3.z), r2B = v2(r3.w, r4.x); float n2 = r4.y, t2 = r4.z; const float nm2 = r4.w, tm2 = r5.x;
+  const V2 r1A = v2(r1.y, r1.z), r1B = v2(r1.w, r2.x); const float nm1 = r2.w, tm1 = r3.x;
+  const V2 r2A = v2(r3.y, r3.z), r2B = v2(r3.w, r4.x); const float nm2 = r4.w, tm2 = r5.x;
   {
     const V2 dv = vB + cross(wB, r1B) - vA - cross(wA, r1A);
     const float vt = dot(dv, tangent) - 0.0f;
@@ -523,13 +534,13 @@ __device__ __forceinline__ void cc_velocity_bl(const CcMass& S, float* __restric
     V2 x; bool ok = false;
     for (;;) {
       x = -v2(nm11 * bb.x + nm12 * bb.y, nm12 * bb.x + nm22 * bb.y);
-      if (x.x >= 0.0f && x.y >= 0.0f) { ok = true; break; }
+      if (ANYL(x.x >= 0.0f && x.y >= 0.0f)) { ok = true; break; }
       x.x = -nm1 * bb.x; x.y = 0.0f; vn1 = 0.0f; vn2 = k12 * x.x + bb.y;
-      if (x.x >= 0.0f && vn2 >= 0.0f) { ok = true; break; }
+      if (ANYL(x.x >= 0.0f && vn2 >= 0.0f)) { ok = true; break; }
       x.x = 0.0f; x.y = -nm2 * bb.y; vn1 = k12 * x.y + bb.x; vn2 = 0.0f;
-      if (x.y >= 0.0f && vn1 >= 0.0f) { ok = true; break; }
+      if (ANYL(x.y >= 0.0f && vn1 >= 0.0f)) { ok = true; break; }
       x.x = 0.0f; x.y = 0.0f; vn1 = bb.x; vn2 = bb.y;
-      if (vn1 >= 0.0f && vn2 >= 0.0f) { ok = true; break; }
+      if (ANYL(vn1 >= 0.0f && vn2 >= 0.0f)) { ok = true; break; }
       break;
     }
     if (ok) {
@@ -540,7 +551,8 @@ __device__ __forceinline__ void cc_velocity_bl(const CcMass& S, float* __restric
       n1 = x.x; n2 = x.y;
     }
   }
-  vcf[cc::VC_P0 + 4] = n1; vcf[cc::VC_P0 + 5] = t1; vcf[cc::VC_P1 + 4] = n2; vcf[cc::VC_P1 + 5] = t2;      // (every lane, the same values)
+  const bool own = lane == i;
+  imp.n1 = own ? n1 : imp.n1; imp.t1 = own ? t1 : imp.t1; imp.n2 = own ? n2 : imp.n2; imp.t2 = own ? t2 : imp.t2;
   const bool isA = lane == ia, isB = lane == ib;
   cx = isA ? vA.x : (isB ? vB.x : cx); cy = isA ? vA.y : (isB ? vB.y : cy); cw = isA ? wA : (isB ? wB : cw);
 }
@@ -618,7 +630,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
   using namespace dyn;
   DYN_STAMP(0);
   // LDS used only by waves that contain a touching car<->car pair
-  __shared__ float xv[15][64], xp[15][64];            // body exchange: (vx,vy,w) / (cx,cy,a) x 5 bodies per lane
+  __shared__ __attribute__((aligned(16))) float xv[15][64], xp[15][64];            // body exchange: (vx,vy,w) / (cx,cy,a) x 5 bodies per lane
   __shared__ __attribute__((aligned(16))) float vcpool[DYN_VC_POOL][cc::VC_SIZE];
   __shared__ uint32_t pcrec[DYN_VC_POOL][16];      // manifold records (key, type|n, local normal/point, 2 points) for the position sweeps
   __shared__ int xisl[64], xjok[64];
@@ -773,7 +785,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
   DYN_STAMP(1);
   int pool_base = 0;
   int isl = agent;                        // island id of this car = lowest car id linked to it by touching contacts
-  int cmeta = 0;                          // UNI: lane i holds the description of manifold i
+  int cmeta = 0; CcImp cimp; cimp.n1 = cimp.t1 = cimp.n2 = cimp.t2 = 0.0f;   // UNI: lane i holds the description and the accumulated impulses of manifold i
   if (wave_cc) {
     // LDS pool of velocity-constraint records: exclusive prefix sum of the leaders' needs across the wave
     int need = (agent == 0) ? ccn : 0;
@@ -865,6 +877,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
         const int ra = sa & 7, rb = sb & 7;
         cmeta = ((const int*)vc)[cc::VC_N] | (((sa >> 3) * 5 + ra) << 2) | (((sb >> 3) * 5 + rb) << 8) | ((ra == 0 ? 1 : 0) << 14) | ((rb == 0 ? 1 : 0) << 15) |
                 (xisl[(int)(rec[0] & 15u)] << 16) | ((int)((rec[1] >> 8) & 3u) << 20) | ((int)(rec[1] & 3u) << 22);
+        cimp.n1 = vc[cc::VC_P0 + 4]; cimp.t1 = vc[cc::VC_P0 + 5]; cimp.n2 = vc[cc::VC_P1 + 4]; cimp.t2 = vc[cc::VC_P1 + 5];
       }
     }
     if (run && !resume) {
@@ -944,29 +957,46 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
 #endif
     if constexpr (UNI) {
       const int ccnu = UNI_I(ccn);
-      float* const xt = &xv[0][0];                        // the transposition buffer: xt[comp * 64 + body lane]
-      for (int it = 0; it < vel_iters; ++it) {
-        VP_BEGIN();
-        if (run) {
+      float4* const xt = (float4*)&xv[0][0];              // the transposition buffer: xt[body lane] = (vx, vy, w, -)
+      // (a car's joints reach their limits at full steering lock or in a crash: the env none of whose joints is at one — the state is a constant
+      // of the step — runs its sweeps with the limit-free form of all four, chosen ONCE: no branch inside the loop)
+      auto sweeps = [&](auto lim_tag) {
+        constexpr bool LIM = decltype(lim_tag)::value;
+        VcRec cur = vc_load(vcpool[0]);
+        for (int it = 0; it < vel_iters; ++it) {
+          VP_BEGIN();
+          if (run) {
 #pragma unroll
-          for (int q = 3; q >= 0; --q) joint_velocity(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);
-        }
-        VP_MARK(0);
-        if (run) {
+            for (int q = 3; q >= 0; --q) joint_velocity<LIM>(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);
+          }
+          VP_MARK(0);
+          if (run) {
 #pragma unroll
-          for (int k = 0; k < 5; ++k) { xt[0 * 64 + agent * 5 + k] = b[k].vx; xt[1 * 64 + agent * 5 + k] = b[k].vy; xt[2 * 64 + agent * 5 + k] = b[k].w; }
-        }
-        float cx = xt[0 * 64 + lane], cy = xt[1 * 64 + lane], cw = xt[2 * 64 + lane];
-        VP_MARK(1);
-        for (int i = 0; i < ccnu; ++i) cc_velocity_bl(CM, vcpool[i], __builtin_amdgcn_readlane(cmeta, i), lane, cx, cy, cw);
-        VP_MARK(2);
-        xt[0 * 64 + lane] = cx; xt[1 * 64 + lane] = cy; xt[2 * 64 + lane] = cw;
-        if (run) {
+            for (int k = 0; k < 5; ++k) xt[agent * 5 + k] = make_float4(b[k].vx, b[k].vy, b[k].w, 0.0f);
+          }
+          const float4 c4 = xt[lane];
+          float cx = c4.x, cy = c4.y, cw = c4.z;
+          VP_MARK(1);
+          for (int i = 0; i < ccnu; ++i) {
+            VcRec nxt = cur;
+            if (ccnu > 1) nxt = vc_load(vcpool[i + 1 == ccnu ? 0 : i + 1]);     // the next manifold's constants, a manifold ahead of their use
+            cc_velocity_bl(CM, cur, __builtin_amdgcn_readlane(cmeta, i), cimp, i, lane, cx, cy, cw);
+            cur = nxt;
+          }
+          VP_MARK(2);
+          xt[lane] = make_float4(cx, cy, cw, 0.0f);
+          if (run) {
 #pragma unroll
-          for (int k = 0; k < 5; ++k) { b[k].vx = xt[0 * 64 + agent * 5 + k]; b[k].vy = xt[1 * 64 + agent * 5 + k]; b[k].w = xt[2 * 64 + agent * 5 + k]; }
+            for (int k = 0; k < 5; ++k) { const float4 v = xt[agent * 5 + k]; b[k].vx = v.x; b[k].vy = v.y; b[k].w = v.z; }
+          }
+          VP_MARK(3);
         }
-        VP_MARK(3);
-      }
+      };
+      bool any_limit = false;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) any_limit = any_limit || J[q].limit != 0;
+      if (__any(any_limit)) sweeps(std::true_type{}); else sweeps(std::false_type{});
+      if (lane < ccnu) { float* vc = vcpool[lane]; vc[cc::VC_P0 + 4] = cimp.n1; vc[cc::VC_P0 + 5] = cimp.t1; vc[cc::VC_P1 + 4] = cimp.n2; vc[cc::VC_P1 + 5] = cimp.t2; }   // for StoreImpulses
     } else
     for (int it = 0; it < vel_iters; ++it) {
       VP_BEGIN();
@@ -1097,7 +1127,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
       // the uniform form: contacts (every lane, on the owners' registers), then the joints, island verdicts by ballots — no LDS traffic but
       // the constants of the manifolds
       const int ccnu = UNI_I(ccn);
-      float* const xt = &xp[0][0];                        // the transposition buffer: xt[comp * 64 + body lane]
+      float4* const xt = (float4*)&xp[0][0];              // the transposition buffer: xt[body lane] = (c.x, c.y, angle, -)
       for (int it = 0; it < pos_iters_cc; ++it) {
         const unsigned long long actm = __ballot(active);
         if (!actm) break;
@@ -1110,9 +1140,10 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
         {
           if (run) {
 #pragma unroll
-            for (int k = 0; k < 5; ++k) { xt[0 * 64 + agent * 5 + k] = b[k].cx; xt[1 * 64 + agent * 5 + k] = b[k].cy; xt[2 * 64 + agent * 5 + k] = b[k].a; }
+            for (int k = 0; k < 5; ++k) xt[agent * 5 + k] = make_float4(b[k].cx, b[k].cy, b[k].a, 0.0f);
           }
-          float px = xt[0 * 64 + lane], py = xt[1 * 64 + lane], pa = xt[2 * 64 + lane];
+          const float4 p4 = xt[lane];
+          float px = p4.x, py = p4.y, pa = p4.z;
           for (int i = 0; i < ccnu; ++i) {
             const int meta = __builtin_amdgcn_readlane(cmeta, i);
             const int r = (meta >> 16) & 15;
@@ -1120,10 +1151,10 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
             const float ms = cc_position_bl(CM, pcrec[i], meta, lane, px, py, pa);
             myMin = (isl == r) ? mcr_min(myMin, ms) : myMin;
           }
-          xt[0 * 64 + lane] = px; xt[1 * 64 + lane] = py; xt[2 * 64 + lane] = pa;
+          xt[lane] = make_float4(px, py, pa, 0.0f);
           if (active) {
 #pragma unroll
-            for (int k = 0; k < 5; ++k) { b[k].cx = xt[0 * 64 + agent * 5 + k]; b[k].cy = xt[1 * 64 + agent * 5 + k]; b[k].a = xt[2 * 64 + agent * 5 + k]; }
+            for (int k = 0; k < 5; ++k) { const float4 v = xt[agent * 5 + k]; b[k].cx = v.x; b[k].cy = v.y; b[k].a = v.z; }
           }
         }
         PP_MARK(1);

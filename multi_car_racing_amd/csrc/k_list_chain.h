@@ -31,6 +31,7 @@ __global__ __launch_bounds__(64) void k_list_chain(McrParams pa, McrParams pb, c
   __builtin_amdgcn_s_setprio(3);
   // soft_sync (mcr_kernels.h): the contact chain follows the contact pass in its stream — its start IS the contact pass's completion
   if (pa.soft_sync && pa.role == 2 && pa.cc_mode && blockIdx.x == 0 && threadIdx.x == 0) mcr_post(pa, W_COL);
+  if (pa.role == 2 && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&pa.host_counts[HC_CONTACT_ENVS], (uint32_t)pa.clist[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (the contact pass is complete: the list is)
   if (pa.soft_sync && pa.role == 3) {
     // the resume chain follows the main dynamics in its stream: its start IS the dynamics' completion (the third stream's kernels wait for
     // that); and its envs read what the contact pass left for them (a deferred env never got to the main dynamics' in-kernel wait)

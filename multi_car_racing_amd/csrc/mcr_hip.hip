@@ -193,10 +193,10 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   (void)hipHostGetDevicePointer(&dptr, h->consumed_host, 0);
   P.consumed_host = (int32_t*)dptr;
   h->consumed_seen = new int32_t[B]();
-  if (hipHostMalloc((void**)&h->status_host, sizeof(uint32_t) * MCR_STATUS_WORDS, hipHostMallocMapped) != hipSuccess) { g_err = "hipHostMalloc failed"; (void)hipHostFree(h->consumed_host); delete[] h->consumed_seen; (void)hipFree(h->slab); delete h; return MCR_ERR_HIP; }
-  memset(h->status_host, 0, sizeof(uint32_t) * MCR_STATUS_WORDS);
+  if (hipHostMalloc((void**)&h->status_host, sizeof(uint32_t) * (MCR_STATUS_WORDS + MCR_HOST_COUNTS), hipHostMallocMapped) != hipSuccess) { g_err = "hipHostMalloc failed"; (void)hipHostFree(h->consumed_host); delete[] h->consumed_seen; (void)hipFree(h->slab); delete h; return MCR_ERR_HIP; }
+  memset(h->status_host, 0, sizeof(uint32_t) * (MCR_STATUS_WORDS + MCR_HOST_COUNTS));
   (void)hipHostGetDevicePointer(&dptr, h->status_host, 0);
-  P.status = (uint32_t*)dptr;
+  P.status = (uint32_t*)dptr; P.host_counts = P.status + MCR_STATUS_WORDS;
   // Contact side stream.  k_dynamics is a serial dependency chain whose duration is set by its slowest wavefront,
   // and a wavefront holding a touching car<->car pair takes 2-3x as long as the others (sequential Gauss-Seidel
   // over the contacts).  With num_streams == 2 those envs (a handful per step) run dynamics -> reset pass ->
@@ -323,12 +323,12 @@ void mcr_view_launch(int variant, int grid, hipStream_t st, const McrParams& P, 
 // persistent workgroups that walk the list (lane k of a wavefront holds a workgroup's k-th env, so never fewer than
 // slots / 64 workgroups).
 static int list_grid(int slots, int want) { return std::min(slots, std::max(want, (slots + 63) / 64)); }
-static void launch_view(mcr_env* h, int kid, int slots, hipStream_t st, const McrParams& P, int only_just_reset, hipEvent_t stop = nullptr) {
+static void launch_view(mcr_env* h, int kid, int slots, hipStream_t st, const McrParams& P, int only_just_reset, hipEvent_t stop = nullptr, int want_grid = 0) {
   TimedLaunch tl; const bool tm = (h->timing >> kid) & 1;
   if (tm) { tl.id = kid; tl.a = get_event(h); tl.b = get_event(h); (void)hipEventRecord(tl.a, st); }
   // (list launches: with more than two cars per env the contact list is long — N = 8: ~340 envs x 8 views per step — and 128
   // workgroups would draw ~20 views each, one after the other, at the end of the side stream's chain)
-  if (P.role >= 2) { McrParams Q = P; Q.split_views = 1; mcr_view_launch(2, list_grid(slots * (Q.split_views ? P.N : 1), h->list_view_grid) + Q.flags_blocks, st, Q, h->view_stamps, only_just_reset, stop); }
+  if (P.role >= 2) { McrParams Q = P; Q.split_views = 1; mcr_view_launch(2, list_grid(slots * (Q.split_views ? P.N : 1), std::max(h->list_view_grid, want_grid)) + Q.flags_blocks, st, Q, h->view_stamps, only_just_reset, stop); }
   else mcr_view_launch((P.debug & 32) ? 1 : 0, slots, st, P, h->view_stamps, only_just_reset, stop);
   if (tm) { (void)hipEventRecord(tl.b, st); h->pending.push_back(tl); }
 }
@@ -361,6 +361,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   // list launches (contact / deferred / re-spawned envs): small grids whose workgroups walk the device-side lists
   const int lg_col = std::min(B, MCR_LIST_GRID), lg_dyn = std::min((B + MCR_SIDE_ENVS_PER_WAVE - 1) / MCR_SIDE_ENVS_PER_WAVE, h->chain_grid);
   const int lg_con = std::min(B, 2 * h->chain_grid);             // the contact chain: one env per wavefront
+  const int prev_contacts = std::min(B, (int)((volatile uint32_t*)h->status_host)[MCR_STATUS_WORDS + HC_CONTACT_ENVS]);   // (mapped host word: no synchronisation)
   const bool draw = P.obs != nullptr;
   // (the raster workgroups reset the raster order entries they consume; a step that filled the list of its parity without
   // drawing — mcr_step without an observation buffer on a handle that has one — left it unconsumed: wipe it before its next use)
@@ -438,12 +439,16 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     // would take them in many rounds at the end of the contact chain, the critical path there; measured N = 2 15.37 -> 15.65 M
     // env-steps/s, N = 4 11.00 -> 11.07, N = 8 5.47 -> 5.44)
     const int fiv = (view_flags && draw && N <= 4) ? (N <= 2 ? 8 : 64) : 0;
+    // (the contact list's raster and bookkeeping workgroups: sized by the LAST step's list — the lists change slowly — so that a long list,
+    // a policy that drives: ~90 envs of 4096, takes one round of workgroups instead of two or three behind the chain, the step's critical path)
+    const int fiv_c = fiv ? std::min(256, std::max(fiv, (prev_contacts * (N + 1) + 3) / 4 + 2)) : 0;
+    const int vg_c = std::min(2048, prev_contacts * N + prev_contacts * N / 4 + 8);
     if (view_flags && !fiv) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, h->s_side, P);
-    if (draw) { McrParams Pv = P; Pv.flags_blocks = fiv; launch_view(h, 6, B, h->s_side, Pv, 0); }
+    if (draw) { McrParams Pv = P; Pv.flags_blocks = fiv_c; launch_view(h, 6, B, h->s_side, Pv, 0, nullptr, vg_c); }
     hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, h->s_side, P, (int)W_SIDE);
     P.role = 1;
     P.viewprep_in_flags = (view_flags && draw && h->viewprep_in_flags) ? 1 : 0;
-    const bool flags_on_caller = view_flags && draw && !P.viewprep_in_flags && N <= 7;   // (N = 8: the contact chain is the critical one; no gain, and the raster would share the machine with the bookkeeping)
+    const bool flags_on_caller = view_flags && draw && !P.viewprep_in_flags && N <= 7;   // (N = 8: the raster would share the machine with the bookkeeping: 6.70 -> 6.49 M env-steps/s, round 5)
     LAUNCH(1, k_dynamics<false>, dyn_blocks, 64, st, P, 0);          // (the main envs: no touching car<->car pair)
     P.role = 3;
     {
@@ -489,7 +494,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   // (the side stream's last kernel completes ev_join; which one that is depends on the step's shape)
   { McrParams Pc = P; Pc.list_envs_per_block = 1; LAUNCH_LDS_STOP(5, k_list_chain<true>, lg_con, 64, col::lds_bytes(N), h->s_side, STOP((!draw && !flags_list) ? h->ev_join : nullptr), Pc, Pc, fuse_flags, lg_con); }
   if (flags_list) hipExtLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, h->s_side, nullptr, STOP(!draw ? h->ev_join : nullptr), 0, P);
-  if (draw) launch_view(h, 6, B, h->s_side, P, 0, STOP(h->ev_join));
+  if (draw) launch_view(h, 6, B, h->s_side, P, 0, STOP(h->ev_join), std::min(2048, prev_contacts * N + prev_contacts * N / 4 + 8));
   P.role = 1;
   // the main envs' view records and car polygons: by k_viewprep on the side stream, beside the bookkeeping kernel, in a drawn step
   // with actions; otherwise by the dynamics' own epilogue

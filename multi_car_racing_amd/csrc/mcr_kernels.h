@@ -19,6 +19,7 @@ struct McrParams {
   uint32_t* bp_stamp;           // [B][TILE_CAP][4 * N] batch label of the tile<->wheel contact: the contact pass that first saw the two fat AABBs overlap
   int32_t bp_fresh;             // the car proxies are re-created at the current poses by this step's contact pass (after mcr_set_bodies)
   uint32_t* status;             // [MCR_STATUS_WORDS] mapped host memory: conditions that make results wrong or degraded (mcr_step checks them without synchronising)
+  uint32_t* host_counts;        // [MCR_HOST_COUNTS] mapped host memory (HC_*)
   uint32_t* status_dev;         // [MCR_STATUS_WORDS] the same counts in device memory: where the kernels count (mcr_raise)
   const McrShapes* shapes;
   float* viewp;                 // [BN][MCR_VIEWP_FLOATS] per-car camera + HUD geometry, written by k_dynamics, read by k_view
@@ -87,7 +88,10 @@ enum { ST_SPIN_GIVEUP = 0,     // a kernel gave up waiting for another stream's 
        ST_VERDICT = 1,         // the contact pass disagreed with the one-step-ahead touch verdict
        ST_CC_OVERFLOW = 2,     // more touching car<->car fixture pairs than the manifold store / the LDS pool holds: the excess was dropped
        ST_EVENT_OVERFLOW = 3,  // more tile begin events in one env-step than the replay buffer holds
-       MCR_STATUS_WORDS = 8 };
+       MCR_STATUS_WORDS = 8,
+       // behind the status words, in the same mapped allocation: counts the host sizes the NEXT step's list launches by (read without synchronising)
+       HC_CONTACT_ENVS = 0,    // the length of the last step's contact list
+       MCR_HOST_COUNTS = 8 };
 __device__ __forceinline__ int mcr_epoch(const McrParams& p) { return p.epoch_ptr ? *p.epoch_ptr : p.epoch; }
 // Report condition `w` (ST_*): counted in device memory, the new count then STORED (system scope) into the mapped host word mcr_step polls —
 // no atomic on host memory, which needs PCIe atomics and is silently dropped where the platform lacks them.  (Two reports racing may land

@@ -3,11 +3,12 @@ import sys, os, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multi_car_racing_amd.vec_env import VecMultiCarRacing
 from multi_car_racing_amd import _lib
-B, N = 4096, 2
+B, N = 4096, int(os.environ.get("N", "2"))
 env = VecMultiCarRacing(B, N, seed=0, auto_reset=True)
 env.reset()
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 pool = torch.rand((64, B, N, 3), device="cuda", generator=g); pool[..., 0] = pool[..., 0] * 2 - 1
+if int(os.environ.get("DRIVE", "0")): pool[..., 0] *= 0.1; pool[..., 1] = 1.0; pool[..., 2] = 0.0      # bench.py --actions drive
 cnt = np.zeros(B, np.int32); hist = np.zeros(32, int); mx = []
 for k in range(1000):
     env.step(pool[k % 64])
