@@ -98,7 +98,7 @@ int mcr_reset(mcr_env* h, const uint8_t* d_env_mask, uint8_t* d_obs, void* strea
  *   d_reward   [B,N] f64 step_reward (:443,:507)
  *   d_done     [B] u8   (:498-499, :503-506, TimeLimit)
  *   d_trunc    [B] u8 or NULL: info['TimeLimit.truncated']
- * With auto_reset, a finished env's obs row is the first observation of its next episode. */
+ * With auto_reset, a finished env's obs row is the first observation of its next episode (its last frame: mcr_set_terminal_obs). */
 int mcr_step(mcr_env* h, const float* d_actions, uint8_t* d_obs, double* d_reward, uint8_t* d_done,
              uint8_t* d_trunc, void* stream);
 /* render(mode) at another viewport (multi_car_racing.py:511-604 with VP_W x VP_H of :573-586; 'rgb_array' = 600 x 400):
@@ -109,6 +109,15 @@ int mcr_render(mcr_env* h, int env, int width, int height, uint8_t* d_out, void*
  * episode (done), mcr_step writes the sum of the step rewards of that episode per agent into d_ep_return[B,N] and
  * its length in steps into d_ep_len[B]; other rows are left untouched.  NULL disables either. */
 int mcr_set_episode_stats(mcr_env* h, double* d_ep_return, int32_t* d_ep_len);
+/* Terminal observations (what a baselines / SB3-style VecEnv hands out as info["terminal_observation"]).  The reference renders
+ * the state AFTER the last solve of an episode and returns it with done = True (multi_car_racing.py:431, :509; TimeLimit: __init__.py:8); with
+ * auto_reset the env's row of d_obs already shows the first observation of the next episode.  With this set, every step that ends an env's
+ * episode and re-spawns it also draws that last frame: entry i = env d_term_ids[i], frames d_term_obs[i] [N,96,96,3]; *d_term_count = the
+ * number of entries of the last completed step (0 when no episode ended), at most `cap` — episodes that end beyond `cap` in one step get no
+ * entry (cap = num_envs never drops one).  The three buffers are the caller's device memory, overwritten by every mcr_step with actions and
+ * valid once that step is complete on its stream.  An env that ends while the host has not staged its next episode FREEZES instead of being
+ * re-spawned (mcr_debug_read_counters [3]) and gets no entry.  All NULL: off.  Synchronises the device (allocates the entries' state). */
+int mcr_set_terminal_obs(mcr_env* h, uint8_t* d_term_obs, int32_t* d_term_ids, int32_t* d_term_count, int cap);
 /* Rollout statistics accumulated on the device since creation / the last reset of the counters (synchronises):
  * out2[0] = episodes finished, out2[1] = sum of their returns over all agents.  These are the per-rank inputs of the
  * job-wide metric all-reduce. */

@@ -51,6 +51,7 @@ SYMBOLS = {
     "mcr_debug_set": (_i, [_vp, _i]),
     "mcr_debug_read_view_scratch": (_i, [_vp, _i, _vp, _i]),
     "mcr_set_episode_stats": (_i, [_vp, _vp, _vp]),
+    "mcr_set_terminal_obs": (_i, [_vp, _vp, _vp, _vp, _i]),
     "mcr_read_rollout_stats": (_i, [_vp, _vp, _i]),
     "mcr_render": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mcr_debug_read_contact_counts": (_i, [_vp, _vp]),

@@ -1380,6 +1380,35 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
     }
     respawn = (run && done && p.auto_reset && es.staged_ready) || thaw;
   }
+  // ---- terminal observation (mcr_set_terminal_obs): an episode that ends with a re-spawn leaves an ENTRY — what its frames need of the state
+  // the cars end it with — before the spawn poses overwrite that state; the env's reset pass and the list raster of its chain do the rest
+  int tidx = -1;
+  if (mode == 0 && p.term_cnt != nullptr && p.obs != nullptr) {
+    const bool fin = run && done && respawn;                        // (a thaw re-spawns without an ending)
+    if (fin && agent == 0) {
+      tidx = atomicAdd(&p.term_cnt[0], 1);
+      if (tidx < p.term_cap) {
+        const int chain = p.role == 2 ? 1 : 0;
+        p.term_list[chain * p.term_cap + atomicAdd(&p.term_cnt[1 + chain], 1)] = tidx;
+        p.term_ids[tidx] = env;
+        McrTermEnv te; te.t = es.t + 1.0 / MCR_FPS; te.slot = es.slot; te.env = env; te.consumed = es.consumed + 1; te.pad = 0;
+        p.term_env[tidx] = te;
+      } else tidx = -1;
+    }
+    tidx = __shfl(tidx, leader_lane);
+    if (respawn && agent == 0) p.term_idx[env] = fin ? tidx : -1;
+    if (fin && tidx >= 0) {
+      const int tn = p.term_cap * p.N, tc = tidx * p.N + agent;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) { p.term_carf[(CF_CX + k) * tn + tc] = b[k].cx; p.term_carf[(CF_CY + k) * tn + tc] = b[k].cy; p.term_carf[(CF_A + k) * tn + tc] = b[k].a; }
+      p.term_carf[(CF_VX + 0) * tn + tc] = b[0].vx; p.term_carf[(CF_VY + 0) * tn + tc] = b[0].vy; p.term_carf[(CF_W + 0) * tn + tc] = b[0].w;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { p.term_card[(CD_OMEGA + k) * tn + tc] = omega[k]; p.term_card[(CD_PHASE + k) * tn + tc] = phase[k]; }
+      float* tvp = p.term_viewp + (size_t)tc * MCR_VIEWP_FLOATS;
+      tvp[VP_SCORE] = __int_as_float(mcr_label_value(reward_shown));
+      tvp[VP_OLDFLAGS] = __uint_as_float(flags);
+    }
+  }
 
   // ---- env state update by the group leader
   if (lane_ok && agent == 0 && (es.active || thaw) && (mode == 0 || es.resetting)) {
@@ -1388,7 +1417,9 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
       if (respawn) {
         E->slot = es.slot ^ 1; E->staged_ready = 0; E->consumed = es.consumed + 1; E->resetting = 1; E->just_reset = 1;
         E->t = 0.0; E->steps = 0; E->active = 1; E->frozen = 0;
-        p.consumed_host[env] = es.consumed + 1;
+        // (with a terminal entry, the host learns that the staged episode was consumed when the entry's frames are drawn — the end of the
+        // step —: they read the episode slot the env leaves, which the host refills as soon as it sees the counter)
+        if (tidx < 0) p.consumed_host[env] = es.consumed + 1;
       } else {
         E->t = es.t + 1.0 / MCR_FPS;
         if (p.actions) E->steps = es.steps + 1;
@@ -1634,6 +1665,7 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
     if (p.soft_sync && p.role == 1) mcr_post(p, W_BEGIN);         // the caller's stream is here: the side stream may start this step
     if (p.role == 1) p.clist_next[0] = 0;
     for (int i = 0; i < 4; ++i) if (p.next_counts[i]) *p.next_counts[i] = 0;
+    if (p.term_cnt_next) { p.term_cnt_next[0] = 0; p.term_cnt_next[1] = 0; p.term_cnt_next[2] = 0; }
   }
   dynamics_block<CC>(p, mode, (int)blockIdx.x);
 }

@@ -14,6 +14,7 @@
 // re-detect), then the action-less dynamics step
 __device__ __forceinline__ void list_reset_pass(const McrParams& p, const int blk) {
   __threadfence();                                             // E->resetting as this step's dynamics left it
+  if (p.term_idx) for (int k = 0; k < p.list_envs_per_block; ++k) term_prepare(p, mcr_env_of_slot(p, blk * p.list_envs_per_block + k));   // (before the pass clears the tile flags)
   for (int k = 0; k < p.list_envs_per_block; ++k) { collide_block(p, 1, blk * p.list_envs_per_block + k); __syncthreads(); }
   __threadfence();                                             // the dynamics lanes read what the collide lanes stored
   __syncthreads();
@@ -84,6 +85,10 @@ __global__ __launch_bounds__(64) void k_flags_list(McrParams p) {
   const int nb = mcr_list_len(p) * p.N;
   for (int blk = blockIdx.x; blk < nb; blk += gridDim.x) flags_block(p, blk);
 }
+
+__global__ void k_term_finish(McrParams p) { term_finish(p); }
+// single-stream step: the terminal entries of all re-spawned envs, in front of the reset pass (one wavefront per env)
+__global__ __launch_bounds__(64) void k_term_prep(McrParams p) { term_prepare(p, p.env0 + (int)blockIdx.x); }
 
 // soft_sync's one-thread kernels (see mcr_post / mcr_await)
 // (debug bit 13: the side stream's completion is never posted — what a stalled stream looks like to the step's join; tests)

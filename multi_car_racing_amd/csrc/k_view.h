@@ -238,6 +238,9 @@ __global__ __launch_bounds__(VIEW_THREADS, LIST ? 3 : 4) void k_view(McrParams p
     return;
   }
   int my_env = -1, my_slot = 0, my_P = -1, my_agent = 0;
+  // (LIST) a TERMINAL item (mcr_kernels.h: McrTermEnv): the frames of an env's finished episode.  my_env addresses the episode slot (the
+  // env's old one), my_benv the per-car / per-env buffers — the entry's own view records, car polygons, tile flags and frames
+  int my_benv = -1, my_term = 0;
   // List launches with `split_views`: a work slot is ONE VIEW (list entry s / N, agent s % N) instead of an env with its N views —
   // the few envs of a list are the tail of a chain on the step's critical path, and their views side by side take half the time
   // of one after the other (what an env's views share is fetched once per view then).
@@ -246,13 +249,21 @@ __global__ __launch_bounds__(VIEW_THREADS, LIST ? 3 : 4) void k_view(McrParams p
     const int s = (int)blockIdx.x + (LIST ? lane * vgrid : 0);
     int e = -1;
     bool ojr = only_just_reset != 0;
+    int term_i = -1;                                                       // position in the chain's list of terminal entries
     if (p.role == 5) {
-      // the tail of the caller's stream: the deferred envs, then the envs the main dynamics re-spawned (their first observation) — one launch
+      // the tail of the caller's stream: the deferred envs, then the envs the main dynamics re-spawned (their first observation), then the
+      // terminal entries of the caller-side chains — one launch
       const int idx = split_views ? s / N : s, nd = p.dlist[0], nr = p.rlist[0];
       if (idx < nd) e = p.dlist[1 + idx]; else if (idx - nd < nr) { e = p.rlist[1 + idx - nd]; ojr = true; }
+      else if (p.term_cnt != nullptr && idx - nd - nr < p.term_cnt[1]) term_i = idx - nd - nr;
       my_agent = split_views ? s % N : 0;
     }
-    else if (p.role >= 2) { e = mcr_env_of_slot(p, split_views ? s / N : s); if (e >= p.env0 + p.nenv) e = -1; my_agent = split_views ? s % N : 0; }
+    else if (p.role == 6) { const int idx = split_views ? s / N : s; if (p.term_cnt != nullptr && idx < p.term_cnt[1]) term_i = idx; my_agent = split_views ? s % N : 0; }   // single-stream step: the terminal entries alone
+    else if (p.role >= 2) {
+      const int idx = split_views ? s / N : s, nl = mcr_list_len(p);
+      e = mcr_env_of_slot(p, idx); if (e >= p.env0 + p.nenv) e = -1; my_agent = split_views ? s % N : 0;
+      if (p.role == 2 && p.term_cnt != nullptr && idx >= nl && idx - nl < p.term_cnt[2]) term_i = p.term_cap + idx - nl;      // the contact chain's entries
+    }
     else if (p.use_vorder) {
       // one load instead of a chain of four (list counts -> list entry -> env record -> slot header): the entry k_dynamics left
       // carries the env, its episode slot and the slot's entry count; only envs this launch draws are listed (active, not
@@ -270,18 +281,35 @@ __global__ __launch_bounds__(VIEW_THREADS, LIST ? 3 : 4) void k_view(McrParams p
       if (!es.active || (ojr && !es.just_reset) || (p.role >= 2 && !ojr && es.resetting)) e = -1;
       my_slot = es.slot;
     }
-    my_env = e;
+    my_env = e; my_benv = e;
+    if (LIST && term_i >= 0) {
+      const int ti = p.term_list[term_i];
+      const McrTermEnv te = p.term_env[ti];
+      my_env = te.env; my_slot = te.slot; my_benv = ti; my_term = 1;
+    }
   }
   unsigned long long todo = LIST ? __ballot(my_env >= 0) : (my_env >= 0 ? 1ull : 0ull);
   // (soft_sync: the step's join, see McrParams::await_tail)
-  auto join_tail = [&]() { if (LIST && p.await_tail && blockIdx.x == 0 && threadIdx.x == 0) { (void)mcr_await(p, W_SIDE); (void)mcr_await(p, W_MAIN); } };
+  // (... and, with terminal observations, the step's last act: the entry count and the consumed-episode news, mcr_kernels.h: term_finish)
+  auto join_tail = [&]() {
+    if (LIST && p.await_tail && blockIdx.x == 0) {
+      if (threadIdx.x == 0) { (void)mcr_await(p, W_SIDE); (void)mcr_await(p, W_MAIN); }
+      if (p.term_cnt != nullptr) { __syncthreads(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); term_finish(p); }
+    }
+  };
   if (!todo) { join_tail(); return; }
   auto slot_of = [&](int k) -> const uint8_t* {
     return p.slots + ((size_t)__builtin_amdgcn_readlane(my_env, k) * 2 + __builtin_amdgcn_readlane(my_slot, k)) * MCR_SLOT_BYTES;
   };
   int env, P, a_lo;
+  int term = 0;                                                             // (LIST) the item being drawn is a terminal entry
   const uint8_t* __restrict__ slot;
-  { const int k = UNI(__builtin_ctzll(todo)); todo &= todo - 1; env = __builtin_amdgcn_readlane(my_env, k); slot = slot_of(k); a_lo = __builtin_amdgcn_readlane(my_agent, k); }
+  { const int k = UNI(__builtin_ctzll(todo)); todo &= todo - 1; env = __builtin_amdgcn_readlane(my_benv, k); slot = slot_of(k); a_lo = __builtin_amdgcn_readlane(my_agent, k); if (LIST) term = __builtin_amdgcn_readlane(my_term, k); }
+  // the per-car / per-env buffers of an item: the live ones, or the terminal entries' (same layouts, `env` = the entry index)
+  auto vp_of = [&](int t) -> const float* { return (LIST && t) ? p.term_viewp : p.viewp; };
+  auto cp_of = [&](int t) -> const float* { return (LIST && t) ? p.term_carpoly : p.carpoly; };
+  auto tf_of = [&](int t) -> const uint16_t* { return (LIST && t) ? p.term_tflags : p.tile_flags; };
+  auto ob_of = [&](int t) -> uint8_t* { return (LIST && t) ? p.term_obs : p.obs; };
   // what a candidate needs from HBM, requested one round ahead: a quad's 4 vertices + meta word, or 4 vertices of a Car.draw polygon +
   // its vertex count (the 8-gon's two slots fetch vertices 0..3 and 4..7)
   struct Raw { float4 a, b; uint32_t m; };
@@ -313,15 +341,15 @@ __global__ __launch_bounds__(VIEW_THREADS, LIST ? 3 : 4) void k_view(McrParams p
   // In two parts, so that what runs between them (the HUD's preparation) covers the loads: lb_load requests a lane's box, a car's anchor and — lanes
   // 0..11, one float each: vector loads, which unlike scalar ones are not waited for by the first LDS access — the view's camera and its inverse.
   struct LbRaw { float4 bbox; float a0, a1, a8, a9, cam; };
-  auto lb_load = [&](const uint8_t* __restrict__ sl, int e, int vw, const int lane) -> LbRaw {
+  auto lb_load = [&](const uint8_t* __restrict__ sl, int e, int vw, const int lane, int t) -> LbRaw {
     LbRaw r; r.bbox = make_float4(1.0f, 1.0f, -1.0f, -1.0f); r.a0 = r.a1 = r.a8 = r.a9 = 0.0f;
     if (lane < NBLK) r.bbox = ((const float4*)(sl + MCR_OFF_QBLK))[lane];
     const int cc = lane - NBLK;
     if (cc >= 0 && cc < N) {                                                // two opposite vertices of the hull's 8-gon (Car.draw polygon 10)
-      const float* __restrict__ cp = p.carpoly + (size_t)(e * N + cc) * MCR_CARPOLY_FLOATS + 10 * 16;
+      const float* __restrict__ cp = cp_of(t) + (size_t)(e * N + cc) * MCR_CARPOLY_FLOATS + 10 * 16;
       r.a0 = cp[0]; r.a1 = cp[1]; r.a8 = cp[8]; r.a9 = cp[9];
     }
-    r.cam = p.viewp[(size_t)vw * MCR_VIEWP_FLOATS + min(lane, 11)];         // VP_CAM (6) then VP_INV (6)
+    r.cam = vp_of(t)[(size_t)vw * MCR_VIEWP_FLOATS + min(lane, 11)];        // VP_CAM (6) then VP_INV (6)
     return r;
   };
   static_assert(VP_CAM == 0 && VP_INV == 6, "lb_load fetches the first 12 floats of a view record");
@@ -364,9 +392,9 @@ __global__ __launch_bounds__(VIEW_THREADS, LIST ? 3 : 4) void k_view(McrParams p
   // ---- once per workgroup: palette, glyphs, grass lattice; the first env's tile flags, view record, block list
   if (tid < 24) palc[tid] = PALETTE_RGB[tid];
   if (tid >= 128 && tid < 128 + 77) glyphs[tid - 128] = ((const uint8_t*)LABEL_GLYPHS)[tid - 128];
-  pack_tile_flags(((const uint32_t*)(p.tile_flags + (size_t)env * MCR_TILE_CAP))[tid]);
-  if (tid >= 64 && tid < 64 + MCR_VIEWP_FLOATS) vrec[0][tid - 64] = p.viewp[(size_t)(env * N + a_lo) * MCR_VIEWP_FLOATS + (tid - 64)];
-  if (wave == 3) lb_finish(lb_load(slot, env, env * N + a_lo, lane), 0, lane);
+  pack_tile_flags(((const uint32_t*)(tf_of(term) + (size_t)env * MCR_TILE_CAP))[tid]);
+  if (tid >= 64 && tid < 64 + MCR_VIEWP_FLOATS) vrec[0][tid - 64] = vp_of(term)[(size_t)(env * N + a_lo) * MCR_VIEWP_FLOATS + (tid - 64)];
+  if (wave == 3) lb_finish(lb_load(slot, env, env * N + a_lo, lane, term), 0, lane);
   // grass lattice as the reference builds it (:620-627): f32(k*x) and f32(k*x + k) for x = -20, -18, .., 18
   if (tid >= 224 && tid < 244) { const double k = MCR_PLAYFIELD / 20.0, x = 2.0 * (double)(tid - 224 - 10); glo[tid - 224] = (float)(k * x + 0); ghi[tid - 224] = (float)(k * x + k); }
   // Candidates of a view (env e, episode slot sl with pe road_poly entries, visible blocks vblk[buf][0 .. pv / QBLK), visible
@@ -375,7 +403,7 @@ __global__ __launch_bounds__(VIEW_THREADS, LIST ? 3 : 4) void k_view(McrParams p
   // is a pad that keeps pairs aligned), the 5 vertical gauges when one of them is taller than the HUD bar, the playfield quad
   // (only when the view leaves it), the G light grass squares the viewport can see.
   auto quad_of = [&](int c, int buf) -> int { return (int)vblk[buf][c / MCR_QBLK] * MCR_QBLK + (c & (MCR_QBLK - 1)); };
-  auto fetch_raw = [&](int c, int pv, int sb, int cs, int buf, const uint8_t* __restrict__ sl, int pe, int e) -> Raw {
+  auto fetch_raw = [&](int c, int pv, int sb, int cs, int buf, const uint8_t* __restrict__ sl, int pe, int e, int t) -> Raw {
     Raw r; r.a = r.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f); r.m = 0u;
     if (c < pv) {
       const int q = quad_of(c, buf);
@@ -384,7 +412,7 @@ __global__ __launch_bounds__(VIEW_THREADS, LIST ? 3 : 4) void k_view(McrParams p
       const int vc = (c - sb) / 14, sl14 = (c - sb) - vc * 14;
       if (sl14 != 13) {
         const int j = sl14 < 11 ? sl14 : sl14 - 1;                          // slot 11 sets up the second half of polygon 10 (the 8-gon): its vertices 4..7
-        const float* __restrict__ cp = p.carpoly + (size_t)(e * N + (int)vcar[buf][vc]) * MCR_CARPOLY_FLOATS;
+        const float* __restrict__ cp = cp_of(t) + (size_t)(e * N + (int)vcar[buf][vc]) * MCR_CARPOLY_FLOATS;
         const float4* cv = (const float4*)(cp + j * 16) + (sl14 == 11 ? 2 : 0);
         r.a = cv[0]; r.b = cv[1];
         r.m = (uint32_t)__float_as_int(cp[MCR_CARPOLY_NOFF + j]);
@@ -417,9 +445,9 @@ __global__ __launch_bounds__(VIEW_THREADS, LIST ? 3 : 4) void k_view(McrParams p
   for (;;) {
   // the workgroup's next env, if any
   const bool has_next = LIST && todo != 0ull;
-  int env_n = env, a_lo_n = 0; const uint8_t* __restrict__ slot_n = slot;
+  int env_n = env, a_lo_n = 0, term_n = term; const uint8_t* __restrict__ slot_n = slot;
   uint32_t tfl_n = 0u; int P_nv = 0;
-  if (LIST && has_next) { const int k = UNI(__builtin_ctzll(todo)); todo &= todo - 1; env_n = __builtin_amdgcn_readlane(my_env, k); slot_n = slot_of(k); a_lo_n = __builtin_amdgcn_readlane(my_agent, k); }
+  if (LIST && has_next) { const int k = UNI(__builtin_ctzll(todo)); todo &= todo - 1; env_n = __builtin_amdgcn_readlane(my_benv, k); slot_n = slot_of(k); a_lo_n = __builtin_amdgcn_readlane(my_agent, k); term_n = __builtin_amdgcn_readlane(my_term, k); }
   const int a_hi = split_views ? a_lo + 1 : N;
 #pragma nounroll
   for (int agent = a_lo; agent < a_hi; ++agent, ++vs) {
@@ -429,7 +457,7 @@ __global__ __launch_bounds__(VIEW_THREADS, LIST ? 3 : 4) void k_view(McrParams p
     // the view after this one: the env's next agent, or agent 0 of the workgroup's next env
     const bool last = agent + 1 == a_hi;
     const bool nv_ok = !last || has_next;
-    const int env_v = last ? env_n : env, vw_v = last ? env_n * N + a_lo_n : vw + 1;
+    const int env_v = last ? env_n : env, vw_v = last ? env_n * N + a_lo_n : vw + 1, term_v = last ? term_n : term;
     const uint8_t* __restrict__ slot_v = last ? slot_n : slot;
     // the view's own copy of the thread index: what the phases derive from it (key-buffer addresses of clear and resolve, frame offsets,
     // the HUD's column masks) is computed where it is used instead of being hoisted out of the view loop and kept in 20 VGPRs across it
@@ -444,8 +472,8 @@ __global__ __launch_bounds__(VIEW_THREADS, LIST ? 3 : 4) void k_view(McrParams p
     // (requested here, stored to LDS behind the candidates: nobody waits for it)
     const bool vrec_mine = nv_ok && tl >= 64 && tl < 64 + MCR_VIEWP_FLOATS;
     float vrec_n = 0.0f;
-    if (vrec_mine) vrec_n = p.viewp[(size_t)vw_v * MCR_VIEWP_FLOATS + (tl - 64)];
-    if (last && has_next) { tfl_n = ((const uint32_t*)(p.tile_flags + (size_t)env_n * MCR_TILE_CAP))[tl]; if (LIST) P_nv = ((const McrSlotHeader*)slot_n)->P; }
+    if (vrec_mine) vrec_n = vp_of(term_v)[(size_t)vw_v * MCR_VIEWP_FLOATS + (tl - 64)];
+    if (last && has_next) { tfl_n = ((const uint32_t*)(tf_of(term_n) + (size_t)env_n * MCR_TILE_CAP))[tl]; if (LIST) P_nv = ((const McrSlotHeader*)slot_n)->P; }
     // camera, shifted so that key-buffer row 0 is GL row 12
     const float m00 = vr[VP_CAM + 0], m01 = vr[VP_CAM + 1], m10 = vr[VP_CAM + 2], m11 = vr[VP_CAM + 3], ctx = vr[VP_CAM + 4], cty = vr[VP_CAM + 5] - (float)HUD_ROWS;
     // grass squares the viewport can see / "is the whole viewport inside the playfield" (k_dynamics, from the inverse camera)
@@ -465,16 +493,16 @@ __global__ __launch_bounds__(VIEW_THREADS, LIST ? 3 : 4) void k_view(McrParams p
       // candidates are road quads only: that one then arrives last — 82 instead of 79 us.)
       __builtin_amdgcn_s_setprio(2);
       LbRaw lbr; lbr.bbox = make_float4(1.0f, 1.0f, -1.0f, -1.0f); lbr.a0 = lbr.a1 = lbr.a8 = lbr.a9 = lbr.cam = 0.0f;
-      if (nv_ok) lbr = lb_load(slot_v, env_v, vw_v, ll);
+      if (nv_ok) lbr = lb_load(slot_v, env_v, vw_v, ll, term_v);
       const bool hud_flag = (__float_as_uint(vr[VP_OLDFLAGS]) & 1u) != 0u && p.backwards_flag != 0;
       const HudState hud = hud_prep(vr, glyphs, ll, hud_flag);
       if (nv_ok) lb_finish(lbr, buf ^ 1, ll);
-      if (!(dbg & 8)) hud_store(hud, (uint32_t*)(p.obs + (size_t)vw * (96 * 96 * 3)), ll, hud_flag);
+      if (!(dbg & 8)) hud_store(hud, (uint32_t*)(ob_of(term) + (size_t)vw * (96 * 96 * 3)), ll, hud_flag);
       __builtin_amdgcn_s_setprio(LIST ? 3 : 0);
     }
     const Layout L = layout_of(buf);
     const int Pv = L.pv, CS = L.cs, TG = L.tg, F = L.f, G = L.g, nround = L.nround, SB = L.sb;
-    if (vs == 0 && tl < RC) nxt = fetch_raw(tl, Pv, SB, CS, buf, slot, P, env);   // later views: requested while the previous one was drawn
+    if (vs == 0 && tl < RC) nxt = fetch_raw(tl, Pv, SB, CS, buf, slot, P, env, term);   // later views: requested while the previous one was drawn
 #pragma nounroll
     for (int rd = 0; rd < nround; ++rd) {
       const int c = rd * RC + tl;
@@ -605,10 +633,10 @@ __global__ __launch_bounds__(VIEW_THREADS, LIST ? 3 : 4) void k_view(McrParams p
       // next round's candidates (or round 0 of the next agent's view: the same quads): their HBM / L2 data travels
       // while this round's spans are drawn
       if (tl < RC) {
-        if (rd + 1 < nround) nxt = fetch_raw(c + RC, Pv, SB, CS, buf, slot, P, env);
+        if (rd + 1 < nround) nxt = fetch_raw(c + RC, Pv, SB, CS, buf, slot, P, env, term);
         else if (nv_ok) {                                                   // round 0 of the next view (its record, block and car lists are in LDS)
           const Layout Ln = layout_of(buf ^ 1);
-          nxt = fetch_raw(tl, Ln.pv, Ln.sb, Ln.cs, buf ^ 1, slot_v, last ? UNI(P_nv) : P, env_v);
+          nxt = fetch_raw(tl, Ln.pv, Ln.sb, Ln.cs, buf ^ 1, slot_v, last ? UNI(P_nv) : P, env_v, term_v);
         }
       }
       int off = incl - g4;
@@ -679,7 +707,7 @@ __global__ __launch_bounds__(VIEW_THREADS, LIST ? 3 : 4) void k_view(McrParams p
     }
     // ---- resolve + packed RGB write-out of the scene rows: 4 pixels -> 12 bytes per ll, rows top-down (arr[::-1], :602)
     if (!(dbg & 8)) {
-      uint32_t* __restrict__ out = (uint32_t*)(p.obs + (size_t)vw * (96 * 96 * 3));
+      uint32_t* __restrict__ out = (uint32_t*)(ob_of(term) + (size_t)vw * (96 * 96 * 3));
       // 240 threads x 9 trips of 10 rows: a thread keeps its 4-pixel group's column and walks down 10 rows per trip, so that key-buffer and
       // frame addresses are one division per view plus constants (256 threads x 8 trips: a division and a bounds check per trip); the
       // winners' RGB bytes are packed with three byte permutes
@@ -714,7 +742,7 @@ __global__ __launch_bounds__(VIEW_THREADS, LIST ? 3 : 4) void k_view(McrParams p
   }
   if (!has_next) break;
   // hand-over: every thread is past the last barrier of the view's span fill, nobody reads the tile flags any more
-  env = env_n; slot = slot_n; P = UNI(P_nv); pack_tile_flags(tfl_n); a_lo = a_lo_n;
+  env = env_n; slot = slot_n; P = UNI(P_nv); pack_tile_flags(tfl_n); a_lo = a_lo_n; term = term_n;
   }
   join_tail();
 }

@@ -11,12 +11,13 @@
 
 __device__ __forceinline__ double vprep_sign(double x) { return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : 0.0); }
 
-__device__ __forceinline__ void viewprep_car(const McrParams& p, const int ci, const double t_now) {
-  const int BN = p.BN;
-  const McrShapes& S = *p.shapes;
-  float* vp = p.viewp + (size_t)ci * MCR_VIEWP_FLOATS;
-  float4* cp4 = (float4*)(p.carpoly + (size_t)ci * MCR_CARPOLY_FLOATS);
-  int* cnt = (int*)(p.carpoly + (size_t)ci * MCR_CARPOLY_FLOATS + MCR_CARPOLY_NOFF);
+// (carf / card: per-car SoA fields at stride BN — the live state, or the state the cars of a terminal entry ended their episode with)
+__device__ __forceinline__ void viewprep_car(const McrShapes& S, const float* __restrict__ carf, const double* __restrict__ card, const int BN, const int ci,
+                                             float* __restrict__ viewp, float* __restrict__ carpoly, const double h_ratio, const double t_now) {
+  struct { const float* carf; const double* card; double h_ratio; } p = {carf, card, h_ratio};
+  float* vp = viewp + (size_t)ci * MCR_VIEWP_FLOATS;
+  float4* cp4 = (float4*)(carpoly + (size_t)ci * MCR_CARPOLY_FLOATS);
+  int* cnt = (int*)(carpoly + (size_t)ci * MCR_CARPOLY_FLOATS + MCR_CARPOLY_NOFF);
   {
     const float hcx = p.carf[(CF_CX + 0) * BN + ci], hcy = p.carf[(CF_CY + 0) * BN + ci], ha = p.carf[(CF_A + 0) * BN + ci];
     const float hvx = p.carf[(CF_VX + 0) * BN + ci], hvy = p.carf[(CF_VY + 0) * BN + ci];
@@ -140,6 +141,20 @@ __device__ __forceinline__ void viewprep_block(const McrParams& p, const int blk
   if (env >= p.env0 + p.nenv || agent >= p.N) return;
   const McrEnvState es = p.env[env];
   if (!es.active || es.just_reset) return;
-  viewprep_car(p, env * p.N + agent, es.t);
+  viewprep_car(*p.shapes, p.carf, p.card, p.BN, env * p.N + agent, p.viewp, p.carpoly, p.h_ratio, es.t);
+}
+// Terminal entry of env `env` (if this step's dynamics made one): view records and car polygons from the state its cars ended the episode
+// with (lanes 0 .. N-1), and the tiles' recolour flags before the reset pass clears them.  Called by the env's reset pass, one wavefront.
+__device__ __forceinline__ void term_prepare(const McrParams& p, const int env) {
+  if (p.term_idx == nullptr || env >= p.env0 + p.nenv) return;
+  const McrEnvState es = p.env[env];
+  if (!es.active || !es.resetting) return;
+  const int tidx = p.term_idx[env];
+  if (tidx < 0) return;
+  const int lane = threadIdx.x & 63;
+  const uint32_t* __restrict__ src = (const uint32_t*)(p.tile_flags + (size_t)env * MCR_TILE_CAP);
+  uint32_t* __restrict__ dst = (uint32_t*)(p.term_tflags + (size_t)tidx * MCR_TILE_CAP);
+  for (int i = lane; i < MCR_TILE_CAP / 2; i += 64) dst[i] = src[i];
+  if (lane < p.N) viewprep_car(*p.shapes, p.term_carf, p.term_card, p.term_cap * p.N, tidx * p.N + lane, p.term_viewp, p.term_carpoly, p.h_ratio, p.term_env[tidx].t);
 }
 __global__ __launch_bounds__(64) void k_viewprep(McrParams p) { viewprep_block(p, (int)blockIdx.x); }

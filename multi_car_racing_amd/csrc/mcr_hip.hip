@@ -74,6 +74,9 @@ struct mcr_env {
   bool stop_events = true;    // events completed by the launches they mark (hipExtLaunchKernelGGL) instead of marker packets behind them
   int chain_grid;             // workgroups of a list chain launch (each walks the list, 2 envs at a time)
   bool vorder_dirty[2];       // the raster order list of that step parity was filled by a step that did not draw
+  void* term_slab = nullptr;  // terminal observations (mcr_set_terminal_obs): entry state, view records, per-parity counters and lists
+  int32_t* term_cnt2 = nullptr;   // [2][4] counters by step parity
+  int32_t* term_list2 = nullptr;  // [2][2][cap] entry lists by step parity and chain
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -259,6 +262,7 @@ extern "C" int mcr_destroy(mcr_env* h) {
     (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_fork2); (void)hipEventDestroy(h->ev_join2); (void)hipEventDestroy(h->ev_col);
   }
   (void)hipFree(h->slab);
+  if (h->term_slab) (void)hipFree(h->term_slab);
   (void)hipHostFree(h->consumed_host);
   (void)hipHostFree(h->status_host);
   delete[] h->consumed_seen;
@@ -376,6 +380,8 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     P.part = h->P.part + par * B; P.part_next = cc_active(h) ? h->P.part + oth * B : nullptr;
     P.next_counts[0] = h->P.dlist + oth * (B + 1); P.next_counts[1] = h->P.rlist + oth * (B + 1);
     P.next_counts[2] = h->P.vcount + oth * (B + 2); P.next_counts[3] = P.next_counts[2] + 1;
+    if (h->term_slab && P.obs && P.actions) { P.term_cnt = h->term_cnt2 + par * 4; P.term_cnt_next = h->term_cnt2 + oth * 4; P.term_list = h->term_list2 + par * 2 * (size_t)P.term_cap; }
+    else { P.term_cnt = P.term_cnt_next = nullptr; P.term_idx = nullptr; }
     h->step_parity ^= 1;
   }
   if (!h->split) {
@@ -383,12 +389,14 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), st, P, 0);
     LAUNCH_DYN(1, P.car_contacts && N > 1, dyn_blocks, st, P, 0);
     if (P.auto_reset) {
+      if (P.term_cnt) hipLaunchKernelGGL(k_term_prep, dim3(B), dim3(64), 0, st, P);     // (the terminal entries of the envs that end here, before the pass clears their tile flags)
       LAUNCH_LDS(3, k_collide, B, 64, col::lds_bytes(N), st, P, 1);
       LAUNCH_DYN(4, P.car_contacts && N > 1, dyn_blocks, st, P, 1);
     }
     P.use_vorder = 1;
     if (draw) launch_view(h, 2, B, st, P, 0);
     P.use_vorder = 0;
+    if (P.term_cnt) { McrParams Pt = P; Pt.role = 6; launch_view(h, 7, B, st, Pt, 0); hipLaunchKernelGGL(k_term_finish, dim3(1), dim3(256), 0, st, P); }
     if (view_flags) hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, st, P);
     return;
   }
@@ -444,7 +452,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     const int fiv_c = fiv ? std::min(256, std::max(fiv, (prev_contacts * (N + 1) + 3) / 4 + 2)) : 0;
     const int vg_c = std::min(2048, prev_contacts * N + prev_contacts * N / 4 + 8);
     if (view_flags && !fiv) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, h->s_side, P);
-    if (draw) { McrParams Pv = P; Pv.flags_blocks = fiv_c; launch_view(h, 6, B, h->s_side, Pv, 0, nullptr, vg_c); }
+    if (draw) { McrParams Pv = P; Pv.flags_blocks = fiv_c; launch_view(h, 6, P.term_cnt ? 2 * B : B, h->s_side, Pv, 0, nullptr, vg_c); }
     hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, h->s_side, P, (int)W_SIDE);
     P.role = 1;
     P.viewprep_in_flags = (view_flags && draw && h->viewprep_in_flags) ? 1 : 0;
@@ -459,7 +467,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
       // Beyond three cars per env the third stream's chain (bookkeeping of B*N cars, then B*N views) is the longer one and the caller's
       // has slack: the main envs' bookkeeping — which the raster does not depend on — moves here, between the resume chain and its raster
       if (flags_on_caller) { McrParams Pm = P; Pm.role = 1; hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, st, Pm); }
-      if (draw) { McrParams Pv = P; Pv.role = P.auto_reset ? 5 : 3; Pv.await_tail = 1; Pv.flags_blocks = fiv; launch_view(h, 7, B, st, Pv, 0); }     // ... and the step's join
+      if (draw) { McrParams Pv = P; Pv.role = P.auto_reset ? 5 : 3; Pv.await_tail = 1; Pv.flags_blocks = fiv; launch_view(h, 7, P.term_cnt ? 2 * B : B, st, Pv, 0); }     // ... and the step's join (+ the terminal entries' frames and count)
     }
     P.role = 1;
     hipLaunchKernelGGL(k_await, dim3(1), dim3(64), 0, h->s_defer, P, (int)W_DYN, cc ? (int)W_COL : -1);
@@ -494,7 +502,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   // (the side stream's last kernel completes ev_join; which one that is depends on the step's shape)
   { McrParams Pc = P; Pc.list_envs_per_block = 1; LAUNCH_LDS_STOP(5, k_list_chain<true>, lg_con, 64, col::lds_bytes(N), h->s_side, STOP((!draw && !flags_list) ? h->ev_join : nullptr), Pc, Pc, fuse_flags, lg_con); }
   if (flags_list) hipExtLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, h->s_side, nullptr, STOP(!draw ? h->ev_join : nullptr), 0, P);
-  if (draw) launch_view(h, 6, B, h->s_side, P, 0, STOP(h->ev_join), std::min(2048, prev_contacts * N + prev_contacts * N / 4 + 8));
+  if (draw) launch_view(h, 6, P.term_cnt ? 2 * B : B, h->s_side, P, 0, STOP(h->ev_join), std::min(2048, prev_contacts * N + prev_contacts * N / 4 + 8));
   P.role = 1;
   // the main envs' view records and car polygons: by k_viewprep on the side stream, beside the bookkeeping kernel, in a drawn step
   // with actions; otherwise by the dynamics' own epilogue
@@ -518,7 +526,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     McrParams Pr = P; Pr.role = 4; Pr.list_envs_per_block = 1;     // one re-spawned env per workgroup: they run side by side
     LAUNCH_LDS_STOP(7, k_list_chain<false>, ga + gb, 64, col::lds_bytes(N), s_resume, STOP((!draw && !flags_list) ? resume_done : nullptr), P, Pr, fuse_flags, ga);
     if (flags_list) hipExtLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, s_resume, nullptr, STOP(!draw ? resume_done : nullptr), 0, P);
-    if (draw) { McrParams Pv = P; Pv.role = P.auto_reset ? 5 : 3; launch_view(h, 7, B, s_resume, Pv, 0, STOP(resume_done)); }
+    if (draw) { McrParams Pv = P; Pv.role = P.auto_reset ? 5 : 3; launch_view(h, 7, P.term_cnt ? 2 * B : B, s_resume, Pv, 0, STOP(resume_done)); }
   }
   P.role = 1;
   RECORD_UNLESS_STOP(h->ev_join, h->s_side);
@@ -538,6 +546,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   if (!sev || (!draw && !view_flags)) (void)hipEventRecord(h->ev_join2, h->s_defer);
   (void)hipStreamWaitEvent(st, h->ev_join, 0);
   (void)hipStreamWaitEvent(st, h->ev_join2, 0);
+  if (P.term_cnt) hipLaunchKernelGGL(k_term_finish, dim3(1), dim3(256), 0, st, P);     // (the phase-word path: the join's workgroup does it)
 #undef STOP
 #undef RECORD_UNLESS_STOP
 }
@@ -653,6 +662,37 @@ extern "C" int mcr_bind_stream(mcr_env* h, void* stream) {
   }
   if (h->bound.size() >= 64) h->bound.erase(h->bound.begin());
   h->bound.emplace_back(st, ok);
+  return MCR_OK;
+}
+
+extern "C" int mcr_set_terminal_obs(mcr_env* h, uint8_t* d_term_obs, int32_t* d_term_ids, int32_t* d_term_count, int cap) {
+  if (!h) { g_err = "null handle"; return MCR_ERR_ARG; }
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipDeviceSynchronize());
+  for (auto& g : h->sg) if (g.valid) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); g.valid = false; }
+  if (h->term_slab) { (void)hipFree(h->term_slab); h->term_slab = nullptr; }
+  McrParams& P = h->P;
+  P.term_obs = nullptr; P.term_ids = nullptr; P.term_count_out = nullptr; P.term_cap = 0; P.term_idx = nullptr;
+  if (!d_term_obs && !d_term_ids && !d_term_count) return MCR_OK;                      // off
+  if (!d_term_obs || !d_term_ids || !d_term_count || cap < 1) { g_err = "mcr_set_terminal_obs: all three buffers and cap >= 1, or all null"; return MCR_ERR_ARG; }
+  if (!h->cfg.obs_enabled || !h->cfg.auto_reset) { g_err = "terminal observations need obs_enabled and auto_reset"; return MCR_ERR_STATE; }
+  cap = std::min(cap, h->cfg.num_envs);
+  const size_t N = h->cfg.num_agents, CN = (size_t)cap * N, B = h->cfg.num_envs;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  const size_t o_cnt = carve(sizeof(int32_t) * 8), o_list = carve(sizeof(int32_t) * 4 * cap), o_idx = carve(sizeof(int32_t) * B);
+  const size_t o_carf = carve(sizeof(float) * CF_COUNT * CN), o_card = carve(sizeof(double) * CD_COUNT * CN);
+  const size_t o_vp = carve(sizeof(float) * MCR_VIEWP_FLOATS * CN), o_cp = carve(sizeof(float) * MCR_CARPOLY_FLOATS * CN);
+  const size_t o_tf = carve(sizeof(uint16_t) * MCR_TILE_CAP * (size_t)cap), o_te = carve(sizeof(McrTermEnv) * cap);
+  if (hipMalloc(&h->term_slab, off) != hipSuccess) { h->term_slab = nullptr; g_err = "hipMalloc failed"; return MCR_ERR_HIP; }
+  uint8_t* base = (uint8_t*)h->term_slab;
+  HIPCHK(hipMemset(base, 0, off));
+  HIPCHK(hipMemset(base + o_idx, 0xff, sizeof(int32_t) * B));
+  HIPCHK(hipMemset(d_term_count, 0, sizeof(int32_t)));
+  h->term_cnt2 = (int32_t*)(base + o_cnt); h->term_list2 = (int32_t*)(base + o_list);
+  P.term_obs = d_term_obs; P.term_ids = d_term_ids; P.term_count_out = d_term_count; P.term_cap = cap;
+  P.term_idx = (int32_t*)(base + o_idx); P.term_carf = (float*)(base + o_carf); P.term_card = (double*)(base + o_card);
+  P.term_viewp = (float*)(base + o_vp); P.term_carpoly = (float*)(base + o_cp); P.term_tflags = (uint16_t*)(base + o_tf); P.term_env = (McrTermEnv*)(base + o_te);
   return MCR_OK;
 }
 

@@ -2,6 +2,12 @@
 #pragma once
 #include "mcr_common.h"
 
+// Terminal observations (include/mcr.h: mcr_set_terminal_obs).  An env whose episode ends in a step that re-spawns it (auto-reset) gets an
+// ENTRY: the state its cars ended the episode with (the per-car SoA fields k_viewprep reads, at stride term_cap * N), the env's clock and the
+// episode slot it played in; the reset pass of the env turns that into view records / car polygons and saves the tiles' recolour flags before
+// it clears them; the list raster launch of the env's chain draws the entry's N frames into the caller's buffer.
+struct McrTermEnv { double t; int32_t slot, env, consumed, pad; };
+
 struct McrParams {
   int32_t B, N, G;              // envs, agents, lanes per env in the dynamics kernel (pow2 >= N)
   int32_t BN;                   // B*N: stride of every per-car SoA field
@@ -75,6 +81,18 @@ struct McrParams {
   uint8_t* trunc_out;           // [B] or null
   double* ep_return_out;        // [B,N] or null: episode return per agent, written in the step that ends an episode
   int32_t* ep_len_out;          // [B] or null: episode length in steps, written in the step that ends an episode
+  // terminal observations (null / 0: off)
+  uint8_t* term_obs;            // [term_cap][N][96][96][3] the caller's buffer
+  int32_t* term_ids;            // [term_cap] the caller's: env of entry i
+  int32_t* term_count_out;      // [1] the caller's: entries of the step (<= term_cap), written when the step is complete
+  int32_t term_cap;
+  int32_t* term_cnt;            // [4] this step's counters (buffers by step parity): [0] episodes that ended with a re-spawn, [1] entries of the caller-side chains, [2] of the contact chain
+  int32_t* term_cnt_next;       // the other parity's: zeroed by this step's main k_dynamics
+  int32_t* term_list;           // [2][term_cap] this parity: entry indices per chain (0 caller side, 1 contact chain)
+  int32_t* term_idx;            // [B] env -> entry of the step that last re-spawned it (-1: none: a thaw, or more endings than term_cap)
+  float* term_carf; double* term_card;   // [CF_COUNT][term_cap * N], [CD_COUNT][term_cap * N]
+  float* term_viewp; float* term_carpoly; uint16_t* term_tflags;   // [term_cap * N][..], [term_cap * N][..], [term_cap][MCR_TILE_CAP]
+  McrTermEnv* term_env;         // [term_cap]
   const uint8_t* reset_mask;    // [B] or null (k_install)
   int32_t auto_reset, max_steps, car_contacts, backwards_flag, use_ego_color;
   int32_t debug;                // ablation switches for profiling (0 in production)
@@ -141,6 +159,14 @@ __device__ __forceinline__ bool mcr_await(const McrParams& p, int w) {
   for (spin = 0; spin < slow && mcr_behind(p, w, epoch); ++spin) __builtin_amdgcn_s_sleep(127);
   if (spin == slow) { atomicAdd(&p.counters[5], 1ull); mcr_raise(p, ST_SPIN_GIVEUP); return false; }
   return true;
+}
+// Terminal observations, the end of the step: the entry count for the caller, and — only now, the entries' frames are drawn — the news that
+// the envs' staged episodes were consumed (the frames read the episode slots the envs left, which the host refills when it hears).  One workgroup.
+__device__ __forceinline__ void term_finish(const McrParams& p) {
+  if (p.term_cnt == nullptr) return;
+  const int n = min(p.term_cnt[0], p.term_cap);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { const McrTermEnv te = p.term_env[i]; p.consumed_host[te.env] = te.consumed; }
+  if (threadIdx.x == 0) *p.term_count_out = n;
 }
 #define MCR_VORDER_ENV_MASK 0xfffff
 #define MCR_VORDER_SLOT_SHIFT 20

@@ -4,7 +4,9 @@ include/mcr.h.  torch is plumbing only (device memory, streams); every step is t
 Semantics per env follow the reference's `reset()`/`step()` (multi_car_racing.py:340-509) with the
 TimeLimit(1000) of gym_multi_car_racing/__init__.py:8.  With `auto_reset=True` a finished env is re-spawned
 on the device inside the same `step` call (its `obs` row is the first observation of the next episode,
-its `done` row is 1) — the convention of baselines-style VecEnvs.
+its `done` row is 1) — the convention of baselines-style VecEnvs; with `terminal_obs=True` the LAST frame of the finished
+episode (what the reference returns with done = True, multi_car_racing.py:431, :509) is handed out as well, as
+info["terminal_observation"][i] for env info["terminal_env_ids"][i], i < info["terminal_count"].
 
 Every episode is the FIRST episode of a fresh b2World.  The reference reuses one world across reset() (multi_car_racing.py:138,
 341): Box2D's proxy ids — which order same-step tile events, i.e. which of two cars that reach a tile in the same step is its first
@@ -58,7 +60,7 @@ class VecMultiCarRacing:
                  use_random_direction=True, backwards_flag=True, h_ratio=0.25, use_ego_color=False,
                  obs=True, auto_reset=True, max_episode_steps=1000, car_contacts=True,
                  gen_threads=None, async_refill=True, streams=None, refill_lag=64, world_size=1, graph=None,
-                 skid_particles=False):
+                 skid_particles=False, terminal_obs=False, terminal_cap=None):
         if not torch.cuda.is_available():
             raise _lib.McrError("VecMultiCarRacing needs a HIP device: the step path has no CPU fallback")
         self.L = _lib.load()
@@ -111,6 +113,18 @@ class VecMultiCarRacing:
         self.episode_return = torch.zeros((self.B, self.N), dtype=torch.float64, device=self.device)
         self.episode_length = torch.zeros((self.B,), dtype=torch.int32, device=self.device)
         _lib.check(self.L.mcr_set_episode_stats(self.h, ctypes.c_void_p(self.episode_return.data_ptr()), ctypes.c_void_p(self.episode_length.data_ptr())), "mcr_set_episode_stats")
+        # terminal observations (include/mcr.h: mcr_set_terminal_obs): the last frame of every episode that ends in a step, next to the first
+        # frame of the next episode that the env's row of `obs` shows.  Compact: entry i belongs to env terminal_env_ids[i], i < terminal_count.
+        self.terminal_obs = self.terminal_env_ids = self.terminal_count = None
+        if terminal_obs:
+            if not (self.obs_enabled and self.auto_reset):
+                raise ValueError("terminal_obs needs obs=True and auto_reset=True")
+            cap = self.B if terminal_cap is None else max(1, min(int(terminal_cap), self.B))
+            self.terminal_obs = torch.zeros((cap, self.N, 96, 96, 3), dtype=torch.uint8, device=self.device)
+            self.terminal_env_ids = torch.zeros((cap,), dtype=torch.int32, device=self.device)
+            self.terminal_count = torch.zeros((1,), dtype=torch.int32, device=self.device)
+            _lib.check(self.L.mcr_set_terminal_obs(self.h, ctypes.c_void_p(self.terminal_obs.data_ptr()), ctypes.c_void_p(self.terminal_env_ids.data_ptr()),
+                                                   ctypes.c_void_p(self.terminal_count.data_ptr()), cap), "mcr_set_terminal_obs")
         # RNG streams
         self.mt_track = np.zeros((self.B, _lib.MT_WORDS), np.uint32)
         self.mt_draw = np.zeros((self.B, _lib.MT_WORDS), np.uint32)
@@ -314,8 +328,20 @@ class VecMultiCarRacing:
         self._step_idx += 1                   # (only a step that was launched counts: a reported McrError leaves the accounting alone)
         if self.auto_reset:
             self._poll_and_refill()
-        return self.obs, self.reward, self.done, {"TimeLimit.truncated": self.truncated, "episode_return": self.episode_return,
-                                                   "episode_length": self.episode_length}
+        info = {"TimeLimit.truncated": self.truncated, "episode_return": self.episode_return, "episode_length": self.episode_length}
+        if self.terminal_obs is not None:     # (device tensors, like everything else here: entry i < terminal_count is env terminal_env_ids[i])
+            info["terminal_observation"] = self.terminal_obs
+            info["terminal_env_ids"] = self.terminal_env_ids
+            info["terminal_count"] = self.terminal_count
+        return self.obs, self.reward, self.done, info
+
+    def terminal_observations(self):
+        """(env ids [k], frames [k, N, 96, 96, 3]) of the episodes that ended in the last step — what the reference returns as its observation
+        with done = True (multi_car_racing.py:431, :509) — as device tensors; synchronises (reads the count)."""
+        if self.terminal_obs is None:
+            raise _lib.McrError("created without terminal_obs=True")
+        k = int(self.terminal_count.item())
+        return self.terminal_env_ids[:k], self.terminal_obs[:k]
 
     def debug_counters(self):
         """cumulative [envs deferred, envs resumed, contact envs routed to the side stream, env-steps spent frozen
