@@ -144,6 +144,7 @@ def main():
         allowed = sorted(os.sched_getaffinity(0)); total = effective_cpus()
         emu_share = (total, max(1, total // args.emulate_world))
         os.sched_setaffinity(0, set(allowed[:emu_share[1]]))
+    import ctypes
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -317,6 +318,7 @@ def main():
                        "tracks_generated_on_host_in_timed_region_rank0": generated,
                        "env_steps_frozen_waiting_for_host_rank0": int(env.env.debug_counters()[3] - ctr0[3]),
                        "touch_verdict_mismatches_rank0": env.env.verdict_mismatches(),
+                       "status_words_rank0": {k: int(v) for k, v in zip(("waits_given_up", "verdict_mismatches", "manifold_overflows", "event_overflows", "envs_frozen"), env.env.status_words()[:5])},
                        "contact_pass_beside_dynamics": bool(env.env.L.mcr_concurrent_collide(env.env.h)),
                        "contact_envs_per_step_rank0": float(env.env.debug_counters()[2] - ctr0[2]) / K,
                        "deferred_envs_per_step_rank0": float(env.env.debug_counters()[0] - ctr0[0]) / K},
@@ -325,7 +327,7 @@ def main():
         out["config"]["step_blocked_on_refill_s_rank0"] = env.env.blocked_s - blocked0
         out["config"]["host_threads_busy_rank0"] = host_threads               # by thread name (python = the step loop and the refill thread)
         out["config"]["host_cores_busy_rank0"] = round(host_cores, 2)      # CPU time / wall time of the timed region: what one rank asks of the host
-        out["config"]["stream_ordering"] = {1: "phase words", 3: "phase words", 2: "events (stop events)", 0: "events"}.get(int(env.env.L.mcr_step_ordering(env.env.h)), "?") if args.streams != 1 else "single stream"
+        out["config"]["stream_ordering"] = {1: "phase words", 3: "phase words", 2: "events (stop events)", 0: "events", 4: "events (queues shared with another handle)", 6: "events (stop events; queues shared with another handle)"}.get(int(env.env.L.mcr_step_ordering_for(env.env.h, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))), "?") if args.streams != 1 else "single stream"
         if emu:
             out["config"]["emulated_host_share"] = emu
         if args.rccl and world == 1:

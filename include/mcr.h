@@ -204,18 +204,26 @@ int mcr_concurrent_collide(const mcr_env* h);
  *      accepted; on any other stream, and without this bit: events;
  *   2  on the event path, events are completed by the launches they mark (hipExtLaunchKernelGGL) rather than recorded behind them
  *      (MCR_STOP_EVENTS=0 turns it off);
- *   4  kernels do overlap here, but another live handle of this process holds the device's one phase-word token: this handle
- *      runs on events (same results, ~0.02 ms more per step).
+ *   4  kernels do overlap here, but the internal streams of this handle share a hardware queue with those of another live phase-word
+ *      handle of this process (probed pairwise at mcr_create; HIP spreads the streams of a priority class over GPU_MAX_HW_QUEUES queues,
+ *      4 by default): this handle runs on events (same results, ~0.02 ms more per step).  Handles whose streams have queues of their own
+ *      all keep bit 1.
  * A wait that gave up (status word 0) puts the handle on the event path for the rest of its life.
  * gfx950-specific: a phase word is posted with a RELAXED agent-scope store behind the end-of-kernel write-back of the kernels it
  * follows and polled with RELAXED agent-scope loads (sc1 accesses, served by the memory side — the device's coherence point); the
  * release / acquire pair the HIP memory model asks for between kernels of different streams costs +12 us per step (measured) and
  * is not used.  The event path makes no such assumption. */
 int mcr_step_ordering(const mcr_env* h);
+/* The same mask for steps launched on caller stream `stream`: bit 0 only if mcr_bind_stream accepted that stream (a stream that was never
+ * bound, or that the check rejected, steps on events whatever the handle could do). */
+int mcr_step_ordering_for(const mcr_env* h, void* stream);
 /* Check ONCE whether steps launched on caller stream `stream` may use the phase-word ordering: two probe kernels and device
  * synchronisations (~1 ms).  Call it when a stream is first used with the handle (VecMultiCarRacing.step does); mcr_step itself never
  * synchronises: a step on a stream that was not bound, or that the check rejected, orders the internal streams with events. */
 int mcr_bind_stream(mcr_env* h, void* stream);
+/* the per-env records (mcr_common.h: McrEnvState, 48 bytes each: t f64, then steps, slot, staged_ready, consumed, active, resetting, just_reset,
+ * frozen as i32, touch_blocks, bp_step as u32) of the first n_bytes / 48 envs; synchronises.  Diagnostics of the auto-reset's staging protocol. */
+int mcr_debug_read_env_records(mcr_env* h, void* out, int n_bytes);
 /* number of touching car<->car fixture pairs (stored manifolds) per env after the last collide pass */
 int mcr_debug_read_contact_counts(mcr_env* h, int32_t* out /*[num_envs]*/);
 /* Conditions reported by the kernels in mapped host memory (counted on the device, stored with system scope: no PCIe atomics needed),
@@ -224,7 +232,9 @@ int mcr_debug_read_contact_counts(mcr_env* h, int32_t* out /*[num_envs]*/);
  * [1] contact pass vs one-step-ahead touch verdict mismatches — FATAL: the next mcr_step returns MCR_ERR_STATE once per change (the
  *     handle then runs the contact pass in front of the dynamics and orders its streams with events);
  * [2] car<->car manifold store / LDS pool overflows, [3] tile begin-event queue overflows — DEGRADED: a documented capacity was
- *     exceeded and the excess dropped; the rollout goes on, the counts are visible here.
+ *     exceeded and the excess dropped (that env's contacts / tile events of that step are incomplete); [4] envs that FROZE: their episode
+ *     ended before the host had staged the next one (zero outputs until it arrives; stage earlier).  The rollout goes on, the counts are
+ *     visible here; VecMultiCarRacing.step turns every change of [2..4] into an McrWarning.
  * mcr_status copies the cumulative counts (n_words <= 8). */
 int mcr_status(mcr_env* h, uint32_t* out, int n_words);
 /* The sensor predicate of the contact pass (Box2D's b2TestOverlap: GJK b2Distance behind mcr.py:428 -> b2Contact::Update) on

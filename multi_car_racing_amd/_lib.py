@@ -55,10 +55,12 @@ SYMBOLS = {
     "mcr_read_rollout_stats": (_i, [_vp, _vp, _i]),
     "mcr_render": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mcr_debug_read_contact_counts": (_i, [_vp, _vp]),
+    "mcr_debug_read_env_records": (_i, [_vp, _vp, _i]),
     "mcr_debug_read_counters": (_i, [_vp, _vp]),
     "mcr_debug_read_verdict_mismatches": (_i, [_vp, _vp]),
     "mcr_concurrent_collide": (_i, [_vp]),
     "mcr_step_ordering": (_i, [_vp]),
+    "mcr_step_ordering_for": (_i, [_vp, _vp]),
     "mcr_bind_stream": (_i, [_vp, _vp]),
     "mcr_debug_overlap": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
     "mcr_status": (_i, [_vp, _vp, _i]),

@@ -1424,7 +1424,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
         E->t = es.t + 1.0 / MCR_FPS;
         if (p.actions) E->steps = es.steps + 1;
         E->just_reset = 0;
-        if (done && p.auto_reset) { E->active = 0; E->frozen = 1; if (p.part_next) { p.part[env] = 0; p.part_next[env] = 0; } }   // no staged episode yet (host refill late): frozen until it arrives, see `thaw` (a frozen env is the main launch's)
+        if (done && p.auto_reset) { E->active = 0; E->frozen = 1; mcr_raise(p, ST_FROZEN); if (p.part_next) { p.part[env] = 0; p.part_next[env] = 0; } }   // no staged episode yet (host refill late): frozen until it arrives, see `thaw` (a frozen env is the main launch's)
       }
       // raster launch order: zoomed-out frames (first second of an episode, :540-542) cost several times a normal
       // one, so their workgroups go FIRST (front of vorder) and cannot end up as the launch's tail

@@ -87,8 +87,15 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // could starve a contact pass dispatched second).  After a reported give-up the handle stays with the contact pass in front.
 static bool cc_active(const mcr_env* h) { return h->split && h->concurrent_collide; }
 
-#include <atomic>
-static std::atomic<int> g_soft_handles[64];     // live handles per device that order their streams with phase words (at most one: mcr_create)
+#include <mutex>
+#include <algorithm>
+// live handles of this process that order their streams with phase words.  Several per device are fine AS LONG AS their internal streams sit
+// on hardware queues of their own (probed pairwise in mcr_create): an await at the head of a queue that two handles share could hold back the
+// very kernel another handle's await waits for (host threads stepping two handles interleave their enqueues freely) — a cycle that only the
+// wait bound would break.  HIP multiplexes the streams of a priority class over a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default):
+// where the probe finds two handles' streams on one queue, the later handle orders its streams with events.
+static std::mutex g_soft_mu;
+static std::vector<mcr_env*> g_soft_list;
 
 // Do kernels of two streams really run side by side in this process?  Under a counter-collecting profiler, a debugger or
 // AMD_SERIALIZE_KERNEL they do not — and the cc_mode step (the main dynamics waits inside the kernel for words the
@@ -229,7 +236,17 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
         // handle A's waiting kernel can sit in front of the post handle B's join waits for, which in turn sits in front of A's dynamics:
         // a cycle that only the wait bound would break.  Further handles order their streams with events (every wait there is for work
         // enqueued earlier).
-        if (h->soft_sync) { if (g_soft_handles[cfg->device & 63].fetch_add(1) == 0) h->soft_token = true; else { g_soft_handles[cfg->device & 63].fetch_sub(1); h->soft_sync = false; h->soft_denied = true; } }
+        if (h->soft_sync) {
+          std::lock_guard<std::mutex> lk(g_soft_mu);
+          bool own_queues = !getenv("MCR_ONE_SOFT_HANDLE");
+          for (mcr_env* o : g_soft_list)
+            if (own_queues && o->cfg.device == cfg->device)
+              own_queues = kernels_overlap(h->s_side, o->s_side) && kernels_overlap(h->s_side, o->s_defer) && kernels_overlap(h->s_defer, o->s_side) && kernels_overlap(h->s_defer, o->s_defer) &&
+                           kernels_overlap(o->s_side, h->s_side) && kernels_overlap(o->s_defer, h->s_defer);
+          bool other = false; for (mcr_env* o : g_soft_list) other = other || o->cfg.device == cfg->device;
+          if (own_queues || !other) { h->soft_token = true; g_soft_list.push_back(h); }
+          else { h->soft_sync = false; h->soft_denied = true; }
+        }
         // (at 8 cars per env the one-step-ahead touch verdict — a second pass over up to 28 car pairs — costs more than the
         // contact pass gains by running beside the dynamics: measured at N = 8, round 2: 3.66 vs 4.28 M env-steps/s.  Round 3 tried a
         // CONSERVATIVE verdict there instead — bounding discs + car boxes, no narrowphase, the contact chain taking every env it
@@ -251,7 +268,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
 
 extern "C" int mcr_destroy(mcr_env* h) {
   if (!h) return MCR_ERR_ARG;
-  if (h->soft_token) g_soft_handles[h->cfg.device & 63].fetch_sub(1);
+  if (h->soft_token) { std::lock_guard<std::mutex> lk(g_soft_mu); g_soft_list.erase(std::remove(g_soft_list.begin(), g_soft_list.end(), h), g_soft_list.end()); }
   (void)hipSetDevice(h->cfg.device);
   (void)hipDeviceSynchronize();
   for (auto& g : h->sg) if (g.valid) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); g.valid = false; }
@@ -556,7 +573,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
 static int check_status(mcr_env* h) {
   static const char* what[MCR_STATUS_WORDS] = {
       "a kernel gave up waiting for the kernels of another stream (three-chain step: the contact pass of an env, a phase word); the handle now runs the contact pass in front and orders its streams with events",
-      "the contact pass disagreed with the one-step-ahead touch verdict", "", "", "", "", "", ""};
+      "the contact pass disagreed with the one-step-ahead touch verdict; the handle now runs the contact pass in front of the dynamics", "", "", "", "", "", ""};
   // FATAL: a wait that gave up, a verdict mismatch — results of that step are wrong.  The overflow words (ST_CC_OVERFLOW, ST_EVENT_OVERFLOW) are
   // documented capacity deviations (the excess was dropped and flagged): the rollout goes on, mcr_status / VecMultiCarRacing.status_words show them.
   for (int i : {(int)ST_SPIN_GIVEUP, (int)ST_VERDICT}) {
@@ -564,6 +581,7 @@ static int check_status(mcr_env* h) {
     if (v != h->status_seen[i]) {
       h->status_seen[i] = v;
       if (i == ST_SPIN_GIVEUP) { h->concurrent_collide = false; h->soft_sync = false; h->verdict_fresh = false; }
+      if (i == ST_VERDICT) { h->concurrent_collide = false; h->verdict_fresh = false; }     // (the contact pass in front from now on: it marks the contact chain's envs itself)
       g_err = std::string("results of an earlier step are wrong: ") + what[i] + " (" + std::to_string(v) + " so far)";
       return MCR_ERR_STATE;
     }
@@ -659,6 +677,9 @@ extern "C" int mcr_bind_stream(mcr_env* h, void* stream) {
     if (cap != hipStreamCaptureStatusNone) { g_err = "mcr_bind_stream on a capturing stream"; return MCR_ERR_STATE; }
     HIPCHK(hipSetDevice(h->cfg.device));
     ok = kernels_overlap(h->s_side, st) && kernels_overlap(h->s_defer, st);
+    // ... and of every other phase-word handle of the device: their awaits must not sit in front of this stream's posts either
+    std::lock_guard<std::mutex> lk(g_soft_mu);
+    for (mcr_env* o : g_soft_list) if (ok && o != h && o->cfg.device == h->cfg.device) ok = kernels_overlap(o->s_side, st) && kernels_overlap(o->s_defer, st);
   }
   if (h->bound.size() >= 64) h->bound.erase(h->bound.begin());
   h->bound.emplace_back(st, ok);
@@ -973,10 +994,21 @@ extern "C" int mcr_step_ordering(const mcr_env* h) {
   if (!h || !h->split) return 0;
   return ((h->soft_sync && h->use_graph <= 0) ? 1 : 0) | (h->stop_events ? 2 : 0) | (h->soft_denied ? 4 : 0);
 }
+extern "C" int mcr_step_ordering_for(const mcr_env* h, void* stream) {
+  if (!h || !h->split) return 0;
+  const int all = mcr_step_ordering(h);
+  return stream_bound(h, (hipStream_t)stream) ? all : (all & ~1);
+}
 extern "C" int mcr_debug_read_verdict_mismatches(mcr_env* h, uint64_t* out) {
   if (!h || !out) return MCR_ERR_ARG;
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(out, h->P.counters + 4, sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return MCR_OK;
+}
+extern "C" int mcr_debug_read_env_records(mcr_env* h, void* out, int n_bytes) {
+  if (!h || !out || n_bytes < 0) return MCR_ERR_ARG;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out, h->P.env, std::min((size_t)n_bytes, sizeof(McrEnvState) * (size_t)h->cfg.num_envs), hipMemcpyDeviceToHost));
   return MCR_OK;
 }
 extern "C" int mcr_debug_read_contact_counts(mcr_env* h, int32_t* out) {

@@ -106,6 +106,7 @@ enum { ST_SPIN_GIVEUP = 0,     // a kernel gave up waiting for another stream's 
        ST_VERDICT = 1,         // the contact pass disagreed with the one-step-ahead touch verdict
        ST_CC_OVERFLOW = 2,     // more touching car<->car fixture pairs than the manifold store / the LDS pool holds: the excess was dropped
        ST_EVENT_OVERFLOW = 3,  // more tile begin events in one env-step than the replay buffer holds
+       ST_FROZEN = 4,          // an env ended its episode before the host had staged the next one: it froze (zero outputs) until the episode arrived
        MCR_STATUS_WORDS = 8,
        // behind the status words, in the same mapped allocation: counts the host sizes the NEXT step's list launches by (read without synchronising)
        HC_CONTACT_ENVS = 0,    // the length of the last step's contact list

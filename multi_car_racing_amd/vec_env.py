@@ -96,6 +96,7 @@ class VecMultiCarRacing:
                           float(h_ratio), int(bool(skid_particles)), 0)
         self.h = ctypes.c_void_p()
         _lib.check(self.L.mcr_create(ctypes.byref(cfg), ctypes.byref(self.h)), "mcr_create")
+        self._status_now = np.zeros(8, np.uint32); self._status_seen = np.zeros(8, np.uint32)
         self._bound_streams = set()   # caller streams already handed to mcr_bind_stream (the check synchronises the device: once per stream)
         if int(self.L.mcr_step_ordering(self.h)) & 4:
             import warnings
@@ -326,6 +327,7 @@ class VecMultiCarRacing:
                                    ctypes.c_void_p(self.reward.data_ptr()), ctypes.c_void_p(self.done.data_ptr()),
                                    ctypes.c_void_p(self.truncated.data_ptr()), ctypes.c_void_p(st.cuda_stream)), "mcr_step")
         self._step_idx += 1                   # (only a step that was launched counts: a reported McrError leaves the accounting alone)
+        self._warn_degraded()
         if self.auto_reset:
             self._poll_and_refill()
         info = {"TimeLimit.truncated": self.truncated, "episode_return": self.episode_return, "episode_length": self.episode_length}
@@ -343,6 +345,22 @@ class VecMultiCarRacing:
         k = int(self.terminal_count.item())
         return self.terminal_env_ids[:k], self.terminal_obs[:k]
 
+    _DEGRADED = {2: "more touching car<->car fixture pairs in an env than the manifold store holds (MCR_CC_MAX): the excess contacts were dropped — that env's "
+                    "physics deviates from the reference from here on",
+                 3: "more tile begin events in one env-step than the replay buffer holds: the excess events (tile visits, rewards) were dropped",
+                 4: "an env ended its episode before the host had staged its next one and froze (zero reward, done = 0, stale frame) until the episode "
+                    "arrived: the track generator is behind the device (more gen_threads, async_refill=True, a longer TimeLimit, or fence the stepping loop)"}
+
+    def _warn_degraded(self):
+        """The capacity / starvation conditions the kernels count without failing (include/mcr.h: mcr_status words 2..4): say so, once per change.
+        Reads mapped host memory — no synchronisation; a condition raised by a step still in flight surfaces a call later."""
+        _lib.check(self.L.mcr_status(self.h, _lib.ptr(self._status_now), 8), "mcr_status")
+        for w, what in self._DEGRADED.items():
+            if self._status_now[w] != self._status_seen[w]:
+                import warnings
+                warnings.warn(f"{what} ({int(self._status_now[w])} so far)", _lib.McrWarning, stacklevel=3)
+                self._status_seen[w] = self._status_now[w]
+
     def debug_counters(self):
         """cumulative [envs deferred, envs resumed, contact envs routed to the side stream, env-steps spent frozen
         waiting for a staged episode] (synchronises)"""
@@ -359,7 +377,8 @@ class VecMultiCarRacing:
 
     def status_words(self):
         """cumulative status words of include/mcr.h `mcr_status`: [0] in-kernel waits given up, [1] touch-verdict mismatches,
-        [2] car<->car manifold overflows, [3] begin-event queue overflows (all 0 in a healthy rollout; does not synchronise)"""
+        [2] car<->car manifold overflows, [3] begin-event queue overflows, [4] envs that froze waiting for a staged episode (all 0 in a healthy
+        rollout; does not synchronise)"""
         out = np.zeros(8, np.uint32)
         _lib.check(self.L.mcr_status(self.h, _lib.ptr(out), 8), "mcr_status")
         return out

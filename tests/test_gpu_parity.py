@@ -790,9 +790,11 @@ def test_status_word_reports_a_stalled_stream(torch_cuda, lib):
     env.close()
 
 
-def test_second_handle_on_a_device_orders_its_streams_with_events(torch_cuda, lib):
-    """One phase-word handle per device and process (mcr_hip.hip: a waiting kernel of one handle could otherwise sit in front of a
-    kernel another handle's step waits for); two handles stepped alternately on one stream compute the same thing."""
+def test_two_handles_on_a_device(torch_cuda, lib):
+    """Several phase-word handles per device are fine as long as their internal streams have hardware queues of their own (probed at
+    mcr_create: an await of one handle at the head of a shared queue could otherwise hold back a kernel another handle's step waits
+    for); a handle that shares one SAYS that it runs on events (ordering bit 2, McrWarning).  Either way two handles compute the same
+    thing — stepped alternately on one stream, and double-buffered: each on a stream of its own, both steps in flight at once."""
     import gc
     torch = torch_cuda
     gc.collect()
@@ -801,9 +803,13 @@ def test_second_handle_on_a_device_orders_its_streams_with_events(torch_cuda, li
     with warnings.catch_warnings(record=True) as caught:
         warnings.simplefilter("always")
         b_env = _make(256, 2, 9, contacts=True, streams=2)
+    ob_ = int(b_env.L.mcr_step_ordering(b_env.h))
     if a_env.L.mcr_concurrent_collide(a_env.h):
-        assert a_env.L.mcr_step_ordering(a_env.h) & 1 and not (b_env.L.mcr_step_ordering(b_env.h) & 1)
-        assert b_env.L.mcr_step_ordering(b_env.h) & 4 and any(issubclass(w.category, lib.McrWarning) for w in caught), "the second handle must SAY that it runs on events"
+        assert a_env.L.mcr_step_ordering(a_env.h) & 1
+        assert bool(ob_ & 1) != bool(ob_ & 4), f"the second handle keeps phase words or says that it shares queues, not both / neither ({ob_})"
+        if ob_ & 4:
+            assert any(issubclass(w.category, lib.McrWarning) for w in caught), "the second handle must SAY that it runs on events"
+    print("second handle ordering:", ob_)
     oa, ob = a_env.reset().clone(), b_env.reset().clone()
     assert torch.equal(oa, ob)
     g = torch.Generator(device="cuda"); g.manual_seed(4)
@@ -812,11 +818,108 @@ def test_second_handle_on_a_device_orders_its_streams_with_events(torch_cuda, li
         o1, r1, d1, _ = a_env.step(a)
         o2, r2, d2, _ = b_env.step(a)
         assert torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(o1, o2), k
-    a_env.close()
-    c_env = _make(64, 2, 9, contacts=True, streams=2)        # the token is free again
+    # double-buffered: A steps on stream sa while B steps on stream sb; a third handle (one stream) is the reference
+    ref = _make(256, 2, 9, contacts=True, streams=1); ref.reset()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    g2 = torch.Generator(device="cuda"); g2.manual_seed(4)
+    acts = []
+    for k in range(60):
+        a = torch.rand((256, 2, 3), device="cuda", generator=g2); a[..., 0] = a[..., 0] * 2 - 1; acts.append(a)
+    for a in acts:
+        ref.step(a)
+    torch.cuda.synchronize()
+    g3 = torch.Generator(device="cuda"); g3.manual_seed(11)
+    for k in range(120):
+        a = torch.rand((256, 2, 3), device="cuda", generator=g3); a[..., 0] = a[..., 0] * 2 - 1
+        torch.cuda.synchronize()
+        with torch.cuda.stream(sa):
+            o1, r1, d1, _ = a_env.step(a)
+        with torch.cuda.stream(sb):
+            o2, r2, d2, _ = b_env.step(a)
+        o3, r3, d3, _ = ref.step(a)
+        torch.cuda.synchronize()
+        assert torch.equal(r1, r3) and torch.equal(d1, d3) and torch.equal(o1, o3), k
+        assert torch.equal(r2, r3) and torch.equal(d2, d3) and torch.equal(o2, o3), k
+    st = np.zeros(8, np.uint32)
+    for e in (a_env, b_env):
+        lib.check(e.L.mcr_status(e.h, lib.ptr(st), 8)); assert not st[:4].any(), st
+    a_env.close(); ref.close()
+    c_env = _make(64, 2, 9, contacts=True, streams=2)
     if c_env.L.mcr_concurrent_collide(c_env.h):
-        assert c_env.L.mcr_step_ordering(c_env.h) & 1
+        assert c_env.L.mcr_step_ordering(c_env.h) & 1 or c_env.L.mcr_step_ordering(c_env.h) & 4
     c_env.close(); b_env.close()
+
+
+def test_phase_words_beside_a_foreign_stream_that_saturates_the_cus(torch_cuda, lib):
+    """The actor + learner deployment: another stream of the process keeps every CU busy with large GEMMs for the whole of a three-chain
+    rollout.  The step's phase-word ordering must hold (bit 0 for the caller's stream throughout), no wait may give up, no status
+    word may be set, and the results must be bit-identical to a single-stream handle that ran alone."""
+    import time
+    torch = torch_cuda
+    B, N, steps = 1024, 2, 400
+    env = _make(B, N, 21, contacts=True, streams=2, auto_reset=True, max_episode_steps=150)
+    ref = _make(B, N, 21, contacts=True, streams=1, auto_reset=True, max_episode_steps=150)
+    env.reset(); ref.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(8)
+    acts = []
+    for k in range(steps):
+        a = torch.rand((B, N, 3), device="cuda", generator=g); a[..., 0] = a[..., 0] * 2 - 1; a[:, 1, 1] = 1.0
+        acts.append(a)
+    outs = []
+    for k, a in enumerate(acts):
+        o, r, d, _ = ref.step(a); outs.append((r.clone(), d.clone(), o[::64].clone()))
+        if k % 150 == 149:                                    # every env was just re-spawned: have the next episodes staged before the host runs on
+            torch.cuda.synchronize(); ref._poll_and_refill()  # (1024 tracks take the host longer than 150 of these small steps take the device: envs would freeze)
+    torch.cuda.synchronize()
+    st_main = torch.cuda.current_stream()
+    env.step(acts[0]); torch.cuda.synchronize()              # (binds the caller's stream)
+    if not (env.L.mcr_step_ordering_for(env.h, ctypes.c_void_p(st_main.cuda_stream)) & 1):
+        env.close(); ref.close(); pytest.skip("the step uses events here")
+    env.close()
+    env = _make(B, N, 21, contacts=True, streams=2, auto_reset=True, max_episode_steps=150); env.reset()
+    load = torch.cuda.Stream()
+    x = torch.randn((8192, 8192), dtype=torch.bfloat16, device="cuda")
+    with torch.cuda.stream(load):
+        y = x @ x
+    torch.cuda.synchronize()
+    evs = []
+    t0 = time.perf_counter()
+    for k, a in enumerate(acts):
+        with torch.cuda.stream(load):                       # keep ~6 GEMMs (each fills the machine) queued on the foreign stream
+            while len(evs) < 6:
+                y = x @ x
+                e = torch.cuda.Event(); e.record(load); evs.append(e)
+        o, r, d, _ = env.step(a)
+        assert env.L.mcr_step_ordering_for(env.h, ctypes.c_void_p(st_main.cuda_stream)) & 1, f"step {k}: fell back to events"
+        if k % 8 == 7:
+            st_main.synchronize()
+        if k % 150 == 149:
+            st_main.synchronize(); env._poll_and_refill()
+        rr, dd, oo = outs[k]
+        if not (torch.equal(r, rr) and torch.equal(d, dd) and torch.equal(o[::64], oo)):
+            torch.cuda.synchronize()
+            bad = (o[::64] != oo).flatten(1).any(1).nonzero().flatten().tolist()
+            stale = [bool(torch.equal(o[::64][i], outs[k - 1][2][i])) for i in bad[:8]]
+            lib.check(env.L.mcr_status(env.h, lib.ptr(np.zeros(8, np.uint32)), 8))
+            diag = {}
+            rec = np.zeros((B, 12), np.int32)                         # McrEnvState: t (2 words), steps, slot, staged_ready, consumed, active, resetting, just_reset, frozen, 2 x u32
+            lib.check(env.L.mcr_debug_read_env_records(env.h, lib.ptr(rec), rec.nbytes))
+            for name, col in (("steps", 2), ("slot", 3), ("staged_ready", 4), ("consumed", 5), ("active", 6), ("resetting", 7), ("just_reset", 8), ("frozen", 9)):
+                diag[name] = dict(zip(*[x.tolist() for x in np.unique(rec[:, col], return_counts=True)]))
+            diag["episodes_generated"] = int(env.episodes_generated)
+            raise AssertionError(f"env records {diag} "
+                                 f"step {k} differs from the handle that ran alone: reward {torch.equal(r, rr)} done {torch.equal(d, dd)}; sampled envs with "
+                                 f"different frames {bad[:16]} of {o[::64].shape[0]} (equal to the previous step's frame: {stale}); frozen env-steps "
+                                 f"{int(env.debug_counters()[3])}, counters {env.debug_counters().tolist()}, status {env.status_words().tolist()}")
+        evs = [e for e in evs if not e.query()]
+    torch.cuda.synchronize()
+    loaded = time.perf_counter() - t0
+    st = np.zeros(8, np.uint32)
+    lib.check(env.L.mcr_status(env.h, lib.ptr(st), 8))
+    assert not st[:4].any(), f"status words set beside the foreign stream: {st}"
+    assert env.verdict_mismatches() == 0
+    print(f"three-chain step beside a saturating foreign stream: {B * steps / loaded / 1e6:.2f} M env-steps/s (B = {B})")
+    env.close(); ref.close()
 
 
 def test_a_busy_caller_stream_is_waited_out_not_reported(torch_cuda, lib):

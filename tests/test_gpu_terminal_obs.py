@@ -98,7 +98,7 @@ def test_terminal_frames_when_cars_leave_the_playfield(torch_cuda, oracle):
             st = env.get_state()["bodies"].copy()
             for e in range(k % 5, B, 5):
                 car = (e + k) % N
-                st[e, car, :, 0] += 400.0 if e % 2 else -400.0; st[e, car, :, 1] += 120.0
+                st[e, car, :, 0] += 800.0 if e % 2 else -800.0; st[e, car, :, 1] += 120.0
                 for b in range(5):
                     fol[e].o.set_body(car, b, st[e, car, b])
                 moved.append((k, e))
