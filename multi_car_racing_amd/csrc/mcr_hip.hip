@@ -255,7 +255,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
         // contact chain itself — 585 us for its slowest wavefront, a sequential Gauss-Seidel over the contacts between the joint sweeps)
         // (round 3, phase-word path, contact pass beside / in front of the dynamics: N = 5 8.99 / 8.50 M env-steps/s, N = 6 7.87 / 7.49,
         // N = 7 7.16 / 6.80, N = 8 4.90 / 5.47 — up to seven cars per env it runs beside)
-        h->concurrent_collide = N <= 7 && !getenv("MCR_SEQUENTIAL_COLLIDE") && (B * G + 63) / 64 <= h->simd_count && kernels_overlap(h->s_defer, h->s_side);
+        h->concurrent_collide = N <= (getenv("MCR_CC_MAXN") ? atoi(getenv("MCR_CC_MAXN")) : 7) && !getenv("MCR_SEQUENTIAL_COLLIDE") && (B * G + 63) / 64 <= h->simd_count && kernels_overlap(h->s_defer, h->s_side);
         h->split = true;
       } else (void)hipStreamDestroy(h->s_side);
     }

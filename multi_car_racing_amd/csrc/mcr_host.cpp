@@ -266,6 +266,7 @@ bool track_attempt(uint32_t* mt, std::vector<TrackPt>& lap) {
   std::vector<TrackPt> path; path.reserve(2600);
   double x = 1.5 * kTrackRad, y = 0, beta = 0;
   long gate = 0; int laps = 0; int budget = 2500; bool below_axis = false;
+  double trig_beta = -1.0, trig_c = 0.0, trig_s = 0.0;
   for (;;) {
     double alpha = atan2(y, x);
     if (below_axis && alpha > 0) { ++laps; below_axis = false; }
@@ -283,7 +284,8 @@ bool track_attempt(uint32_t* mt, std::vector<TrackPt>& lap) {
       if (!wrapped) break;
       alpha -= 2 * PI;
     }
-    double head_x = cos(beta), head_y = sin(beta);
+    if (beta != trig_beta) { trig_c = cos(beta); trig_s = sin(beta); trig_beta = beta; }   // (the heading only turns while the walk is off the gate's line: same argument, same libm value)
+    double head_x = trig_c, head_y = trig_s;
     double fwd_x = -head_y, fwd_y = head_x;
     double to_cp_x = gate_px - x, to_cp_y = gate_py - y;
     double lateral = head_x * to_cp_x + head_y * to_cp_y;
@@ -379,11 +381,13 @@ extern "C" int mcr_episode_generate(uint32_t* mt_track, int num_agents, int cw, 
   float* TA = (float*)(blob + MCR_OFF_TAABB); float* VA = (float*)(blob + MCR_OFF_TVA); float* VB = (float*)(blob + MCR_OFF_TVB);
   float* NA = (float*)(blob + MCR_OFF_TNA); float* NB = (float*)(blob + MCR_OFF_TNB); uint32_t* TC = (uint32_t*)(blob + MCR_OFF_TCNT);
   int q = 0;
+  // cos / sin of every tile's heading ONCE (the reference evaluates math.cos(beta1), math.cos(beta2) per tile, :300-307: tile i's beta2 is tile
+  // i-1's beta1 — the same argument, the same libm value; half of this loop's libm calls, which are what the generator spends its time in)
+  for (int i = 0; i < T; ++i) { TCs[i] = cos(lap[i].beta); TSn[i] = sin(lap[i].beta); }
   for (int i = 0; i < T; ++i) {
     const TrackPt& a = lap[i]; const TrackPt& b = lap[wrap(i - 1, T)];
     TX[i] = a.x; TY[i] = a.y; TB[i] = a.beta; TAl[i] = a.alpha;
-    double c1 = cos(a.beta), s1 = sin(a.beta), c2 = cos(b.beta), s2 = sin(b.beta);
-    TCs[i] = c1; TSn[i] = s1;
+    const double c1 = TCs[i], s1 = TSn[i], c2 = TCs[wrap(i - 1, T)], s2 = TSn[wrap(i - 1, T)];
     double vx[4] = {a.x - kTrackWidth * c1, a.x + kTrackWidth * c1, b.x + kTrackWidth * c2, b.x - kTrackWidth * c2};
     double vy[4] = {a.y - kTrackWidth * s1, a.y + kTrackWidth * s1, b.y + kTrackWidth * s2, b.y - kTrackWidth * s2};
     float fx[4], fy[4];

@@ -99,10 +99,10 @@ def _contact_envs(torch, B, N, seed, steps, max_steps, car1_floors):
 
 
 def _run_sampled(torch, O, B, N, seed, steps, n_sample, max_steps, masked_reset_at=(), state_every=50, car1_floors=False,
-                 prefer=None):
+                 prefer=None, with_obs=True):
     from multi_car_racing_amd.vec_env import VecMultiCarRacing
     env = VecMultiCarRacing(B, N, seed=seed, use_random_direction=True, auto_reset=True, max_episode_steps=max_steps,
-                            car_contacts=True, async_refill=True, streams=2)
+                            car_contacts=True, async_refill=True, streams=2, obs=with_obs)
     obs = env.reset()
     rs = np.random.RandomState(seed + 99)
     if prefer is not None and len(prefer):                 # half the sample from the preferred envs, the rest at random
@@ -113,9 +113,10 @@ def _run_sampled(torch, O, B, N, seed, steps, n_sample, max_steps, masked_reset_
         idx = np.sort(rs.choice(B, n_sample, replace=False))
     idx_t = torch.from_numpy(idx).cuda()
     fol = [_Follower(O, N, seed, int(g), max_steps) for g in idx]
-    o0 = obs[idx_t].cpu().numpy()
-    for j, f in enumerate(fol):
-        _cmp_pixels(o0[j], f.first_obs, f.first_amb, f"reset env {f.g}")
+    if with_obs:
+        o0 = obs[idx_t].cpu().numpy()
+        for j, f in enumerate(fol):
+            _cmp_pixels(o0[j], f.first_obs, f.first_amb, f"reset env {f.g}")
     g = torch.Generator(device="cuda"); g.manual_seed(seed)
     threads = os.cpu_count() or 1
     n_resets = n_contacts = 0
@@ -123,6 +124,8 @@ def _run_sampled(torch, O, B, N, seed, steps, n_sample, max_steps, masked_reset_
         a = _actions(torch, g, B, N, car1_floors)
         obs, rew, done, info = env.step(a)
         check_px = (k % state_every == state_every - 1)
+        check_st = check_px
+        check_px = check_px and with_obs
         a_s = a[idx_t].cpu().numpy()
         rw = rew[idx_t].cpu().numpy(); dn = done[idx_t].cpu().numpy().astype(bool); tr = info["TimeLimit.truncated"][idx_t].cpu().numpy().astype(bool)
         o_obs, o_amb, o_rew, o_done = O.step_batch([f.o for f in fol], a_s, np.full(n_sample, int(check_px), np.uint8), threads=threads)
@@ -135,23 +138,25 @@ def _run_sampled(torch, O, B, N, seed, steps, n_sample, max_steps, masked_reset_
             if d:
                 resets.append(j)
         if check_px or resets:
-            got = obs[idx_t].cpu().numpy()
+            got = obs[idx_t].cpu().numpy() if with_obs else None
             for j, f in enumerate(fol):
                 if j in resets:
                     f.new_episode(); n_resets += 1
-                    _cmp_pixels(got[j], f.first_obs, f.first_amb, f"step {k} env {f.g} first frame after auto-reset")
+                    if with_obs:
+                        _cmp_pixels(got[j], f.first_obs, f.first_amb, f"step {k} env {f.g} first frame after auto-reset")
                 elif check_px:
                     _cmp_pixels(got[j], o_obs[j], o_amb[j], f"step {k} env {f.g}")
-        if check_px:
+        if check_st:
             _cmp_state(env, fol, idx, f"step {k}")
         if k in masked_reset_at:                       # masked reset of a random quarter of the batch incl. some followers
             m = (rs.uniform(size=B) < 0.25); m[idx[::3]] = True
             obs = env.reset_envs(torch.from_numpy(m.astype(np.uint8)).cuda())
-            got = obs[idx_t].cpu().numpy()
+            got = obs[idx_t].cpu().numpy() if with_obs else None
             for j, f in enumerate(fol):
                 if m[f.g]:
                     f.new_episode(); n_resets += 1
-                    _cmp_pixels(got[j], f.first_obs, f.first_amb, f"masked reset at step {k} env {f.g}")
+                    if with_obs:
+                        _cmp_pixels(got[j], f.first_obs, f.first_amb, f"masked reset at step {k} env {f.g}")
             _cmp_state(env, fol, idx, f"after masked reset at step {k}")
     frozen = int(env.debug_counters()[3])
     assert env.verdict_mismatches() == 0, "the touch verdict of the main launches disagreed with the contact pass"
@@ -177,6 +182,17 @@ def test_benched_config_b4096_contacts_sample(torch_cuda, oracle):
                                                 max_steps=120, state_every=40, car1_floors=True, prefer=hot)
     assert n_resets >= 96 and n_contacts > 0, (n_resets, n_contacts)
     assert frozen == 0
+
+
+def test_physics_only_b4096_sampled_oracles(torch_cuda, oracle):
+    """BASELINE configs[4] at full size: num_agents=2, batch=4096, obs=none (the physics-only step bench.py --obs 0 times) — 64 sampled envs
+    == their oracles (rewards, done, truncation every step; full rigid-body and bookkeeping state every 50) across a TimeLimit round with its
+    4096 device-side auto-resets and a masked reset; half of the sample are envs known to hold touching car<->car pairs."""
+    prefer = _contact_envs(torch_cuda, 4096, 2, seed=23, steps=240, max_steps=200, car1_floors=True)
+    n_resets, n_contacts, frozen = _run_sampled(torch_cuda, oracle, B=4096, N=2, seed=23, steps=260, n_sample=64, max_steps=200,
+                                                masked_reset_at=(120,), car1_floors=True, prefer=prefer, with_obs=False)
+    assert n_resets >= 64 and frozen == 0
+    assert n_contacts > 0, "no sampled env ever held a car<->car contact"
 
 
 @pytest.mark.parametrize("knobs, ordering", [({}, 1), ({"MCR_SOFT_SYNC": "0"}, 2), ({"MCR_SOFT_SYNC": "0", "MCR_STOP_EVENTS": "0"}, 0)])
