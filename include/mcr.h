@@ -84,6 +84,21 @@ int mcr_episode_unpack(const void* blob, int32_t* T, int32_t* P, int32_t* cw, do
                        float* quads /*[P*8]*/, uint32_t* quad_meta /*[P]*/, double* spawn /*[8*3]*/,
                        double* track_alpha /*[T]*/);
 
+/* ---- the env's b2World across reset() (NO GPU needed).  The reference keeps ONE world for the life of an env (multi_car_racing.py:138; _destroy
+ * :173-181 and reset :341 destroy and re-create its bodies): from the second episode on, the fixtures' broadphase proxy ids come off the dynamic
+ * tree's free list, and the ids order the contact callbacks of a step — which of two cars that reach a tile in the same step is its first visitor
+ * (:113-120).  A handle's episodes are by default each the first of a fresh world; a caller that wants the reference's behaviour keeps an
+ * mcr_world next to its env: mcr_world_reset(w, blob) before staging an episode blob (destroys the old episode's proxies and creates the new
+ * one's in the reference's order; writes the ids into the blob, where the contact pass finds them), mcr_world_step(w, bodies) after EVERY step
+ * and after the reset's own step, with the bodies of mcr_get_state (b2Body::SynchronizeFixtures -> b2DynamicTree::MoveProxy in b2World::Solve's
+ * order).  The single-env facade (env.py) does; the batched envs do not (the tree would have to be advanced on the device every step). */
+typedef struct mcr_world mcr_world;
+mcr_world* mcr_world_create(int num_agents);
+void mcr_world_destroy(mcr_world* w);
+int mcr_world_reset(mcr_world* w, void* blob_io);
+int mcr_world_step(mcr_world* w, const float* bodies /*[N,5,6]*/);
+int mcr_world_proxy_ids(const mcr_world* w, int32_t* out, int cap);
+
 /* ---- device side */
 /* Copy n host blobs into the STAGED slot of envs env_ids[0..n) (async on stream; blobs must stay valid
  * until the stream reaches this point — use pinned memory for real overlap). */
@@ -240,7 +255,8 @@ int mcr_status(mcr_env* h, uint32_t* out, int n_words);
 /* The sensor predicate of the contact pass (Box2D's b2TestOverlap: GJK b2Distance behind mcr.py:428 -> b2Contact::Update) on
  * caller-supplied cases, for differential tests: case i = a tile given by its 4 points quads[i][8] (host, f32; the hull is
  * built as the episode generator builds it) against car fixture `fixture` (0..3 hull polygons, 4 the wheel box) of a body
- * whose origin and angle are poses[i][3]; out[i] = touching (host).  Synchronous. */
+ * whose origin and angle are poses[i][3]; out[i] = touching (host).  fixture + 8: the car fixture is fixtureA (b2TestOverlap(fixture, tile):
+ * what a world that lives across reset() can ask for, mcr_world above).  Synchronous. */
 int mcr_debug_overlap(mcr_env* h, int n, const float* quads, const float* poses, int fixture, uint8_t* out);
 #define MCR_TIMING_SLOTS 8
 int mcr_timing_read(mcr_env* h, double* ms_out /*[MCR_TIMING_SLOTS]*/, int64_t* launches_out /*[MCR_TIMING_SLOTS]*/);

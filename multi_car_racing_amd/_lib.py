@@ -64,6 +64,11 @@ SYMBOLS = {
     "mcr_bind_stream": (_i, [_vp, _vp]),
     "mcr_debug_overlap": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
     "mcr_status": (_i, [_vp, _vp, _i]),
+    "mcr_world_create": (_vp, [_i]),
+    "mcr_world_destroy": (None, [_vp]),
+    "mcr_world_reset": (_i, [_vp, _vp]),
+    "mcr_world_step": (_i, [_vp, _vp]),
+    "mcr_world_proxy_ids": (_i, [_vp, _vp, _i]),
     "mcr_debug_read_dynamics_stamps": (_i, [_vp, _vp, _i]),
     "mcr_timing_read": (_i, [_vp, _vp, _vp]),
     "mcr_set_step_graph": (_i, [_vp, _i]),

@@ -8,7 +8,7 @@ LIB = os.path.join(HERE, "_lib", "libmcr_hip.so")
 # mcr_hip.hip: the SLP vectoriser's packed f32 forms pay in k_dynamics' velocity sweeps (without it: 135 instead of 118 us), but with the
 # default profitability threshold a seventh of the loop is register shuffling for their operands; sweep on the GPU (dynamics / step):
 # threshold 0: 118.2 us / 14.70 M, 4: 114.6 / 14.91, 5: 112.6 / 15.03, 8: 115.7 / 14.95, 12: 114.1 / 15.04, 16: 122.2 / 14.73, off: 135.3 / 14.15
-SOURCES = [("mcr_hip.hip", ["-mllvm", "-slp-threshold=5"] + os.environ.get("MCR_HIP_CFLAGS", "").split()), ("mcr_view.hip", ["-fno-slp-vectorize"]), ("mcr_host.cpp", [])]
+SOURCES = [("mcr_hip.hip", ["-mllvm", "-slp-threshold=5"] + os.environ.get("MCR_HIP_CFLAGS", "").split()), ("mcr_view.hip", ["-fno-slp-vectorize"]), ("mcr_host.cpp", []), ("mcr_world.cpp", [])]
 
 
 def deps():

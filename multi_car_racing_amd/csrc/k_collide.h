@@ -61,13 +61,14 @@ __device__ __forceinline__ float sat_tile_fixture(const TilePoly& T, const float
 //                       degrees: distance <= 1.6 s): GJK returns a distance far below 0.02 and says "touching";
 //   in between       -> GJK decides.  (oracle sweep, tests/test_oracle_pinning.py: an exact-distance predicate and GJK
 //                       never differ beyond 5e-5 of the threshold, so the filter's 1e-3 changes no result.)
+// (fixture_first: the car fixture holds the lower proxy id and is the pair's fixtureA — b2TestOverlap(fixture, tile) instead of (tile, fixture))
 __device__ __forceinline__ bool overlap(const float* avx, const float* avy, const float* anx, const float* any_, int an, const TilePoly& T,
-                                        const float4 va, const float4 vb, const McrPoly* __restrict__ PB, const float4 xfB) {
+                                        const float4 va, const float4 vb, const McrPoly* __restrict__ PB, const float4 xfB, const bool fixture_first) {
   const float R = 2.0f * B2_POLYGON_RADIUS;
   const float s = mcr_max(sat_fixture_tile(avx, avy, anx, any_, an, T), sat_tile_fixture(T, avx, avy, an));
   if (s > R + 1e-3f) return false;
   if (s <= 0.0f) return true;
-  return gjk::touching(va, vb, T.n, PB, xfB);
+  return fixture_first ? gjk::touching_fixture_first(va, vb, T.n, PB, xfB) : gjk::touching(va, vb, T.n, PB, xfB);
 }
 
 // cross-lane reductions by DPP (one VALU operation per level, no LDS round trip).  Groups of 8 lanes: lane ^ 1, lane ^ 2 inside the quad,
@@ -121,6 +122,12 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   const int N = p.N, BN = p.BN;
   const uint8_t* slot = p.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES;
   const int T = ((const McrSlotHeader*)slot)->T;
+  // broadphase proxy ids: a fresh world's ascend in creation order (tile t -> t, car fixture pf -> TILE_CAP + pf sorts the same way); an episode
+  // slot that carries tables (the facade's world across reset(), mcr_world.cpp) has its own
+  const bool has_pid = ((const McrSlotHeader*)slot)->pad0 != 0;
+  const uint16_t* __restrict__ TPID = (const uint16_t*)(slot + MCR_OFF_TPID); const uint16_t* __restrict__ FPID = (const uint16_t*)(slot + MCR_OFF_FPID);
+  auto tile_pid = [&](int t) -> uint32_t { return has_pid ? (uint32_t)TPID[t] : (uint32_t)t; };
+  auto fix_pid = [&](int pf) -> uint32_t { return has_pid ? (uint32_t)FPID[pf] : (uint32_t)(MCR_TILE_CAP + pf); };
   // (asked for now, used after the fixtures are built: the boxes of the track's tile blocks; the cars' reward / visit-count accumulators)
   float4 kb_pre = make_float4(1.0f, 1.0f, -1.0f, -1.0f);
   if (lane < MCR_TILE_CAP / MCR_TBLK) kb_pre = ((const float4*)(slot + MCR_OFF_TBLK))[lane];
@@ -141,7 +148,7 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   __shared__ float cbox[MCR_MAX_AGENTS][4];
   __shared__ uint32_t newrec[MCR_CC_MAX][16];
   __shared__ uint32_t tres[MCR_TILE_CAP], tany[MCR_TILE_CAP / 32];
-  __shared__ uint32_t cand[CAND_CAP];
+  __shared__ __attribute__((aligned(8))) uint32_t cand[CAND_CAP];
   // ---- broadphase model of the wheels (Box2D: b2Fixture::Synchronize / b2DynamicTree::MoveProxy at the END of the last
   // step, b2BroadPhase::UpdatePairs -> b2ContactManager::AddPair right after it; evaluated lazily here, on the next pass).
   // A tile<->wheel contact exists exactly while the two proxies' FAT AABBs overlap, and Collide serves the contacts
@@ -310,7 +317,7 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
           TP.vx[0] = va.x; TP.vy[0] = va.y; TP.vx[1] = va.z; TP.vy[1] = va.w; TP.vx[2] = vb.x; TP.vy[2] = vb.y; TP.vx[3] = vb.z; TP.vy[3] = vb.w;
           TP.nx[0] = na.x; TP.ny[0] = na.y; TP.nx[1] = na.z; TP.ny[1] = na.w; TP.nx[2] = nb.x; TP.ny[2] = nb.y; TP.nx[3] = nb.z; TP.ny[3] = nb.w;
           const McrShapes& S = *p.shapes;
-          if (overlap(fvx[f], fvy[f], fnx[f], fny[f], fcnt[f], TP, va, vb, fi < 4 ? &S.hull[fi] : &S.wheel, fxf[f]))
+          if (overlap(fvx[f], fvy[f], fnx[f], fny[f], fcnt[f], TP, va, vb, fi < 4 ? &S.hull[fi] : &S.wheel, fxf[f], has_pid && fix_pid(f) < tile_pid(t)))
           { if (fi >= 4) atomicOr(&tres[t], 1u << (c * 4 + (fi - 4))); atomicOr(&tany[t >> 5], 1u << (t & 31)); }
         }
       }
@@ -397,7 +404,10 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
     }
     for (; begins; begins &= begins - 1u) {
       const int f = __builtin_ctz(begins);                                              // car * 4 + wheel
-      const unsigned long long key = (1ull << 62) | ((unsigned long long)p.bp_stamp[((size_t)env * MCR_TILE_CAP + t) * (4 * N) + f] << 14) | ((unsigned long long)t << 5) | (unsigned long long)f;
+      // key: batch, then the pair's (lower, higher) proxy id — b2PairLessThan — then, below the bits that order, the event itself
+      const uint32_t pt = tile_pid(t), pw = fix_pid((f >> 2) * 8 + 4 + (f & 3));
+      const unsigned long long key = (1ull << 62) | ((unsigned long long)p.bp_stamp[((size_t)env * MCR_TILE_CAP + t) * (4 * N) + f] << 38) |
+                                     ((unsigned long long)(pt < pw ? pt : pw) << 26) | ((unsigned long long)(pt < pw ? pw : pt) << 14) | ((unsigned long long)t << 5) | (unsigned long long)f;
       const int slot = atomicAdd(&evn, 1);
       if (slot < EVQ_CAP) evq[slot] = key;
     }
@@ -405,7 +415,7 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
     if (newbits) new_blocks |= 1u << (t / MCR_TBLK);
   }
   __syncthreads();
-  // ... and are replayed in Box2D's order: highest (batch, tile, car * 4 + wheel) first.  Every lane keeps the same reward /
+  // ... and are replayed in Box2D's order: highest (batch, lower proxy id, higher proxy id) first — (batch, tile, car * 4 + wheel) in a fresh world.  Every lane keeps the same reward /
   // count accumulators; the road_visited bits of the tiles involved live in LDS during the replay.
   {
     int n = evn;
@@ -482,6 +492,7 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
       const int fa = lane >> 3, fb = lane & 7;
       const bool valid = !(fa >= 4 && fb >= 4);                              // wheel (0x20, mask 1) vs wheel: filtered
       cc::Manifold M; M.n = 0; M.type = 0; M.pl[0] = M.pl[1] = v2(0.0f, 0.0f); M.id[0] = M.id[1] = 0; M.localNormal = M.localPoint = v2(0.0f, 0.0f);
+      bool flipped = false;
       if (valid) {
         const int ia = a * 8 + fa, ib = b * 8 + fb;
         const float4 A = fbox[ia], Bb = fbox[ib];
@@ -489,7 +500,8 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
           const McrPoly& pa = fa < 4 ? S.hull[fa] : S.wheel; const McrPoly& pb = fb < 4 ? S.hull[fb] : S.wheel;
           Xf xa, xb; const float4 ta = fxf[ia], tb = fxf[ib];
           xa.p = v2(ta.x, ta.y); xa.q.s = ta.z; xa.q.c = ta.w; xb.p = v2(tb.x, tb.y); xb.q.s = tb.z; xb.q.c = tb.w;
-          cc::collide_polygons(M, pa, xa, pb, xb);
+          flipped = has_pid && fix_pid(ib) < fix_pid(ia);                  // fixtureA = the fixture with the lower proxy id
+          if (flipped) cc::collide_polygons(M, pb, xb, pa, xa); else cc::collide_polygons(M, pa, xa, pb, xb);
         }
       }
       const bool hit = valid && M.n > 0;
@@ -497,7 +509,7 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
       if (hit) {
         const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
         if (slot < MCR_CC_MAX) {
-          const uint32_t key = (uint32_t)a | ((uint32_t)fa << 4) | ((uint32_t)b << 8) | ((uint32_t)fb << 12);
+          const uint32_t key = flipped ? ((uint32_t)b | ((uint32_t)fb << 4) | ((uint32_t)a << 8) | ((uint32_t)fa << 12)) : ((uint32_t)a | ((uint32_t)fa << 4) | ((uint32_t)b << 8) | ((uint32_t)fb << 12));
           float ni[2] = {0.0f, 0.0f}, ti[2] = {0.0f, 0.0f};
           for (int j = 0; j < old_n; ++j) {
             const uint32_t* o = store + 4 + j * MCR_CC_WORDS;
@@ -535,17 +547,22 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
     // cars, touch disjoint bodies and commute: what is left is ONE order of the contacts — the records are stored in it, the contact
     // chain of k_dynamics takes them as they come — and an order of the 4 joints per car (store[2..3], 2 bits per position; a car
     // that the search enters through its wheel k solves joint k first).  One lane; the scratch aliases the candidate list.
-    uint8_t* const dord = (uint8_t*)(cand + MCR_CC_MAX) + MCR_CC_MAX;     // island order: dord[i] = index of the i-th contact in newrec
-    uint32_t* const skey = cand; uint8_t* const sorted = (uint8_t*)(cand + MCR_CC_MAX); uint8_t* const stk = dord + MCR_CC_MAX;
+    // (keys: creation batch, then b2PairLessThan's (lower, higher) proxy id — 64 bits: the batch label counts the episode's steps)
+    unsigned long long* const skey = (unsigned long long*)cand;
+    uint8_t* const sorted = (uint8_t*)(cand + 2 * MCR_CC_MAX); uint8_t* const dord = sorted + MCR_CC_MAX;     // island order: dord[i] = index of the i-th contact in newrec
+    uint8_t* const stk = dord + MCR_CC_MAX;
+    static_assert(2 * MCR_CC_MAX * 4 + 2 * MCR_CC_MAX + 5 * MCR_MAX_AGENTS <= CAND_CAP * 4, "the island search's scratch aliases the candidate list");
     if (lane < nn) {
       const uint32_t k = newrec[lane][0];
       const int pa = (int)(k & 15u) * 8 + (int)((k >> 4) & 15u), pb = (int)((k >> 8) & 15u) * 8 + (int)((k >> 12) & 15u);
-      skey[lane] = (ccs[2 + pa * 8 * N + pb] << 12) | ((uint32_t)pa << 6) | (uint32_t)pb;
+      const int sa = pa < pb ? pa : pb, sb = pa < pb ? pb : pa;            // (the stamps are kept per pair, lower car first)
+      const uint32_t ia = fix_pid(pa), ib = fix_pid(pb);
+      skey[lane] = ((unsigned long long)ccs[2 + sa * 8 * N + sb] << 24) | ((unsigned long long)(ia < ib ? ia : ib) << 12) | (unsigned long long)(ia < ib ? ib : ia);
     }
     __syncthreads();
     uint32_t incars = 0u;                                                  // cars with a touching contact (the others: no contacts, joints 3,2,1,0)
     if (lane < nn) {
-      const uint32_t mine = skey[lane];
+      const unsigned long long mine = skey[lane];
       int rank = 0;
       for (int j2 = 0; j2 < nn; ++j2) rank += skey[j2] > mine ? 1 : 0;     // (keys are distinct) newest first
       sorted[rank] = (uint8_t)lane;

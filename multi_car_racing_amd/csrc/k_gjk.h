@@ -38,19 +38,24 @@ __device__ __forceinline__ int support_poly(const McrPoly* __restrict__ P, float
   for (int i = 1; i < n; ++i) { const float value = P->vx[i] * dx + P->vy[i] * dy; if (value > bestValue) { best = i; bestValue = value; } }
   return best;
 }
+// SWAP: the car fixture is proxy A and the tile proxy B (a world that lives across reset() hands out proxy ids off its tree's free list:
+// a car fixture's can be the lower one, include/mcr.h: mcr_world) — iA then indexes the fixture, iB the tile
+template <bool SWAP>
 __device__ __forceinline__ SV make_vertex(const float4 va, const float4 vb, int iA, const McrPoly* __restrict__ PB, const float4 xfB, int iB) {
   SV v; v.iA = iA; v.iB = iB;
-  tile_vertex(va, vb, iA, v.wAx, v.wAy);
-  const float lx = PB->vx[iB], ly = PB->vy[iB];
-  v.wBx = (xfB.w * lx - xfB.z * ly) + xfB.x; v.wBy = (xfB.z * lx + xfB.w * ly) + xfB.y;       // b2Mul(xfB, v)
+  float tx, ty; tile_vertex(va, vb, SWAP ? iB : iA, tx, ty);
+  const float lx = PB->vx[SWAP ? iA : iB], ly = PB->vy[SWAP ? iA : iB];
+  const float fx = (xfB.w * lx - xfB.z * ly) + xfB.x, fy = (xfB.z * lx + xfB.w * ly) + xfB.y;     // b2Mul(xf, v) of the car fixture's vertex
+  if (SWAP) { v.wAx = fx; v.wAy = fy; v.wBx = tx; v.wBy = ty; } else { v.wAx = tx; v.wAy = ty; v.wBx = fx; v.wBy = fy; }
   v.wx = v.wBx - v.wAx; v.wy = v.wBy - v.wAy; v.a = 1.0f;
   return v;
 }
 
 // tile: hull vertices v0 v1 | v2 v3 (CCW, b2PolygonShape::Set order), tn = 3 or 4;  PB: the car fixture in body-local
 // coordinates;  xfB = (p.x, p.y, sin, cos) of its body.  Both shapes have radius b2_polygonRadius.
-__device__ __noinline__ bool touching(const float4 va, const float4 vb, const int tn, const McrPoly* __restrict__ PB, const float4 xfB) {
-  SV v0 = make_vertex(va, vb, 0, PB, xfB, 0), v1 = v0, v2 = v0;
+template <bool SWAP>
+__device__ __noinline__ bool touching_as(const float4 va, const float4 vb, const int tn, const McrPoly* __restrict__ PB, const float4 xfB) {
+  SV v0 = make_vertex<SWAP>(va, vb, 0, PB, xfB, 0), v1 = v0, v2 = v0;
   int count = 1;
   int saveA0 = 0, saveA1 = 0, saveA2 = 0, saveB0 = 0, saveB1 = 0, saveB2 = 0, saveCount = 0;
   int iter = 0;
@@ -97,9 +102,16 @@ __device__ __noinline__ bool touching(const float4 va, const float4 vb, const in
       else { dx = 1.0f * e12y; dy = -1.0f * e12x; }                        // b2Cross(e12, 1.0f)
     }
     if (dx * dx + dy * dy < B2_EPSILON * B2_EPSILON) break;
-    const int iA = support_tile(va, vb, tn, -dx, -dy);                     // b2MulT(identity, -d)
-    const int iB = support_poly(PB, xfB.w * dx + xfB.z * dy, -xfB.z * dx + xfB.w * dy);      // b2MulT(xfB.q, d)
-    const SV nv = make_vertex(va, vb, iA, PB, xfB, iB);
+    int iA, iB;
+    if (SWAP) {
+      const float ndx = -dx, ndy = -dy;
+      iA = support_poly(PB, xfB.w * ndx + xfB.z * ndy, -xfB.z * ndx + xfB.w * ndy);        // b2MulT(xfA.q, -d), A the car fixture
+      iB = support_tile(va, vb, tn, dx, dy);                                                // b2MulT(identity, d)
+    } else {
+      iA = support_tile(va, vb, tn, -dx, -dy);                                              // b2MulT(identity, -d)
+      iB = support_poly(PB, xfB.w * dx + xfB.z * dy, -xfB.z * dx + xfB.w * dy);             // b2MulT(xfB.q, d)
+    }
+    const SV nv = make_vertex<SWAP>(va, vb, iA, PB, xfB, iB);
     ++iter;
     bool duplicate = (saveCount > 0 && iA == saveA0 && iB == saveB0) || (saveCount > 1 && iA == saveA1 && iB == saveB1) ||
                      (saveCount > 2 && iA == saveA2 && iB == saveB2);
@@ -122,5 +134,8 @@ __device__ __noinline__ bool touching(const float4 va, const float4 vb, const in
   if (distance > rr && distance > B2_EPSILON) distance -= rr; else distance = 0.0f;      // input.useRadii
   return distance < 10.0f * B2_EPSILON;
 }
+// tile = proxy A (a fresh world: tiles are created before the cars) / car fixture = proxy A
+__device__ __forceinline__ bool touching(const float4 va, const float4 vb, const int tn, const McrPoly* __restrict__ PB, const float4 xfB) { return touching_as<false>(va, vb, tn, PB, xfB); }
+__device__ __forceinline__ bool touching_fixture_first(const float4 va, const float4 vb, const int tn, const McrPoly* __restrict__ PB, const float4 xfB) { return touching_as<true>(va, vb, tn, PB, xfB); }
 
 }  // namespace gjk

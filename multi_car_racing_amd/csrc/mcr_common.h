@@ -51,7 +51,7 @@
 // One env owns two slots (current / staged).  Arrays are capacity-strided so that a wave reading
 // consecutive tiles/quads issues fully coalesced 16-byte-per-lane loads.
 struct McrSlotHeader {
-  int32_t T, P, cw, pad0;
+  int32_t T, P, cw, pad0;            // pad0: 1 = the slot carries proxy-id tables (MCR_OFF_TPID / MCR_OFF_FPID)
   double spawn[MCR_MAX_AGENTS][3];   // (angle, x, y) per car id, as handed to Car(...)
   int32_t pad1[12];
 };
@@ -75,7 +75,12 @@ struct McrSlotHeader {
 #define MCR_OFF_QBLK (MCR_OFF_TCNT + 4 * MCR_TILE_CAP)        // float4 [QUAD_CAP / QBLK]  lo.xy hi.xy of each run of QBLK road_poly entries (empty: lo > hi)
 #define MCR_TBLK 16                                           // tiles per culling block of the contact pass
 #define MCR_OFF_TBLK (MCR_OFF_QBLK + 16 * (MCR_QUAD_CAP / MCR_QBLK))   // float4 [TILE_CAP / TBLK]  lo.xy hi.xy of each run of TBLK tile sensor AABBs (empty: lo > hi)
-#define MCR_SLOT_BYTES (MCR_OFF_TBLK + 16 * (MCR_TILE_CAP / MCR_TBLK))
+// broadphase proxy ids of the episode's fixtures (header.pad0 != 0: present — the single-env facade's world, mcr_world.cpp; 0: the ids of a
+// fresh world, ascending in creation order): what orders the contact callbacks of a step and names fixtureA of a pair (k_collide.h)
+#define MCR_OFF_TPID (MCR_OFF_TBLK + 16 * (MCR_TILE_CAP / MCR_TBLK))  // u16 [TILE_CAP]          tile t
+#define MCR_OFF_FPID (MCR_OFF_TPID + 2 * MCR_TILE_CAP)                // u16 [MAX_AGENTS * 8]    car * 8 + fixture
+#define MCR_PID_LIMIT 4096                                            // ids are node indices of the tree: < 2 * (TILE_CAP + 64) rounded up to its pool size
+#define MCR_SLOT_BYTES (MCR_OFF_FPID + 2 * MCR_MAX_AGENTS * 8)
 
 // quad colour ids (u8 RGB after the GL float->unorm8 conversion)
 enum { MCR_COL_ROAD0 = 0, MCR_COL_ROAD1 = 1, MCR_COL_ROAD2 = 2, MCR_COL_KERB_WHITE = 3, MCR_COL_KERB_RED = 4 };

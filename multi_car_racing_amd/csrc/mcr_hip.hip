@@ -1025,12 +1025,14 @@ extern "C" int mcr_debug_read_dynamics_stamps(mcr_env* h, uint64_t* out, int n_u
   return MCR_OK;
 }
 // the sensor predicate of k_collide (col::overlap: SAT far-field filter + Box2D's GJK) on caller-supplied cases
-__global__ void k_debug_overlap(const McrShapes* shapes, int fixture, int n, const float4* __restrict__ va, const float4* __restrict__ vb,
+__global__ void k_debug_overlap(const McrShapes* shapes, int fixture_arg, int n, const float4* __restrict__ va, const float4* __restrict__ vb,
                                 const float4* __restrict__ na, const float4* __restrict__ nb, const int* __restrict__ cnt,
                                 const float* __restrict__ poses, uint8_t* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const McrShapes& S = *shapes;
+  const bool fixture_first = fixture_arg >= 8;                     // b2TestOverlap(fixture, tile): the car fixture holds the lower proxy id
+  const int fixture = fixture_arg & 7;
   const McrPoly& P = fixture < 4 ? S.hull[fixture] : S.wheel;
   const V2 lc = fixture < 4 ? v2(S.hull_lcx, S.hull_lcy) : v2(0.0f, 0.0f);
   // the body origin is given (b2BodyDef.position); sweep.c = xf * localCenter, then the transform k_collide derives from (c, a)
@@ -1043,11 +1045,11 @@ __global__ void k_debug_overlap(const McrShapes* shapes, int fixture, int n, con
   TP.n = cnt[i];
   TP.vx[0] = a.x; TP.vy[0] = a.y; TP.vx[1] = a.z; TP.vy[1] = a.w; TP.vx[2] = b.x; TP.vy[2] = b.y; TP.vx[3] = b.z; TP.vy[3] = b.w;
   TP.nx[0] = c.x; TP.ny[0] = c.y; TP.nx[1] = c.z; TP.ny[1] = c.w; TP.nx[2] = d.x; TP.ny[2] = d.y; TP.nx[3] = d.z; TP.ny[3] = d.w;
-  out[i] = col::overlap(wx, wy, nx, ny, P.n, TP, a, b, &P, make_float4(xf.p.x, xf.p.y, xf.q.s, xf.q.c)) ? 1 : 0;
+  out[i] = col::overlap(wx, wy, nx, ny, P.n, TP, a, b, &P, make_float4(xf.p.x, xf.p.y, xf.q.s, xf.q.c), fixture_first) ? 1 : 0;
 }
 void mcr_tile_hull(const float* fx, const float* fy, float* aabb4, float* va4, float* vb4, float* na4, float* nb4, int* count);   // mcr_host.cpp
 extern "C" int mcr_debug_overlap(mcr_env* h, int n, const float* quads, const float* poses, int fixture, uint8_t* out) {
-  if (!h || !quads || !poses || !out || n < 0 || fixture < 0 || fixture > 4) { g_err = "bad argument"; return MCR_ERR_ARG; }
+  if (!h || !quads || !poses || !out || n < 0 || fixture < 0 || (fixture & 7) > 4 || fixture > 12) { g_err = "bad argument"; return MCR_ERR_ARG; }
   if (n == 0) return MCR_OK;
   std::vector<float> hull((size_t)n * 16); std::vector<int> cnt(n);
   float* VA = hull.data(); float* VB = VA + (size_t)n * 4; float* NA = VB + (size_t)n * 4; float* NB = NA + (size_t)n * 4;

@@ -278,15 +278,18 @@ def overlap_sweep(n, seed=1, band=1e-5, far=5e-5, threads=None):
     return dict(samples=int(out[0]), disagree=int(out[1]), gjk_touching=int(out[2]), sat_touching=int(out[3]), max_gjk_iters=int(out[4]), disagree_far=int(out[5]))
 
 
-def overlap_cases(n, seed=1, band=1e-5, threads=None):
+def overlap_cases(n, seed=1, band=1e-5, threads=None, wheel_first=False):
     """The sweep's cases themselves: (quads [k,4,2] f32 — a tile's 4 input points, poses [k,3] f32 — wheel body x, y, angle,
-    gjk [k] bool — Box2D's b2TestOverlap verdict with the tile as proxy A)."""
+    gjk [k] bool — Box2D's b2TestOverlap verdict with the tile as proxy A, or (wheel_first) with the wheel as proxy A)."""
     out = np.zeros(7, np.int64)
+    lib().orc_set_overlap_order.restype = None
+    lib().orc_set_overlap_order(ctypes.c_int(int(bool(wheel_first))))
     quads = np.zeros((int(n), 8), np.float32); poses = np.zeros((int(n), 3), np.float32); g = np.zeros(int(n), np.uint8)
     L = lib(); L.orc_overlap_cases.restype = None
     L.orc_overlap_cases(ctypes.c_longlong(int(n)), ctypes.c_uint(int(seed)), ctypes.c_double(band), ctypes.c_double(5e-5), _p(out),
                         ctypes.c_int(threads or os.cpu_count() or 1), _p(quads), _p(poses), _p(g), ctypes.c_longlong(int(n)))
     k = int(out[6])
+    L.orc_set_overlap_order(ctypes.c_int(0))
     return quads[:k].reshape(k, 4, 2), poses[:k], g[:k].astype(bool)
 
 

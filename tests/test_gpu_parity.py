@@ -464,6 +464,45 @@ def test_facade_matches_reference_surface(torch_cuda, oracle):
     e2.close()
 
 
+@pytest.mark.parametrize("N", [2, 4])
+def test_facade_reset_reset_is_reward_exact_on_one_world(torch_cuda, oracle, N):
+    """The reference keeps ONE b2World across reset() (multi_car_racing.py:138, 341): from the second episode on the fixtures' proxy ids come
+    off the broadphase tree's free list and decide which of two cars that reach a tile in the same step is its first visitor (:113-120).  The
+    facade carries the world's tree on the host (include/mcr.h: mcr_world_*): four consecutive episodes equal the oracle in world mode 1 —
+    every step's rewards bit for bit — and an oracle in the fresh-world mode, on the same episodes, does NOT (the deviation is real)."""
+    import multi_car_racing_amd as M
+    from multi_car_racing_amd import seeding
+    np.random.seed(11)
+    env = M.MultiCarRacing(num_agents=N, verbose=0, use_random_direction=True)      # (draws a direction from the global stream, :157)
+    env.seed(9)
+    rs, _ = seeding.np_random(9)
+    o1 = oracle.OracleEnv(N); o1.set_world_mode(1)                 # one world across the resets
+    o0 = oracle.OracleEnv(N)                                       # every episode the first of a fresh world
+    rng = np.random.RandomState(2)
+    fresh_differs = 0
+    for epi in range(4):
+        st = np.random.get_state()
+        obs = env.reset()
+        np.random.set_state(st)
+        ep = oracle.new_episode(N, rs, np.random, use_random_direction=True)
+        oo = o1.reset(ep); o0.reset(ep, render=False)
+        assert ((oo != obs).any(-1) & (o1.last_amb == 0)).sum() == 0, f"episode {epi}: first frame"
+        # tie-breaks live where several cars reach a tile in one step: the grid start, and cars driving side by side
+        for k in range(70):
+            a = np.stack([rng.uniform(-0.05, 0.05, N), np.ones(N), np.zeros(N)], -1)
+            ob, r, d, _ = env.step(a)
+            _, r1, d1, _ = o1.step(a, render=False); _, r0, d0, _ = o0.step(a, render=False)
+            assert np.array_equal(r, r1) and d == d1, f"episode {epi} step {k}: reward {r} vs the one-world oracle {r1}"
+            fresh_differs += int(not np.array_equal(r, r0))
+        s1 = o1.state()
+        got = np.zeros((1, N, 5, 6), np.float32)
+        from multi_car_racing_amd import _lib
+        _lib.check(env.L.mcr_get_state(env._h, _lib.ptr(got), None, None, None, None, None))
+        assert np.array_equal(got[0], s1["bodies"]), f"episode {epi}: body state"
+    assert fresh_differs > 0, "the fresh-world oracle never disagreed: the test did not exercise the tie-break"
+    env.close(); o1.close(); o0.close()
+
+
 def _rear_end_setup(env, orcs, gap=5.2):
     """Put car 1 of every env `gap` behind car 0 (same heading) so that full gas on car 1 + brake on car 0 collide."""
     st = env.get_state()["bodies"].copy()
@@ -665,6 +704,18 @@ def test_device_sensor_predicate_is_box2d_gjk(torch_cuda, oracle, lib):
         assert 0.2 * k < g.sum() < 0.8 * k            # the cases do straddle the threshold
         total += k if band <= 1e-5 else 0
     assert total >= 1_000_000
+    # ... and with the car fixture as fixtureA (a world that lives across reset() hands out ids off its tree's free list, include/mcr.h: mcr_world)
+    flipped = 0
+    for n, seed, band in ((400_000, 5, 1e-5), (100_000, 6, 1e-3)):
+        quads, poses, g = oracle.overlap_cases(n, seed=seed, band=band, wheel_first=True)
+        _, _, g0 = oracle.overlap_cases(n, seed=seed, band=band)
+        k = len(g)
+        out = np.zeros(k, np.uint8)
+        lib.check(L.mcr_debug_overlap(env.h, k, lib.ptr(np.ascontiguousarray(quads.reshape(k, 8))), lib.ptr(np.ascontiguousarray(poses)), 4 + 8, lib.ptr(out)), "mcr_debug_overlap")
+        diff = int((out.astype(bool) != g).sum())
+        assert diff == 0, f"band {band}, wheel as proxy A: device predicate differs from Box2D's GJK in {diff} of {k} cases"
+        flipped += int((g != g0[:k]).sum()) if len(g0) == k else 0
+    print("cases whose verdict depends on which shape is proxy A:", flipped)
     env.close()
 
 

@@ -212,3 +212,47 @@ def test_generator_pool_survives_fork_and_concurrent_callers(lib):
         raise AssertionError("mcr_episodes_generate hung in a forked child")
     assert os.read(r, 1) == b"1"
     os.waitpid(pid, 0)
+
+
+def _product_blob(L, lib, N, seed, g=0):
+    """the product's episode of global env index g (vec_env.py: track stream seed + g, draw stream seed + g + 2**31) — what tests.util.oracle_episode
+    builds for the oracle"""
+    s = (seed + g) % 2 ** 32
+    mt_t = _mt(L, lib, s).reshape(1, -1); mt_g = _mt(L, lib, (s + 2 ** 31) % 2 ** 32).reshape(1, -1)
+    blob = np.zeros((1, lib.episode_bytes()), np.uint8); info = np.zeros((1, 12), np.int32)
+    assert L.mcr_episodes_generate(lib.ptr(mt_t), lib.ptr(mt_g), 1, N, 2, lib.ptr(blob), lib.ptr(info), 1) == 0
+    return blob[0]
+
+
+def test_world_reuse_tree_ids_of_the_product_host_tree(lib, oracle):
+    """The product's own b2DynamicTree (csrc/mcr_world.cpp, include/mcr.h: mcr_world_*) — what the facade carries across reset() the way the
+    reference carries its b2World (multi_car_racing.py:138, 341) — against the oracle's literal tree (world mode 1): fed the same episodes and
+    the same body transforms step by step, the two hand out the same proxy ids in the first episode (ascending, 2k - 1), in the second (off the
+    free list: no longer ascending) and in the third — which they only do if every MoveProxy in between restructured both trees alike."""
+    from tests.util import oracle_episode
+    L = lib.load()
+    for N in (2, 4):
+        w = ctypes.c_void_p(L.mcr_world_create(N))
+        o = oracle.OracleEnv(N); o.set_world_mode(1)
+        rng = np.random.RandomState(3)
+        not_ascending = 0
+        for ei, (seed, steps) in enumerate([(31, 160), (77, 120), (5, 200), (12, 10)]):
+            blob = _product_blob(L, lib, N, seed)
+            ep = oracle_episode(oracle, N, seed, 0, use_random_direction=True)
+            o.reset(ep, render=False)
+            assert L.mcr_world_reset(w, lib.ptr(blob)) == 0
+            assert L.mcr_world_step(w, lib.ptr(np.ascontiguousarray(o.state()["bodies"], np.float32))) == 0      # the reset's own step (:408)
+            tid, fid = o.proxy_ids()
+            want = np.concatenate([tid, fid.ravel()]).astype(np.int32)
+            got = np.zeros(len(want) + 8, np.int32)
+            n = L.mcr_world_proxy_ids(w, lib.ptr(got), len(got))
+            assert n == len(want) and np.array_equal(got[:n], want), f"N={N} episode {ei}: ids differ at {np.nonzero(got[:n] != want)[0][:8]}"
+            hdr = blob[:16].view(np.int32)
+            assert hdr[3] == 1, "the blob says that it carries proxy-id tables"
+            not_ascending += int(not np.all(np.diff(want) > 0))
+            for k in range(steps):
+                act = np.stack([rng.uniform(-0.4, 0.4, N), np.ones(N), np.zeros(N)], -1).astype(np.float32)
+                o.step(act, render=False)
+                assert L.mcr_world_step(w, lib.ptr(np.ascontiguousarray(o.state()["bodies"], np.float32))) == 0
+        assert not_ascending >= 2, "the later episodes' ids come off the free list"
+        o.close(); L.mcr_world_destroy(w)

@@ -282,7 +282,8 @@ def test_world_reuse_tree_ids(oracle):
     (multi_car_racing.py:138, 341) does to proxy ids.  Pins: (a) DESIGN 4's claim for the first episode of a world — the k-th fixture
     created gets leaf id 2k-1 (the first one 0) —, so mode 1 and mode 0 (what the kernels implement) are the same computation there;
     (b) in a second episode the ids are the free list's: still one distinct id per proxy, no longer ascending in creation order;
-    (c) visits (which tile, which car, when) never depend on ids — only the order of same-step events does."""
+    (c) visits (which tile, which car, when) do not depend on ids — the order of same-step events does, and (through fixtureA of a car<->car
+    contact = the lower id) the manifold of two cars that touch."""
     N = 2
     a, b = oracle.OracleEnv(N), oracle.OracleEnv(N)
     b.set_world_mode(1)
@@ -305,12 +306,21 @@ def test_world_reuse_tree_ids(oracle):
     ids = np.concatenate([tid2, fid2.ravel()])
     assert len(set(ids.tolist())) == len(ids) and ids.min() >= 0
     assert not np.all(np.diff(ids) > 0), "ids of a reused world come off the free list: not ascending in creation order"
+    touched = False
+    same_until_touch = True
     for k in range(120):
         act = np.stack([rng.uniform(-0.4, 0.4, N), np.ones(N), np.zeros(N)], -1).astype(np.float32)
         a.step(act, render=False); b.step(act, render=False)
+        touched = touched or b.num_car_contacts() > 0 or a.num_car_contacts() > 0     # (the contacts the step just solved)
+        if not touched:
+            same_until_touch = same_until_touch and np.array_equal(a.state()["bodies"], b.state()["bodies"])
     sa, sb = a.env_state(), b.env_state()
     assert np.array_equal(sa["visited"], sb["visited"]) and np.array_equal(sa["tile_visited_count"], sb["tile_visited_count"])
-    assert np.array_equal(a.state()["bodies"], b.state()["bodies"])           # ids never reach the solver
+    # ids reach the solver in ONE way: fixtureA of a car<->car contact is the fixture with the lower proxy id (b2Contact::Create), and
+    # b2CollidePolygons is not symmetric in its arguments (reference-face tie-break) — until two cars touch, the poses are the fresh world's
+    assert same_until_touch
+    if not touched:
+        assert np.array_equal(a.state()["bodies"], b.state()["bodies"])
     a.close(); b.close()
 
 
