@@ -207,6 +207,8 @@ int mcr_debug_read_dynamics_stamps(mcr_env* h, uint64_t* out, int n_u64);
  * [2] contact envs routed to the side stream, [3] env-steps frozen because the host had not staged the next episode yet
  * (a healthy rollout keeps this at 0) */
 int mcr_debug_read_counters(mcr_env* h, uint64_t* out4);
+/* all eight: [4] touch-verdict mismatches, [5] waits given up, [6] the last mismatch (env | manifolds << 20 | verdict << 28 | role << 32 | episode step << 36), [7] its step counter */
+int mcr_debug_read_counters8(mcr_env* h, uint64_t* out8);
 /* the three-chain step decides one step ahead which envs hold a touching car<->car pair (the main dynamics launch runs
  * beside the contact pass); the contact pass counts the envs where it disagrees: must stay 0 */
 int mcr_debug_read_verdict_mismatches(mcr_env* h, uint64_t* out1);
@@ -239,6 +241,10 @@ int mcr_bind_stream(mcr_env* h, void* stream);
 /* the per-env records (mcr_common.h: McrEnvState, 48 bytes each: t f64, then steps, slot, staged_ready, consumed, active, resetting, just_reset,
  * frozen as i32, touch_blocks, bp_step as u32) of the first n_bytes / 48 envs; synchronises.  Diagnostics of the auto-reset's staging protocol. */
 int mcr_debug_read_env_records(mcr_env* h, void* out, int n_bytes);
+/* the last step's contact partition (three-chain step): part_out[B] = the touch verdicts it went by, clist_out[1 + B] = its contact list (count, env ids); synchronises */
+int mcr_debug_read_partition(mcr_env* h, uint8_t* part_out, int32_t* clist_out);
+/* out NULL: fill the verdict buffer the next step WRITES with fill_value; out != NULL (after that step): read it back [B].  Synchronises. */
+int mcr_debug_next_verdicts(mcr_env* h, int fill_value, uint8_t* out_or_null);
 /* number of touching car<->car fixture pairs (stored manifolds) per env after the last collide pass */
 int mcr_debug_read_contact_counts(mcr_env* h, int32_t* out /*[num_envs]*/);
 /* Conditions reported by the kernels in mapped host memory (counted on the device, stored with system scope: no PCIe atomics needed),

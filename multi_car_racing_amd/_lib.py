@@ -56,7 +56,10 @@ SYMBOLS = {
     "mcr_render": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mcr_debug_read_contact_counts": (_i, [_vp, _vp]),
     "mcr_debug_read_env_records": (_i, [_vp, _vp, _i]),
+    "mcr_debug_read_partition": (_i, [_vp, _vp, _vp]),
+    "mcr_debug_next_verdicts": (_i, [_vp, _i, _vp]),
     "mcr_debug_read_counters": (_i, [_vp, _vp]),
+    "mcr_debug_read_counters8": (_i, [_vp, _vp]),
     "mcr_debug_read_verdict_mismatches": (_i, [_vp, _vp]),
     "mcr_concurrent_collide": (_i, [_vp]),
     "mcr_step_ordering": (_i, [_vp]),

@@ -112,6 +112,7 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
     for (int i = 0; i < 8; ++i) { pvx[i] = P.vx[i]; pvy[i] = P.vy[i]; pnx[i] = P.nx[i]; pny[i] = P.ny[i]; }      // (all eight: no load waits for the count)
   }
   const McrEnvState es = p.env[env];
+  if (pass == 0 && p.fuse_collide && p.role < 2 && p.part[env]) return;      // a contact env: its chain's workgroup runs this pass itself (k_list_chain.h)
   if (!es.active) {
     // contact pass in front (single stream, N > 4, serialised kernels): this pass owns the contact chain's marks — an env
     // that froze while its cars were touching must not keep a stale one (it would be skipped by every main launch)
@@ -621,10 +622,15 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   // side-stream partition: envs whose dynamics chain is going to be long (a touching car<->car pair).  cc_mode: the verdict
   // the main launches go by (p.part: mcr_touch_verdict, evaluated by last step's bookkeeping on the same poses) must
   // agree — counters[4] counts disagreements (tests and bench assert 0).
-  if (pass == 0 && p.split && lane == 0) {
-    if (nn_final > 0) { p.clist[1 + atomicAdd(&p.clist[0], 1)] = env; atomicAdd(&p.counters[2], 1ull); }
+  if (pass == 0 && lane == 0) MCR_TRACE(p, env, p.role == 2 ? 3 : 4, nn_final);                                  // (contact pass by the chain / by k_collide)
+  if (pass == 0 && (p.split || p.fuse_collide) && lane == 0) {
+    if (nn_final > 0) { if (!p.fuse_collide) p.clist[1 + atomicAdd(&p.clist[0], 1)] = env; atomicAdd(&p.counters[2], 1ull); }     // (fuse_collide: the list was made with the verdicts)
     if (!p.cc_mode) p.part[env] = nn_final > 0 ? 1 : 0;         // the contact pass runs first: it is the one that marks the contact chain's envs
-    else if ((nn_final > 0) != (p.part[env] != 0)) { atomicAdd(&p.counters[4], 1ull); mcr_raise(p, ST_VERDICT); }
+    else if ((nn_final > 0) != (p.part[env] != 0)) {
+      atomicAdd(&p.counters[4], 1ull); mcr_raise(p, ST_VERDICT);
+      p.counters[6] = (unsigned long long)env | ((unsigned long long)nn_final << 20) | ((unsigned long long)p.part[env] << 28) | ((unsigned long long)p.role << 32) | ((unsigned long long)es.steps << 36);   // (diagnostics: the last mismatch)
+      p.counters[7] = (unsigned long long)(uint32_t)mcr_epoch(p);
+    }
   }
   if (pass == 0 && p.cc_mode && !((p.debug & 4096) && env == p.env0)) {     // the main dynamics, running beside this launch, may read this env's results now
     // (debug bit 12: env 0's word is withheld — what a starved contact pass looks like to the dynamics; tests)

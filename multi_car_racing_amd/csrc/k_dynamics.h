@@ -1652,6 +1652,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
   }
   }   // run
   DYN_STAMP(4);
+  if (mode == 0 && lane_ok && agent == 0 && (run || thaw)) MCR_TRACE(p, env, p.role == 2 ? 0 : 1, p.role);   // (slot 0: stepped by the contact chain, 1: by anybody else)
 
 }
 
@@ -1663,7 +1664,9 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
   __builtin_amdgcn_s_setprio(3);
   if (mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) {         // the next step's lists: every reader of these buffers finished last step
     if (p.soft_sync && p.role == 1) mcr_post(p, W_BEGIN);         // the caller's stream is here: the side stream may start this step
-    if (p.role == 1) p.clist_next[0] = 0;
+    // (fuse_collide: the next step's contact list is filled DURING this step, by verdict writers that may run while this kernel — whose
+    // stores sit in its XCD's L2 until it ends — is still going: that list is emptied a step earlier, by the side stream's last kernel)
+    if (p.role == 1 && !p.fuse_collide) p.clist_next[0] = 0;
     for (int i = 0; i < 4; ++i) if (p.next_counts[i]) *p.next_counts[i] = 0;
     if (p.term_cnt_next) { p.term_cnt_next[0] = 0; p.term_cnt_next[1] = 0; p.term_cnt_next[2] = 0; }
   }

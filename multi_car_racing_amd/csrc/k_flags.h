@@ -20,7 +20,7 @@ __device__ __forceinline__ void verdict_block(const McrParams& p, const int env)
   if (p.part_next == nullptr || env >= p.env0 + p.nenv) return;
   const bool active = p.env[env].active != 0;
   const bool v = mcr_touch_verdict(p, env);
-  if ((threadIdx.x & 63) == 0) p.part_next[env] = (active && v) ? 1 : 0;
+  if ((threadIdx.x & 63) == 0) mcr_set_verdict(p, env, active && v);
 }
 // (env_of_list >= 0 ...; verdict_elsewhere: another wavefront settles the env's touch verdict)
 __device__ __forceinline__ void flags_block(const McrParams& p, const int blk, const int env_of_list = -1, const bool verdict_elsewhere = false) {
@@ -41,7 +41,7 @@ __device__ __forceinline__ void flags_block(const McrParams& p, const int blk, c
   auto settle_verdict = [&]() {
     if (vwave && vmark == 2u) {
       const bool v = mcr_touch_verdict(p, env);
-      if (lane == 0) p.part_next[env] = (es.active && v) ? 1 : 0;
+      if (lane == 0) mcr_set_verdict(p, env, es.active && v);
     }
   };
   if (!es.active || es.just_reset) { settle_verdict(); return; }   // reset() -> step(None) skips the block (:435); a re-spawned car keeps its zeroed flags

@@ -31,7 +31,7 @@ template <bool CC>
 __global__ __launch_bounds__(64) void k_list_chain(McrParams pa, McrParams pb, const int with_flags, const int ga) {
   __builtin_amdgcn_s_setprio(3);
   // soft_sync (mcr_kernels.h): the contact chain follows the contact pass in its stream — its start IS the contact pass's completion
-  if (pa.soft_sync && pa.role == 2 && pa.cc_mode && blockIdx.x == 0 && threadIdx.x == 0) mcr_post(pa, W_COL);
+  if (pa.soft_sync && pa.role == 2 && pa.cc_mode && !pa.fuse_collide && blockIdx.x == 0 && threadIdx.x == 0) mcr_post(pa, W_COL);
   if (pa.role == 2 && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&pa.host_counts[HC_CONTACT_ENVS], (uint32_t)pa.clist[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (the contact pass is complete: the list is)
   if (pa.soft_sync && pa.role == 3) {
     // the resume chain follows the main dynamics in its stream: its start IS the dynamics' completion (the third stream's kernels wait for
@@ -49,6 +49,11 @@ __global__ __launch_bounds__(64) void k_list_chain(McrParams pa, McrParams pb, c
     const McrParams& p = pa;
     const int nb = mcr_virtual_blocks(p, p.list_envs_per_block);
     for (int blk = blockIdx.x; blk < nb; blk += ga) {
+      if (CC && p.fuse_collide) {                                  // the env's own contact pass (k_collide skipped it): manifolds, tile events, rewards at the entry poses
+        for (int k = 0; k < p.list_envs_per_block; ++k) { collide_block(p, 0, blk * p.list_envs_per_block + k); __syncthreads(); }
+        __threadfence();                                           // the dynamics lanes read what the collide lanes stored
+        __syncthreads();
+      }
       dynamics_block<CC, CC>(p, 0, blk);                          // (CC: the contact chain, one env per wavefront — the uniform contact sweeps)
       __syncthreads();
       if (p.auto_reset) list_reset_pass(p, blk);
@@ -71,7 +76,7 @@ __global__ __launch_bounds__(64) void k_list_chain(McrParams pa, McrParams pb, c
           const int env = mcr_env_of_slot(p, blk * p.list_envs_per_block + k);
           if (env >= p.env0 + p.nenv) continue;
           const bool v = p.env[env].active ? mcr_touch_verdict(p, env) : false;
-          if (threadIdx.x == 0) p.part_next[env] = v ? 1 : 0;
+          if (threadIdx.x == 0) mcr_set_verdict(p, env, v);
         }
       }
     }
@@ -92,7 +97,12 @@ __global__ __launch_bounds__(64) void k_term_prep(McrParams p) { term_prepare(p,
 
 // soft_sync's one-thread kernels (see mcr_post / mcr_await)
 // (debug bit 13: the side stream's completion is never posted — what a stalled stream looks like to the step's join; tests)
-__global__ void k_post(McrParams p, int w) { if (threadIdx.x == 0 && !((p.debug & 8192) && w == W_SIDE)) mcr_post(p, w); }
+// (fuse_collide, side stream: this step's contact list has had its last reader — the chain and its raster — and is the list the NEXT step's
+// verdict writers fill: emptied here, a kernel boundary and a whole step ahead of the first append)
+__global__ void k_post(McrParams p, int w) {
+  if (threadIdx.x == 0 && w == W_SIDE && p.fuse_collide) p.clist[0] = 0;
+  if (threadIdx.x == 0 && !((p.debug & 8192) && w == W_SIDE)) mcr_post(p, w);
+}
 __global__ void k_await(McrParams p, int w0, int w1) {
   if (threadIdx.x == 0) { if (w0 >= 0) (void)mcr_await(p, w0); if (w1 >= 0) (void)mcr_await(p, w1); }
 }

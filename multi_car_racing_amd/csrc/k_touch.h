@@ -105,6 +105,6 @@ __global__ __launch_bounds__(64) void k_touch(McrParams p) {
   const int env = p.env0 + (int)blockIdx.x;
   if (env >= p.env0 + p.nenv) return;
   const bool v = p.env[env].active ? mcr_touch_verdict(p, env) : false;
-  if (threadIdx.x == 0) p.part[env] = v ? 1 : 0;
+  if (threadIdx.x == 0) { p.part[env] = v ? 1 : 0; if (v && p.fuse_collide) p.clist[1 + atomicAdd(&p.clist[0], 1)] = env; }     // (... and THIS step's contact list: the caller zeroed its count)
 }
 #endif

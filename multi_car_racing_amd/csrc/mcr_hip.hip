@@ -59,6 +59,7 @@ struct mcr_env {
   int use_graph;              // 0 off, 1 on, -1 capture failed once: stay off
   bool concurrent_collide;    // the contact pass may run beside the main dynamics (kernels of different streams do overlap here: probed at create)
   bool verdict_fresh;         // the touch verdicts (k_touch.h) of the next step's entry poses are in place (last step's bookkeeping wrote them)
+  bool last_fused = false;    // ... and so is the next step's contact list (the last step ran with McrParams::fuse_collide)
   uint32_t* status_host;      // [MCR_STATUS_WORDS] mapped host memory the kernels report trouble in (mcr_kernels.h: ST_*)
   uint32_t status_seen[MCR_STATUS_WORDS];   // what mcr_step has already reported
   int32_t step_count;         // steps launched: the epoch of the three-chain step's per-env "contact pass done" words
@@ -376,12 +377,24 @@ static bool stream_bound(const mcr_env* h, hipStream_t st) {
   for (const auto& b : h->bound) if (b.first == st) return b.second;
   return false;
 }
+// Do the contact chain's workgroups run their envs' contact pass themselves (McrParams::fuse_collide)?  With the contact pass beside the
+// dynamics (the list then comes from the one-step-ahead verdicts) and the phase-word ordering (the side stream's last kernel empties the list)
+// EXPERIMENTAL, off unless MCR_FUSED_COLLIDE=1: measured +0.9 % (N = 2 default), +1.8 % (N = 4); but when the contact list is long enough for the
+// chain's 512-register wavefronts to fill the machine at the step's begin (a driving policy's in-phase start: ~1000 contact envs), 7 of 10 rollouts
+// end with an env whose state differs from the unfused rollout's (caught by the touch-verdict check); with <= 512 chain workgroups, or the chain behind
+// k_collide, 0 of 10.  Not understood yet (NOTES 11): not shipped as the default.
+static bool fused_collide(const mcr_env* h, hipStream_t st) {
+  if (!cc_active(h) || !getenv("MCR_FUSED_COLLIDE")) return false;
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &capturing);
+  return h->soft_sync && h->use_graph <= 0 && capturing == hipStreamCaptureStatusNone && stream_bound(h, st);
+}
 static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags) {
   const int B = P.B, N = P.N;
   const int dyn_blocks = (B * P.G + 63) / 64;
   // list launches (contact / deferred / re-spawned envs): small grids whose workgroups walk the device-side lists
   const int lg_col = std::min(B, MCR_LIST_GRID), lg_dyn = std::min((B + MCR_SIDE_ENVS_PER_WAVE - 1) / MCR_SIDE_ENVS_PER_WAVE, h->chain_grid);
-  const int lg_con = std::min(B, 2 * h->chain_grid);             // the contact chain: one env per wavefront
+  const int lg_con = std::min(B, getenv("MCR_CHAIN_GRID") ? atoi(getenv("MCR_CHAIN_GRID")) : 2 * h->chain_grid);             // the contact chain: one env per wavefront
   const int prev_contacts = std::min(B, (int)((volatile uint32_t*)h->status_host)[MCR_STATUS_WORDS + HC_CONTACT_ENVS]);   // (mapped host word: no synchronisation)
   const bool draw = P.obs != nullptr;
   // (the raster workgroups reset the raster order entries they consume; a step that filled the list of its parity without
@@ -435,6 +448,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   // contact pass simply runs first, on the caller's stream.
     const bool cc = cc_active(h);
   P.cc_mode = cc ? 1 : 0; P.epoch = h->step_count; P.epoch_ptr = nullptr;
+  P.fuse_collide = fused_collide(h, st) ? 1 : 0;
   if (h->use_graph > 0) {
     // a replayed graph has constant arguments: the epoch lives in a device-side counter that the first node of the step advances
     // (before the fork: the contact pass and the dynamics read the same value)
@@ -455,7 +469,19 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     const int lg_flags = std::min(B * N, (N <= 2 ? 4 : 32) * MCR_LIST_GRID);
     if (!cc) LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), st, P, 0);
     hipLaunchKernelGGL(k_await, dim3(1), dim3(64), 0, h->s_side, P, (int)W_BEGIN, -1);
-    if (cc) LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), h->s_side, P, 0);     // (W_COL: posted by the chain that follows)
+    if (cc && !P.fuse_collide) LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), h->s_side, P, 0);     // (W_COL: posted by the chain that follows)
+    if (cc && P.fuse_collide && getenv("MCR_FUSE_SERIAL")) {          // (experiment: the fused chain behind the main envs' contact pass, as the unfused one)
+      LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), h->s_side, P, 0);
+      hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, h->s_side, P, (int)W_COL);
+    } else
+    if (cc && P.fuse_collide) {
+      // the contact pass of the main envs on the THIRD stream (idle until the dynamics is through), the contact chain — each workgroup with its
+      // env's own contact pass in front — on the side stream from the step's begin: the chain, the step's critical path when cars pile up, no
+      // longer waits for the 4096-env launch
+      hipLaunchKernelGGL(k_await, dim3(1), dim3(64), 0, h->s_defer, P, (int)W_BEGIN, -1);
+      LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), h->s_defer, P, 0);
+      hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, h->s_defer, P, (int)W_COL);
+    }
     P.split = 0;
     P.role = 2;
     { McrParams Pc = P; Pc.list_envs_per_block = 1; LAUNCH_LDS(5, k_list_chain<true>, lg_con, 64, col::lds_bytes(N), h->s_side, Pc, Pc, 0, lg_con); }   // ONE contact env per wavefront: the uniform contact sweeps (k_dynamics.h)
@@ -463,10 +489,11 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     // (beyond four cars per env the lists hold thousands of cars — ~315 contact envs x 8 at N = 8 — and a few 256-thread workgroups
     // would take them in many rounds at the end of the contact chain, the critical path there; measured N = 2 15.37 -> 15.65 M
     // env-steps/s, N = 4 11.00 -> 11.07, N = 8 5.47 -> 5.44)
-    const int fiv = (view_flags && draw && N <= 4) ? (N <= 2 ? 8 : 64) : 0;
+    const int fiv_maxn = getenv("MCR_FIV_MAXN") ? atoi(getenv("MCR_FIV_MAXN")) : 8;
+    const int fiv = (view_flags && draw && N <= fiv_maxn) ? (N <= 2 ? 8 : 64) : 0;
     // (the contact list's raster and bookkeeping workgroups: sized by the LAST step's list — the lists change slowly — so that a long list,
     // a policy that drives: ~90 envs of 4096, takes one round of workgroups instead of two or three behind the chain, the step's critical path)
-    const int fiv_c = fiv ? std::min(256, std::max(fiv, (prev_contacts * (N + 1) + 3) / 4 + 2)) : 0;
+    const int fiv_c = fiv ? std::min(getenv("MCR_FIV_CAP") ? atoi(getenv("MCR_FIV_CAP")) : 512, std::max(fiv, (prev_contacts * (N + 1) + 3) / 4 + 2)) : 0;
     const int vg_c = std::min(2048, prev_contacts * N + prev_contacts * N / 4 + 8);
     if (view_flags && !fiv) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, h->s_side, P);
     if (draw) { McrParams Pv = P; Pv.flags_blocks = fiv_c; launch_view(h, 6, P.term_cnt ? 2 * B : B, h->s_side, Pv, 0, nullptr, vg_c); }
@@ -487,7 +514,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
       if (draw) { McrParams Pv = P; Pv.role = P.auto_reset ? 5 : 3; Pv.await_tail = 1; Pv.flags_blocks = fiv; launch_view(h, 7, P.term_cnt ? 2 * B : B, st, Pv, 0); }     // ... and the step's join (+ the terminal entries' frames and count)
     }
     P.role = 1;
-    hipLaunchKernelGGL(k_await, dim3(1), dim3(64), 0, h->s_defer, P, (int)W_DYN, cc ? (int)W_COL : -1);
+    hipLaunchKernelGGL(k_await, dim3(1), dim3(64), 0, h->s_defer, P, (int)W_DYN, (cc && !P.fuse_collide) ? (int)W_COL : -1);
     if (P.viewprep_in_flags) hipLaunchKernelGGL(k_flags_viewprep, dim3(dyn_blocks + B * N), dim3(64), 0, h->s_defer, P, dyn_blocks);      // view records + bookkeeping: one launch
     else if (view_flags && !flags_on_caller) hipLaunchKernelGGL(k_flags, dim3(B * N), dim3(64), 0, h->s_defer, P);
     P.use_vorder = 1;
@@ -624,11 +651,18 @@ extern "C" int mcr_step(mcr_env* h, const float* d_actions, uint8_t* d_obs, doub
   // with auto_reset, finished envs are re-spawned on the device and take the action-less first step of their
   // new episode inside this call; the view kernel always runs (it also owns the backward/on-grass flags)
   const int vf = d_actions ? 1 : 0;
-  if (cc_active(h) && !h->verdict_fresh) {   // after reset() / reset_envs() / a state restore / a step without actions: which envs hold a touching car<->car pair?
+  // (the contact list of a fused step is made by the step before it, if that one was fused too: a change of mode — another caller stream, a
+  // give-up — is treated like stale verdicts one way, and empties the half-made list the other way)
+  const bool fz = fused_collide(h, st);
+  if (h->last_fused && !fz) (void)hipMemsetAsync(h->P.clist + (size_t)h->step_parity * (P.B + 1), 0, sizeof(int32_t), st);
+  if (cc_active(h) && (!h->verdict_fresh || (fz && !h->last_fused))) {   // after reset() / reset_envs() / a state restore / a step without actions: which envs hold a touching car<->car pair?
     McrParams Pt = P; Pt.role = 0; Pt.part = h->P.part + (size_t)h->step_parity * P.B;
+    Pt.fuse_collide = fused_collide(h, st) ? 1 : 0; Pt.clist = h->P.clist + (size_t)h->step_parity * (P.B + 1);
+    if (Pt.fuse_collide) (void)hipMemsetAsync(Pt.clist, 0, sizeof(int32_t), st);
     hipLaunchKernelGGL(k_touch, dim3(P.B), dim3(64), 0, st, Pt);
   }
   h->verdict_fresh = vf != 0;             // this step's bookkeeping evaluates the next step's
+  h->last_fused = fz && vf != 0;
   if (h->use_graph > 0 && !h->timing) {
     // The step is a fixed sequence of ~13 launches on up to three streams whose arguments only change with the
     // contact-list parity: it can be replayed as a hipGraph (measured r02: 0.4 % faster — the gaps between the step's
@@ -989,6 +1023,12 @@ extern "C" int mcr_debug_read_counters(mcr_env* h, uint64_t* out4) {
   HIPCHK(hipMemcpy(out4, h->P.counters, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost));
   return MCR_OK;
 }
+extern "C" int mcr_debug_read_counters8(mcr_env* h, uint64_t* out8) {
+  if (!h || !out8) return MCR_ERR_ARG;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out8, h->P.counters, sizeof(uint64_t) * 8, hipMemcpyDeviceToHost));
+  return MCR_OK;
+}
 extern "C" int mcr_concurrent_collide(const mcr_env* h) { return (h && h->split && h->concurrent_collide) ? 1 : 0; }
 extern "C" int mcr_step_ordering(const mcr_env* h) {
   if (!h || !h->split) return 0;
@@ -1003,6 +1043,28 @@ extern "C" int mcr_debug_read_verdict_mismatches(mcr_env* h, uint64_t* out) {
   if (!h || !out) return MCR_ERR_ARG;
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(out, h->P.counters + 4, sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return MCR_OK;
+}
+// the last step's contact partition: part_out[B] (touch verdicts it went by), clist_out[1 + B] (its contact list: count, env ids); synchronises
+extern "C" int mcr_debug_read_partition(mcr_env* h, uint8_t* part_out, int32_t* clist_out) {
+  if (!h || !part_out || !clist_out) return MCR_ERR_ARG;
+  HIPCHK(hipDeviceSynchronize());
+  const size_t B = h->cfg.num_envs, par = (size_t)(h->step_parity ^ 1);
+  HIPCHK(hipMemcpy(part_out, h->P.part + par * B, B, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(clist_out, h->P.clist + par * (B + 1), sizeof(int32_t) * (B + 1), hipMemcpyDeviceToHost));
+  return MCR_OK;
+}
+// diagnostics of the verdict protocol: fill the buffer the NEXT step's verdict writers write (its part_next) with `value` / read it back after that step
+extern "C" int mcr_debug_next_verdicts(mcr_env* h, int fill_value, uint8_t* out_or_null) {
+  if (!h) return MCR_ERR_ARG;
+  if (!out_or_null && (fill_value & 0x100)) {     // (no synchronisation: the fill is enqueued on the null stream, in front of a step launched there)
+    HIPCHK(hipMemsetAsync(h->P.part + (size_t)(h->step_parity ^ 1) * h->cfg.num_envs, fill_value & 0xff, h->cfg.num_envs, 0));
+    return MCR_OK;
+  }
+  HIPCHK(hipDeviceSynchronize());
+  const size_t B = h->cfg.num_envs;
+  if (out_or_null) { HIPCHK(hipMemcpy(out_or_null, h->P.part + (size_t)h->step_parity * B, B, hipMemcpyDeviceToHost)); }       // (after a step: the parity has flipped)
+  else { HIPCHK(hipMemset(h->P.part + (size_t)(h->step_parity ^ 1) * B, fill_value, B)); }
   return MCR_OK;
 }
 extern "C" int mcr_debug_read_env_records(mcr_env* h, void* out, int n_bytes) {

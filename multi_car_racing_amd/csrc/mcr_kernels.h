@@ -40,6 +40,9 @@ struct McrParams {
   int32_t* clist_next;          // the other buffer (steps alternate): its count is zeroed by this step's main k_dynamics
   int32_t* next_counts[4];      // the counts of the OTHER parity's deferred / re-spawn / raster-order lists (the lists of a step live in the
                                 // buffers of its parity): zeroed by this step's main k_dynamics — every reader of them finished last step
+  int32_t fuse_collide;         // (cc_mode) the contact chain's workgroups run the contact pass of their env themselves, in front of its dynamics: the chain
+                                // starts with the step instead of behind k_collide, which skips those envs.  The contact LIST then has to exist before the
+                                // step: whoever settles an env's touch verdict for the next step (mcr_set_verdict) appends it to clist_next
   int32_t split;                // k_collide pass 0 fills part/clist
   int32_t* dlist;               // [1+B] count + env ids deferred by the main k_dynamics (zeroed by k_collide pass 0)
   int32_t* rlist;               // [1+B] count + env ids the main k_dynamics re-spawned in this step (zeroed by k_collide pass 0); filled when respawn_list
@@ -168,6 +171,14 @@ __device__ __forceinline__ void term_finish(const McrParams& p) {
   const int n = min(p.term_cnt[0], p.term_cap);
   for (int i = threadIdx.x; i < n; i += blockDim.x) { const McrTermEnv te = p.term_env[i]; p.consumed_host[te.env] = te.consumed; }
   if (threadIdx.x == 0) *p.term_count_out = n;
+}
+// debug bit 17 (diagnostics of the step's ordering): who touched env `env` when — dbg_stamps[(dyn blocks + env) * 8 + slot] = wall clock | tag << 56
+#define MCR_TRACE(p, env, slot, tag) do { if ((p).debug & 131072) (p).dbg_stamps[((size_t)(((p).B * (p).G + 63) / 64) + (size_t)(env)) * 8 + (slot)] = (unsigned long long)__builtin_amdgcn_s_memrealtime() | ((unsigned long long)(tag) << 56); } while (0)
+// the touch verdict of env `env` for the NEXT step (one writer per env and step), and — fuse_collide — its place in the next step's contact list
+__device__ __forceinline__ void mcr_set_verdict(const McrParams& p, const int env, const bool v) {
+  p.part_next[env] = v ? 1 : 0;
+  MCR_TRACE(p, env, 2, 0x10 | (v ? 1 : 0) | (p.role << 1));
+  if (v && p.fuse_collide) p.clist_next[1 + atomicAdd(&p.clist_next[0], 1)] = env;
 }
 #define MCR_VORDER_ENV_MASK 0xfffff
 #define MCR_VORDER_SLOT_SHIFT 20
