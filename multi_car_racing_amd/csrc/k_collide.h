@@ -652,5 +652,9 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
 // one workgroup per env (the list launches of roles >= 2 call collide_block from k_list_chain.h)
 // (4 wavefronts per SIMD = 16 per CU: with one wavefront per env the 4096 envs of the bench are resident in ONE round; LDS: see lds_bytes)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_collide(McrParams p, int pass) {
+  if ((p.debug & (1 << 18)) && pass == 0 && p.cc_mode) {                  // debug bit 18 (tests): a contact pass that is held up — every workgroup idles ~400 us first
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < 40000ull) __builtin_amdgcn_s_sleep(64);
+  }
   collide_block(p, pass, (int)blockIdx.x);
 }

@@ -619,6 +619,9 @@ __device__ __forceinline__ float cc_position_bl(const CcMass& S, const uint32_t*
 // mode 1: the action-less step of reset() (:408) for envs whose `resetting` flag is set
 // debug bit 8 (256): lane 0 of every wavefront stamps the clock per phase (0 start, 1 state loaded + Car.step +
 // velocity integration, 2 velocity sweeps done, 3 position loop done, 4 end) into p.dbg_stamps[block][8] (main launch, then the launches of roles 2, 3, 4)
+#ifndef MCR_NO_PARK_WAIT
+#define MCR_NO_PARK_WAIT 0            // (1: the missing wait of rounds 3-4, to see tests/test_gpu_parity.py::test_a_late_contact_pass... fail)
+#endif
 #define UNI_I(x) __builtin_amdgcn_readfirstlane(x)
 #define DYN_STAMP(i) do { if ((p.debug & 256) && mode == 0 && threadIdx.x == 0) p.dbg_stamps[((p.role >= 2 ? (p.B * p.G + 63) / 64 + (p.role - 2) * ((p.B + 1) / 2) : 0) + blk) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 // CC = false: a launch that cannot hold an env with touching car<->car contacts (the main launch of the three-chain step; contacts off;
@@ -1265,6 +1268,16 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
     int dfr = unfinished ? 1 : 0;
     for (int o = 1; o < p.G; o <<= 1) dfr |= __shfl_xor(dfr, o);          // env-wide: its cars finish the step together
     if (!dfr && lane_ok && agent == 0) p.dpart[env] = 0;                  // (the mark of an earlier step's deferral)
+    if (dfr && run && p.cc_mode && mode == 0 && p.role == 1 && !MCR_NO_PARK_WAIT) {
+      // Parking overwrites the env's ENTRY poses, which the contact pass — running beside this launch — reads: not before it is through with
+      // the env.  (It nearly always is by now, 90 us into this kernel; a contact pass held up for longer — a machine full of other work — is
+      // not: found in round 5 as rollouts that diverged when the contact chain filled every SIMD at the step's begin.)
+      const int bound = (p.debug & 4096) ? (1 << 14) : (1 << 24);
+      const int epoch = mcr_epoch(p);
+      int spin = 0;
+      for (; spin < bound && __hip_atomic_load(&p.collide_epoch[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch; ++spin) __builtin_amdgcn_s_sleep(8);
+      if (spin == bound) { atomicAdd(&p.counters[5], 1ull); mcr_raise(p, ST_SPIN_GIVEUP); }
+    }
     if (dfr && run) {
       // park the post-velocity-phase state exactly as the resume launch's prologue reloads it
 #pragma unroll

@@ -379,12 +379,11 @@ static bool stream_bound(const mcr_env* h, hipStream_t st) {
 }
 // Do the contact chain's workgroups run their envs' contact pass themselves (McrParams::fuse_collide)?  With the contact pass beside the
 // dynamics (the list then comes from the one-step-ahead verdicts) and the phase-word ordering (the side stream's last kernel empties the list)
-// EXPERIMENTAL, off unless MCR_FUSED_COLLIDE=1: measured +0.9 % (N = 2 default), +1.8 % (N = 4); but when the contact list is long enough for the
-// chain's 512-register wavefronts to fill the machine at the step's begin (a driving policy's in-phase start: ~1000 contact envs), 7 of 10 rollouts
-// end with an env whose state differs from the unfused rollout's (caught by the touch-verdict check); with <= 512 chain workgroups, or the chain behind
-// k_collide, 0 of 10.  Not understood yet (NOTES 11): not shipped as the default.
+// — measured +0.9 % (N = 2 default), +1.8 % (N = 4).  MCR_UNFUSED_COLLIDE=1: off (the round-4 topology).  (Round 5's first attempt diverged in 7
+// of 10 rollouts with ~1000 contact envs: the chain's wavefronts, filling the machine at the step's begin, held the contact pass of the OTHER
+// envs up long enough for a latent race of the contact-pass-beside-the-dynamics mode to show — k_dynamics.h "Parking overwrites", NOTES 11.)
 static bool fused_collide(const mcr_env* h, hipStream_t st) {
-  if (!cc_active(h) || !getenv("MCR_FUSED_COLLIDE")) return false;
+  if (!cc_active(h) || getenv("MCR_UNFUSED_COLLIDE")) return false;
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(st, &capturing);
   return h->soft_sync && h->use_graph <= 0 && capturing == hipStreamCaptureStatusNone && stream_bound(h, st);

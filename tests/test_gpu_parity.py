@@ -341,6 +341,37 @@ def test_side_stream_is_bit_identical_to_single_stream(torch_cuda, B, N):
     a1.close(); a2.close()
 
 
+def test_a_late_contact_pass_still_reads_the_entry_poses(torch_cuda, lib):
+    """The contact pass runs BESIDE the main dynamics (streams=2, N <= 7) and reads the poses the step was entered with; an env whose position
+    iterations the main launch does not finish is parked — poses overwritten — for the resume chain.  Parking has to wait for the contact pass
+    of that env (k_dynamics.h, "Parking overwrites"): normally it is done 50 us earlier, and the missing wait went unnoticed for two rounds,
+    until a machine full of contact chain wavefronts held the pass up.  Debug bit 18 holds every workgroup of the pass up for ~400 us; stretches
+    of hard steering at full gas park moving cars (a build with -DMCR_NO_PARK_WAIT=1 fails here within 70 steps)."""
+    torch = torch_cuda
+    B, N, seed = 512, 2, 23
+    a1 = _make(B, N, seed, contacts=True, auto_reset=True, max_episode_steps=150, use_random_direction=True, streams=1)
+    a2 = _make(B, N, seed, contacts=True, auto_reset=True, max_episode_steps=150, use_random_direction=True, streams=2)
+    a1.reset(); a2.reset()
+    lib.check(a2.L.mcr_debug_set(a2.h, 1 << 18))
+    g = torch.Generator(device="cuda"); g.manual_seed(9)
+    for k in range(320):
+        a = torch.zeros((B, N, 3), device="cuda")
+        ph = (k // 40) % 4
+        a[..., 1] = 1.0
+        a[..., 0] = (torch.rand((B, N), device="cuda", generator=g) * 2 - 1) * (1.0 if ph in (1, 3) else 0.1)
+        if ph == 2: a[:, 0, 1] = 0.0; a[:, 0, 2] = 0.8
+        _, r1, d1, _ = a1.step(a); _, r2, d2, _ = a2.step(a)
+        assert torch.equal(r1, r2) and torch.equal(d1, d2), f"step {k}: envs {torch.nonzero((r1 != r2).any(1)).flatten().tolist()[:8]}"
+    s1, s2 = a1.get_state(), a2.get_state()
+    for key in s1:
+        assert np.array_equal(s1[key], s2[key]), key
+    ctr = np.zeros(4, np.uint64)
+    lib.check(a2.L.mcr_debug_read_counters(a2.h, lib.ptr(ctr)))
+    assert ctr[0] > 20 and ctr[0] == ctr[1], f"deferred {ctr[0]} resumed {ctr[1]}: the rollout parked too few envs"
+    assert a2.verdict_mismatches() == 0 and not a2.status_words().any()
+    a1.close(); a2.close()
+
+
 def test_rgb_array_skid_particles_match_oracle(torch_cuda, oracle):
     """Car.draw(viewer, True) (:564): the skid particles of gym's Car.step ("Skid trace": skid_start, _create_particle,
     30 points per particle, the last 30 particles per car, road / mud colour) drawn into render('rgb_array') frames.
