@@ -25,13 +25,14 @@ rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
 # in-kernel phase clocks of the SHIPPED raster and dynamics kernels, raster ablations, SQ counters of the raster alone
 python tools/view_phases.py 2>&1 | grep -v amdgpu.ids > gpurun_out/profiles_$R/${R}_view_phases.txt
 python tools/dyn_phases.py 2>&1 | grep -v amdgpu.ids > gpurun_out/profiles_$R/${R}_dyn_phases.txt
+DRIVE=1 python tools/dyn_phases.py 2>&1 | grep -v amdgpu.ids > gpurun_out/profiles_$R/${R}_dyn_phases_drive.txt
 N=8 python tools/dyn_phases.py 2>&1 | grep -v amdgpu.ids > gpurun_out/profiles_$R/${R}_dyn_phases_n8.txt
 for n in 2 8; do N=$n python tools/collide_phases.py 2>&1 | grep -v amdgpu.ids >> gpurun_out/profiles_$R/${R}_collide_phases.txt; done
 STREAMS=1 python tools/ablate_view.py 2>&1 | grep -v amdgpu.ids > gpurun_out/profiles_$R/${R}_view_ablation.txt
 bash tools/pmc_view.sh 2>&1 | grep -v amdgpu.ids | tail -24 > gpurun_out/profiles_$R/${R}_view_counters.txt
 rm -rf gpurun_out/pmc_view
 # the other configurations of the DESIGN table (one bench line each)
-for cfg in "--streams 1" "--stagger 0" "--obs 0" "--agents 8" "--agents 1" "--agents 4" "--emulate-world 8" "--actions drive" "--envs 16384" "--envs 32768" "--rccl"; do
+for cfg in "--streams 1" "--stagger 0" "--obs 0" "--agents 8" "--agents 1" "--agents 4" "--emulate-world 8" "--actions drive" "--envs 16384" "--envs 32768" "--rccl" "--terminal-obs 1"; do
   tag=$(echo $cfg | tr -d ' -')
   timeout 400 python bench.py --no-cpu-baseline $cfg > gpurun_out/profiles_$R/bench_$tag.json 2> /dev/null
 done
