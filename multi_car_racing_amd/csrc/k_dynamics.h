@@ -1117,6 +1117,16 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
       if (agent == 0) for (int i = 0; i < ccn; ++i) pcrec[pool_base + i][0] |= (uint32_t)xisl[leader_lane + (int)(pcrec[pool_base + i][0] & 15u)] << 24;   // the contact's island
     }
     __syncthreads();
+    // the joints' anchors of this car's slot order, ONCE per step and opaque to the optimiser: left to itself it re-reads them from the
+    // shapes table inside the position sweeps (registers are short here) — 20 global loads and 350 SGPR reloads per sweep, each load a
+    // round trip to L2 on the sweep's dependent chain (found in round 5's ISA; the sweep took 5.9 us)
+    float jax[4], jay[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      jax[q] = S.anchor_x[q]; jay[q] = S.anchor_y[q];
+      if (wave_perm) { jax[q] = pick4(wq[q], S.anchor_x[0], S.anchor_x[1], S.anchor_x[2], S.anchor_x[3]); jay[q] = pick4(wq[q], S.anchor_y[0], S.anchor_y[1], S.anchor_y[2], S.anchor_y[3]); }
+      asm volatile("" : "+v"(jax[q]), "+v"(jay[q]));
+    }
     const int pos_iters_cc = (p.debug & 64) ? 2 : 60;
 #ifdef MCR_POSLOOP_PROFILE        // build-time diagnostic (MCR_EXTRA_CFLAGS=-DMCR_POSLOOP_PROFILE, tools/posloop_profile.py): where a contact position sweep goes
     unsigned long long pt[5] = {0, 0, 0, 0, 0}, pt0 = 0; int pn = 0;
@@ -1165,9 +1175,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
         if (active) {
 #pragma unroll
           for (int q = 3; q >= 0; --q) {
-            float ax = S.anchor_x[q], ay = S.anchor_y[q];
-            if (wave_perm) { ax = pick4(wq[q], S.anchor_x[0], S.anchor_x[1], S.anchor_x[2], S.anchor_x[3]); ay = pick4(wq[q], S.anchor_y[0], S.anchor_y[1], S.anchor_y[2], S.anchor_y[3]); }
-            bool jo = joint_position(J[q], b[0], b[q + 1], ax, ay, lcx, lcy, mH, iH, mW, iW, hull_rot);
+            bool jo = joint_position(J[q], b[0], b[q + 1], jax[q], jay[q], lcx, lcy, mH, iH, mW, iW, hull_rot);
             jointsOk = jointsOk && jo;
           }
         }
@@ -1227,9 +1235,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
         }
 #pragma unroll
         for (int q = 3; q >= 0; --q) {
-          float ax = S.anchor_x[q], ay = S.anchor_y[q];
-          if (wave_perm) { ax = pick4(wq[q], S.anchor_x[0], S.anchor_x[1], S.anchor_x[2], S.anchor_x[3]); ay = pick4(wq[q], S.anchor_y[0], S.anchor_y[1], S.anchor_y[2], S.anchor_y[3]); }
-          bool jo = joint_position(J[q], b[0], b[q + 1], ax, ay, lcx, lcy, mH, iH, mW, iW, hull_rot);
+          bool jo = joint_position(J[q], b[0], b[q + 1], jax[q], jay[q], lcx, lcy, mH, iH, mW, iW, hull_rot);
           jointsOk = jointsOk && jo;
         }
       }

@@ -256,7 +256,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
         // contact chain itself — 585 us for its slowest wavefront, a sequential Gauss-Seidel over the contacts between the joint sweeps)
         // (round 3, phase-word path, contact pass beside / in front of the dynamics: N = 5 8.99 / 8.50 M env-steps/s, N = 6 7.87 / 7.49,
         // N = 7 7.16 / 6.80, N = 8 4.90 / 5.47 — up to seven cars per env it runs beside)
-        h->concurrent_collide = N <= (getenv("MCR_CC_MAXN") ? atoi(getenv("MCR_CC_MAXN")) : 7) && !getenv("MCR_SEQUENTIAL_COLLIDE") && (B * G + 63) / 64 <= h->simd_count && kernels_overlap(h->s_defer, h->s_side);
+        h->concurrent_collide = N <= (getenv("MCR_CC_MAXN") ? atoi(getenv("MCR_CC_MAXN")) : 8) && !getenv("MCR_SEQUENTIAL_COLLIDE") && (B * G + 63) / 64 <= h->simd_count && kernels_overlap(h->s_defer, h->s_side);
         h->split = true;
       } else (void)hipStreamDestroy(h->s_side);
     }
@@ -499,7 +499,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, h->s_side, P, (int)W_SIDE);
     P.role = 1;
     P.viewprep_in_flags = (view_flags && draw && h->viewprep_in_flags) ? 1 : 0;
-    const bool flags_on_caller = view_flags && draw && !P.viewprep_in_flags && N <= 7;   // (N = 8: the raster would share the machine with the bookkeeping: 6.70 -> 6.49 M env-steps/s, round 5)
+    const bool flags_on_caller = view_flags && draw && !P.viewprep_in_flags && N <= (getenv("MCR_FOC_MAXN") ? atoi(getenv("MCR_FOC_MAXN")) : 7);   // (N = 8: the raster would share the machine with the bookkeeping: 6.70 -> 6.49 M env-steps/s, round 5)
     LAUNCH(1, k_dynamics<false>, dyn_blocks, 64, st, P, 0);          // (the main envs: no touching car<->car pair)
     P.role = 3;
     {

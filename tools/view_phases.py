@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from multi_car_racing_amd.vec_env import VecMultiCarRacing
 from multi_car_racing_amd import _lib
-B, N = 4096, 2
+B, N = 4096, int(os.environ.get("N", "2"))
 env = VecMultiCarRacing(B, N, seed=1, use_random_direction=True, auto_reset=True)
 env.reset()
 pool = torch.rand((64, B, N, 3), device="cuda"); pool[..., 0] = pool[..., 0] * 2 - 1
