@@ -963,9 +963,20 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
       float4* const xt = (float4*)&xv[0][0];              // the transposition buffer: xt[body lane] = (vx, vy, w, -)
       // (a car's joints reach their limits at full steering lock or in a crash: the env none of whose joints is at one — the state is a constant
       // of the step — runs its sweeps with the limit-free form of all four, chosen ONCE: no branch inside the loop)
-      auto sweeps = [&](auto lim_tag) {
+      // (... and so is the manifold count: an env with up to FOUR manifolds — all but a handful per rollout — keeps their constants in registers for
+      // the whole phase: 530-570 ticks per manifold and sweep with one or two, 680-810 with three or four (registers run out: the joints' state
+      // starts to travel through AGPRs); beyond four they rotate through a record loaded a manifold ahead (960-1190 ticks: ~26 register moves,
+      // 12 LDS reads and ~40 AGPR moves per manifold).  Measured and not kept: two records used alternately instead of the rotation (1080
+      // ticks), the constants in lane registers read out with v_readlane (slower than the LDS prefetch).  tools/posloop_profile.py VEL=1)
+      auto sweeps = [&](auto lim_tag, auto cnt_tag) {
         constexpr bool LIM = decltype(lim_tag)::value;
+        constexpr int CNT = decltype(cnt_tag)::value;     // 1 .. 4: exactly that many manifolds; 0: any number
         VcRec cur = vc_load(vcpool[0]);
+        VcRec second = cur, third = cur, fourth = cur;
+        if constexpr (CNT >= 2) second = vc_load(vcpool[1]);
+        if constexpr (CNT >= 3) third = vc_load(vcpool[2]);
+        if constexpr (CNT >= 4) fourth = vc_load(vcpool[3]);
+        const int meta0 = __builtin_amdgcn_readlane(cmeta, 0), meta1 = __builtin_amdgcn_readlane(cmeta, 1), meta2 = __builtin_amdgcn_readlane(cmeta, 2), meta3 = __builtin_amdgcn_readlane(cmeta, 3);
         for (int it = 0; it < vel_iters; ++it) {
           VP_BEGIN();
           if (run) {
@@ -980,9 +991,13 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
           const float4 c4 = xt[lane];
           float cx = c4.x, cy = c4.y, cw = c4.z;
           VP_MARK(1);
+          if constexpr (CNT == 1) cc_velocity_bl(CM, cur, meta0, cimp, 0, lane, cx, cy, cw);
+          else if constexpr (CNT == 2) { cc_velocity_bl(CM, cur, meta0, cimp, 0, lane, cx, cy, cw); cc_velocity_bl(CM, second, meta1, cimp, 1, lane, cx, cy, cw); }
+          else if constexpr (CNT == 3) { cc_velocity_bl(CM, cur, meta0, cimp, 0, lane, cx, cy, cw); cc_velocity_bl(CM, second, meta1, cimp, 1, lane, cx, cy, cw); cc_velocity_bl(CM, third, meta2, cimp, 2, lane, cx, cy, cw); }
+          else if constexpr (CNT == 4) { cc_velocity_bl(CM, cur, meta0, cimp, 0, lane, cx, cy, cw); cc_velocity_bl(CM, second, meta1, cimp, 1, lane, cx, cy, cw); cc_velocity_bl(CM, third, meta2, cimp, 2, lane, cx, cy, cw); cc_velocity_bl(CM, fourth, meta3, cimp, 3, lane, cx, cy, cw); }
+          else
           for (int i = 0; i < ccnu; ++i) {
-            VcRec nxt = cur;
-            if (ccnu > 1) nxt = vc_load(vcpool[i + 1 == ccnu ? 0 : i + 1]);     // the next manifold's constants, a manifold ahead of their use
+            const VcRec nxt = vc_load(vcpool[i + 1 == ccnu ? 0 : i + 1]);     // the next manifold's constants, a manifold ahead of their use
             cc_velocity_bl(CM, cur, __builtin_amdgcn_readlane(cmeta, i), cimp, i, lane, cx, cy, cw);
             cur = nxt;
           }
@@ -998,7 +1013,13 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
       bool any_limit = false;
 #pragma unroll
       for (int q = 0; q < 4; ++q) any_limit = any_limit || J[q].limit != 0;
-      if (__any(any_limit)) sweeps(std::true_type{}); else sweeps(std::false_type{});
+      const bool lim_any = __any(any_limit) != 0;
+      using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
+      if (ccnu == 1) { if (lim_any) sweeps(std::true_type{}, I1{}); else sweeps(std::false_type{}, I1{}); }
+      else if (ccnu == 2) { if (lim_any) sweeps(std::true_type{}, I2{}); else sweeps(std::false_type{}, I2{}); }
+      else if (ccnu == 3) { if (lim_any) sweeps(std::true_type{}, I3{}); else sweeps(std::false_type{}, I3{}); }
+      else if (ccnu == 4) { if (lim_any) sweeps(std::true_type{}, I4{}); else sweeps(std::false_type{}, I4{}); }
+      else { if (lim_any) sweeps(std::true_type{}, I0{}); else sweeps(std::false_type{}, I0{}); }
       if (lane < ccnu) { float* vc = vcpool[lane]; vc[cc::VC_P0 + 4] = cimp.n1; vc[cc::VC_P0 + 5] = cimp.t1; vc[cc::VC_P1 + 4] = cimp.n2; vc[cc::VC_P1 + 5] = cimp.t2; }   // for StoreImpulses
     } else
     for (int it = 0; it < vel_iters; ++it) {
@@ -1026,7 +1047,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
 #ifdef MCR_POSLOOP_PROFILE
     if ((p.debug & 256) && (p.debug & 65536) && mode == 0 && threadIdx.x == 0 && p.role == 2) {
       unsigned long long* o = p.dbg_stamps + ((size_t)((p.B * p.G + 63) / 64) + blk) * 8;
-      o[5] = vt[0] | (vt[1] << 32); o[6] = vt[2] | (vt[3] << 32);
+      o[5] = vt[0] | (vt[1] << 32); o[6] = vt[2] | (vt[3] << 32); o[7] = (unsigned long long)ccn;
     }
 #endif
   }
@@ -1145,9 +1166,14 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
         const unsigned long long actm = __ballot(active);
         if (!actm) break;
         PP_BEGIN();
+        // (the fixed-point probe — did the sweep move anything? — on every fourth sweep, the last one among them: a fixed point is still
+        // there three sweeps later, with the same poses; 15 values kept and compared, a twelfth of a sweep)
+        const bool probe = (it & 3) == 3;
         float ox[5], oy[5], oa[5];
+        if (probe) {
 #pragma unroll
-        for (int k = 0; k < 5; ++k) { ox[k] = b[k].cx; oy[k] = b[k].cy; oa[k] = b[k].a; }
+          for (int k = 0; k < 5; ++k) { ox[k] = b[k].cx; oy[k] = b[k].cy; oa[k] = b[k].a; }
+        }
         PP_MARK(0);
         float myMin = 0.0f;                               // min separation over the contacts of this car's island
         {
@@ -1180,10 +1206,13 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
           }
         }
         PP_MARK(2);
-        bool moved = false;
+        bool moved = true;
+        if (probe) {
+          moved = false;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) moved = moved || ox[k] != b[k].cx || oy[k] != b[k].cy || oa[k] != b[k].a;
-        const unsigned long long okm = __ballot(jointsOk), mvm = __ballot(moved);
+          for (int k = 0; k < 5; ++k) moved = moved || ox[k] != b[k].cx || oy[k] != b[k].cy || oa[k] != b[k].a;
+        }
+        const unsigned long long okm = __ballot(jointsOk), mvm = probe ? __ballot(moved) : ~0ull;
         if (active) {
           bool ok = jointsOk, mv = moved;
           if (ccn > 0) { ok = myMin >= -3.0f * B2_LINEAR_SLOP && (okm & imask) == imask; mv = (mvm & imask) != 0ull; }
@@ -1262,7 +1291,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
 #ifdef MCR_POSLOOP_PROFILE
     if ((p.debug & 256) && !(p.debug & 65536) && mode == 0 && threadIdx.x == 0 && p.role == 2) {
       unsigned long long* o = p.dbg_stamps + ((size_t)((p.B * p.G + 63) / 64) + blk) * 8;
-      o[5] = pt[0] | ((unsigned long long)pn << 48); o[6] = pt[1] | (pt[2] << 32); o[7] = pt[3];
+      o[5] = pt[0] | ((unsigned long long)pn << 48); o[6] = pt[1] | (pt[2] << 32); o[7] = pt[3] | ((unsigned long long)ccn << 48);
     }
 #endif
     if (wave_perm) {                                     // the (joint, wheel) register sets back where the rest of the step expects them

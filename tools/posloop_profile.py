@@ -25,16 +25,20 @@ for k in range(600):
         st = buf.reshape(nb + 2 * ns, 8)[nb:nb + ns]
         if VEL:
             for r in st[(st[:, 0] > 0) & (st[:, 5] > 0)]:
-                rows.append((180, int(r[5] & np.uint64(0xffffffff)), int(r[5] >> np.uint64(32)), int(r[6] & np.uint64(0xffffffff)), int(r[6] >> np.uint64(32))))
+                rows.append((180, int(r[5] & np.uint64(0xffffffff)), int(r[5] >> np.uint64(32)), int(r[6] & np.uint64(0xffffffff)), int(r[6] >> np.uint64(32)), int(r[7])))
             continue
         ok = (st[:, 0] > 0) & ((st[:, 5] >> np.uint64(48)) > 0)
         for r in st[ok]:
             n = int(r[5] >> np.uint64(48))
-            rows.append((n, int(r[5] & np.uint64((1 << 48) - 1)), int(r[6] & np.uint64(0xffffffff)), int(r[6] >> np.uint64(32)), int(r[7])))
+            rows.append((n, int(r[5] & np.uint64((1 << 48) - 1)), int(r[6] & np.uint64(0xffffffff)), int(r[6] >> np.uint64(32)), int(r[7] & np.uint64((1 << 48) - 1)), int(r[7] >> np.uint64(48))))
 d = np.array(rows, np.float64)
 print(f"N={N}: {len(d)} contact wavefronts, sweeps per wavefront mean {d[:, 0].mean():.1f}; ticks per sweep (2.1 GHz: 1000 ticks = 0.48 us)")
 names = ["4 joints", "exchange out + barrier", "leader: contacts (cc_velocity)", "exchange in"] if VEL else ["exchange out + barrier", "leader: contacts (cc_position)", "exchange in + 4 joint corrections", "island bookkeeping + 2 barriers"]
 for i, n in enumerate(names):
     per = d[:, 1 + i] / d[:, 0]
     print(f"   {n:36s} mean {per.mean():8.0f}  median {np.median(per):8.0f}")
-print(f"   {'total':36s} mean {(d[:, 1:].sum(1) / d[:, 0]).mean():8.0f}")
+print(f"   {'total':36s} mean {(d[:, 1:5].sum(1) / d[:, 0]).mean():8.0f}")
+print("by the env's manifold count (wavefronts; ticks per sweep by segment; total):")
+for c in sorted(set(d[:, 5].astype(int))):
+    m = d[d[:, 5] == c]
+    print(f"   {c:2d} manifolds: {len(m):6d}   " + "  ".join(f"{(m[:, 1 + i] / m[:, 0]).mean():7.0f}" for i in range(4)) + f"   {(m[:, 1:5].sum(1) / m[:, 0]).mean():8.0f}   sweeps {m[:, 0].mean():.1f}")
