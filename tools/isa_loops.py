@@ -33,3 +33,15 @@ for a, b, tgt in sorted(loops):
     lines = collections.Counter(l for _, l in ins[a:b + 1] if l)
     top = ", ".join(f"{f}:{l}x{m}" for (f, l), m in lines.most_common(6))
     print(f"{tgt:>12} [{a:6d},{b:6d}] n={n:5d}  " + " ".join(f"{k}={v}" for k, v in sorted(c.items())) + "   lines " + top)
+# innermost loops that touch memory or reload spilled scalars (the things that do not belong into a latency-bound sweep)
+print("\ninnermost loops with memory traffic or scalar reloads:")
+S = sorted(set((a, b, t) for a, b, t in loops))
+for a, b, tgt in S:
+    if any(a <= a2 and b2 <= b and (a2, b2) != (a, b) for a2, b2, _ in S): continue
+    body = ins[a:b + 1]
+    c = collections.Counter(kind(t.split()[0]) for t, _ in body)
+    rel = sum(1 for t, _ in body if re.match(r"v_readlane_b32 s\d+, v\d+, \d+", t))
+    sl = sum(1 for t, _ in body if t.startswith("s_load"))
+    if c["vmem"] or c["scratch"] or rel or sl:
+        lines = collections.Counter(l for _, l in body if l)
+        print(f"{tgt:>12} n={b - a + 1:5d} vmem={c['vmem']} s_load={sl} scratch={c['scratch']} sgpr_reloads={rel} acc={c['acc']}  lines " + ", ".join(f"{f}:{l}x{m}" for (f, l), m in lines.most_common(4)))
