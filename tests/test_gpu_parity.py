@@ -608,13 +608,13 @@ def test_contacts_are_solved_in_island_dfs_order(torch_cuda, oracle, N):
     env.close()
 
 
-@pytest.mark.parametrize("N", [2, 4])
+@pytest.mark.parametrize("N", [2, 4, 8])
 def test_driving_policy_pile_ups_bit_exact(torch_cuda, oracle, N):
     """A policy that DRIVES (bench.py --actions drive: full gas, a little steering noise) with every other car braking for a while:
     the cars behind run into them — several manifolds per env, islands of more than two cars at N = 4, warm-started impulses over hundreds
     of steps, contact chain and main launch side by side (streams=2).  State and rewards bit-exact, every step."""
     torch = torch_cuda
-    B, seed, steps = 24, 7000 + N, 360
+    B, seed, steps = (24 if N < 8 else 16), 7000 + N, 360
     env = _make(B, N, seed, contacts=True, use_random_direction=True, streams=2); env.reset()
     orcs = _oracles(oracle, B, N, seed, contacts=True, use_random_direction=True)
     rng = np.random.RandomState(N)
@@ -631,7 +631,8 @@ def test_driving_policy_pile_ups_bit_exact(torch_cuda, oracle, N):
         most = max(most, max(nc)); contact_steps += sum(1 for c in nc if c > 0)
         if k % 40 == 39: _assert_state_equal(env, orcs, f"pile-up step {k}")
     _assert_state_equal(env, orcs, "pile-up, end")
-    assert contact_steps > 40 and most >= 3, (contact_steps, most)
+    # (the contact chain's velocity sweeps come in forms for exactly 1, 2, 3, 4 and "any number" of manifolds per env: all of them run here)
+    assert contact_steps > 40 and most >= {2: 3, 4: 4, 8: 5}[N], (contact_steps, most)
     env.close()
 
 
