@@ -627,7 +627,7 @@ __device__ __forceinline__ float cc_position_bl(const CcMass& S, const uint32_t*
 // CC = false: a launch that cannot hold an env with touching car<->car contacts (the main launch of the three-chain step; contacts off;
 // N = 1) — none of the contact code is compiled in, and the contact-free loops keep the registers and the schedule they get alone
 // UNI (with CC): the launch holds ONE env per wavefront (the contact chain, role 2): the contact sweeps run in the uniform form above
-template <bool CC, bool UNI = false>
+template <bool CC, bool UNI = false, bool COOP = false>
 __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mode, const int blk) {
   static_assert(CC || !UNI, "the uniform contact sweeps are part of the contact build");
   using namespace dyn;
@@ -1549,7 +1549,8 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
   bool have_box = false;
   // (three-chain step, main launch: the record and the polygons are produced by k_viewprep, beside the bookkeeping kernel,
   // and only the two words this kernel holds are written here)
-  const bool prep_later = p.viewprep_in_flags && p.role == 1 && mode == 0;
+  // (... list chains, COOP: by viewprep_list_block right behind this function, on five lanes per car)
+  const bool prep_later = (p.viewprep_in_flags && p.role == 1 && mode == 0) || (COOP && mode == 0);
   if (p.obs != nullptr && !respawn && prep_later) {
     float* vp = p.viewp + (size_t)ci * MCR_VIEWP_FLOATS;
     vp[VP_SCORE] = __int_as_float(mcr_label_value(reward_shown));

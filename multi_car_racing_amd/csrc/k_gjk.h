@@ -54,7 +54,7 @@ __device__ __forceinline__ SV make_vertex(const float4 va, const float4 vb, int 
 // tile: hull vertices v0 v1 | v2 v3 (CCW, b2PolygonShape::Set order), tn = 3 or 4;  PB: the car fixture in body-local
 // coordinates;  xfB = (p.x, p.y, sin, cos) of its body.  Both shapes have radius b2_polygonRadius.
 template <bool SWAP>
-__device__ __noinline__ bool touching_as(const float4 va, const float4 vb, const int tn, const McrPoly* __restrict__ PB, const float4 xfB) {
+__device__ __forceinline__ bool touching_as(const float4 va, const float4 vb, const int tn, const McrPoly* __restrict__ PB, const float4 xfB) {
   SV v0 = make_vertex<SWAP>(va, vb, 0, PB, xfB, 0), v1 = v0, v2 = v0;
   int count = 1;
   int saveA0 = 0, saveA1 = 0, saveA2 = 0, saveB0 = 0, saveB1 = 0, saveB2 = 0, saveCount = 0;

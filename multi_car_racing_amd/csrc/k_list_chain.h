@@ -54,7 +54,8 @@ __global__ __launch_bounds__(64) void k_list_chain(McrParams pa, McrParams pb, c
         __threadfence();                                           // the dynamics lanes read what the collide lanes stored
         __syncthreads();
       }
-      dynamics_block<CC, CC>(p, 0, blk);                          // (CC: the contact chain, one env per wavefront — the uniform contact sweeps)
+      dynamics_block<CC, CC, true>(p, 0, blk);                    // (CC: the contact chain, one env per wavefront — the uniform contact sweeps)
+      viewprep_list_block(p, blk);                                 // (the envs' view records and car polygons, five lanes per car)
       __syncthreads();
       if (p.auto_reset) list_reset_pass(p, blk);
       if (with_flags) {

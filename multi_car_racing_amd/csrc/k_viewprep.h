@@ -12,13 +12,15 @@
 __device__ __forceinline__ double vprep_sign(double x) { return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : 0.0); }
 
 // (carf / card: per-car SoA fields at stride BN — the live state, or the state the cars of a terminal entry ended their episode with)
+// `parts`: bit 0 camera + HUD rectangles + grass range + the hull's four polygons, bits 1..4 wheel 0..3 (box + stripe) — the list chains hand the
+// parts of a car to five lanes (viewprep_list_block), everybody else computes all of them on the car's lane
 __device__ __forceinline__ void viewprep_car(const McrShapes& S, const float* __restrict__ carf, const double* __restrict__ card, const int BN, const int ci,
-                                             float* __restrict__ viewp, float* __restrict__ carpoly, const double h_ratio, const double t_now) {
+                                             float* __restrict__ viewp, float* __restrict__ carpoly, const double h_ratio, const double t_now, const uint32_t parts = 31u) {
   struct { const float* carf; const double* card; double h_ratio; } p = {carf, card, h_ratio};
   float* vp = viewp + (size_t)ci * MCR_VIEWP_FLOATS;
   float4* cp4 = (float4*)(carpoly + (size_t)ci * MCR_CARPOLY_FLOATS);
   int* cnt = (int*)(carpoly + (size_t)ci * MCR_CARPOLY_FLOATS + MCR_CARPOLY_NOFF);
-  {
+  if (parts & 1u) {
     const float hcx = p.carf[(CF_CX + 0) * BN + ci], hcy = p.carf[(CF_CY + 0) * BN + ci], ha = p.carf[(CF_A + 0) * BN + ci];
     const float hvx = p.carf[(CF_VX + 0) * BN + ci], hvy = p.carf[(CF_VY + 0) * BN + ci];
     const Xf hxf = xf_of(v2(hcx, hcy), ha, v2(S.hull_lcx, S.hull_lcy));
@@ -63,7 +65,7 @@ __device__ __forceinline__ void viewprep_car(const McrShapes& S, const float* __
       vp[VP_GRASS + 4] = __int_as_float(inside_field ? 1 : 0);
     }
   }
-  {
+  if (parts & 1u) {
     const float hvx = p.carf[(CF_VX + 0) * BN + ci], hvy = p.carf[(CF_VY + 0) * BN + ci];
     const float ha = p.carf[(CF_A + 0) * BN + ci], w1a = p.carf[(CF_A + 1) * BN + ci], hw = p.carf[(CF_W + 0) * BN + ci];
     const double vx = (double)hvx, vy = (double)hvy;
@@ -93,6 +95,7 @@ __device__ __forceinline__ void viewprep_car(const McrShapes& S, const float* __
     vp[VP_HUDTOP] = hud_top;
   }
   for (int k = 0; k < 4; ++k) {
+    if (!((parts >> (1 + k)) & 1u)) continue;
     const Xf wxf = xf_of(v2(p.carf[(CF_CX + 1 + k) * BN + ci], p.carf[(CF_CY + 1 + k) * BN + ci]), p.carf[(CF_A + 1 + k) * BN + ci], v2(0.0f, 0.0f));
     V2 w[4];
 #pragma unroll
@@ -120,6 +123,7 @@ __device__ __forceinline__ void viewprep_car(const McrShapes& S, const float* __
     }
     cnt[2 * k + 1] = ns;
   }
+  if (parts & 1u)
   for (int k = 0; k < 4; ++k) {
     const Xf hxf = xf_of(v2(p.carf[(CF_CX + 0) * BN + ci], p.carf[(CF_CY + 0) * BN + ci]), p.carf[(CF_A + 0) * BN + ci], v2(S.hull_lcx, S.hull_lcy));
     const McrPoly& P = S.hull[k];
@@ -142,6 +146,24 @@ __device__ __forceinline__ void viewprep_block(const McrParams& p, const int blk
   const McrEnvState es = p.env[env];
   if (!es.active || es.just_reset) return;
   viewprep_car(*p.shapes, p.carf, p.card, p.BN, env * p.N + agent, p.viewp, p.carpoly, p.h_ratio, es.t);
+}
+// The view records and car polygons of a list chain's envs (roles 2 / 3, k_list_chain.h), right behind their dynamics: the chain is the
+// step's critical path and its wavefront holds a handful of cars — a car's record is ten f64 sincos on ONE lane (13 us) when the car's lane
+// computes it; here FIVE lanes share it (camera + HUD + hull | wheel 0..3), reading the state the car lanes have just written back.  The same
+// code as everywhere (viewprep_car): identical records.  VP_SCORE / VP_OLDFLAGS are written by the dynamics (it holds the values).
+__device__ __forceinline__ void viewprep_list_block(const McrParams& p, const int blk) {
+  if (p.obs == nullptr) return;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // (same wavefront, same L1: the write-back above is complete and visible to the other lanes)
+  const int lane = threadIdx.x & 63, ncars = p.list_envs_per_block * p.N;
+  for (int base = 0; base < ncars * 8; base += 64) {
+    const int w = base + lane, c = w >> 3, part = w & 7;
+    if (c >= ncars || part >= 5) continue;
+    const int env = mcr_env_of_slot(p, blk * p.list_envs_per_block + c / p.N);
+    if (env >= p.env0 + p.nenv) continue;
+    const McrEnvState es = p.env[env];
+    if (!es.active || es.resetting) continue;                   // (an env that ended its episode here: the reset pass draws up its first record)
+    viewprep_car(*p.shapes, p.carf, p.card, p.BN, env * p.N + c % p.N, p.viewp, p.carpoly, p.h_ratio, es.t, 1u << part);
+  }
 }
 // Terminal entry of env `env` (if this step's dynamics made one): view records and car polygons from the state its cars ended the episode
 // with (lanes 0 .. N-1), and the tiles' recolour flags before the reset pass clears them.  Called by the env's reset pass, one wavefront.
