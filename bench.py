@@ -341,10 +341,15 @@ def main():
                                 "side_dynamics": ms[5] / max(nl[5], 1), "side_view": ms[6] / max(nl[6], 1), "side_reset_pass_kernel": ms[7] / max(nl[7], 1)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, bool(args.obs))
-        print(json.dumps(out))
+        line = json.dumps(out)
     env.close()
     if world > 1 or args.rccl:
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE json line is the last thing on stdout: RCCL's banner (printf into libc's buffer, flushed at exit when stdout is a pipe or a
+        # file) would otherwise land behind it
+        sys.stdout.flush(); ctypes.CDLL(None).fflush(None)
+        print(line); sys.stdout.flush()
 
 
 if __name__ == "__main__":
