@@ -17,6 +17,7 @@ assert torch.equal(oa, ob)
 g = torch.Generator(device="cuda"); g.manual_seed(9)
 pool = torch.rand((128, B, N, 3), device="cuda", generator=g); pool[..., 0] = pool[..., 0] * 2 - 1
 pool[:, :, 1, 1] = torch.clamp(pool[:, :, 1, 1] + 0.4, max=1.0) if N > 1 else pool[:, :, 0, 1]      # car 1 is faster: rear-ends happen
+if int(os.environ.get("DRIVE", "0")): pool[..., 0] *= 0.1; pool[..., 1] = 1.0; pool[..., 2] = 0.0      # bench.py --actions drive: ~1000 contact envs per step
 bad = torch.zeros((), dtype=torch.int64, device="cuda")
 t0 = time.perf_counter(); resets = 0
 for k in range(steps):
@@ -30,6 +31,6 @@ for k in range(steps):
             print("MISMATCH by step", k); break
 sa, sb = a.get_state(), b.get_state()
 state_ok = all(np.array_equal(sa[key], sb[key]) for key in sa)
-print(f"N={N} B={B}: {k + 1} steps in {time.perf_counter() - t0:.1f} s, mismatching comparisons: {int(bad)}, final state identical: {state_ok}, verdict mismatches: {a.verdict_mismatches()}, counters {a.debug_counters().tolist()}")
+print(f"N={N} B={B}{' DRIVE' if int(os.environ.get('DRIVE', '0')) else ''}: {k + 1} steps in {time.perf_counter() - t0:.1f} s, mismatching comparisons: {int(bad)}, final state identical: {state_ok}, verdict mismatches: {a.verdict_mismatches()}, counters {a.debug_counters().tolist()}")
 a.close(); b.close()
 sys.exit(0 if int(bad) == 0 and state_ok else 1)
