@@ -57,6 +57,7 @@ struct mcr_env {
   struct StepGraph { bool valid; McrParams P; hipStream_t st; int view_flags; hipGraph_t graph; hipGraphExec_t exec; };
   StepGraph sg[2];
   int use_graph;              // 0 off, 1 on, -1 capture failed once: stay off
+  bool unfused_collide;       // MCR_UNFUSED_COLLIDE=1 (read at create): the contact chain waits for the all-env contact pass instead of running its envs' own
   bool concurrent_collide;    // the contact pass may run beside the main dynamics (kernels of different streams do overlap here: probed at create)
   bool verdict_fresh;         // the touch verdicts (k_touch.h) of the next step's entry poses are in place (last step's bookkeeping wrote them)
   bool last_fused = false;    // ... and so is the next step's contact list (the last step ran with McrParams::fuse_collide)
@@ -127,7 +128,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   if (cfg->num_envs < 1 || cfg->num_envs > MCR_VORDER_ENV_MASK || cfg->num_agents < 1 || cfg->num_agents > MCR_MAX_AGENTS) { g_err = "num_envs/num_agents out of range"; return MCR_ERR_ARG; }
   HIPCHK(hipSetDevice(cfg->device));
   mcr_env* h = new mcr_env();
-  h->cfg = *cfg; h->timing = 0; h->any_reset = false; h->use_graph = 0; h->verdict_fresh = false; h->concurrent_collide = false; h->sg[0].valid = h->sg[1].valid = false;
+  h->cfg = *cfg; h->timing = 0; h->any_reset = false; h->use_graph = 0; h->verdict_fresh = false; h->concurrent_collide = false; h->unfused_collide = getenv("MCR_UNFUSED_COLLIDE") != nullptr; h->sg[0].valid = h->sg[1].valid = false;
   h->vorder_dirty[0] = h->vorder_dirty[1] = false;
   // A list chain is a serial solver chain per wavefront (2 envs each).  With i.i.d. random actions and two cars per env the
   // contact list holds ~15 envs of 4096, but a policy that actually drives (or N = 8: ~340 envs) fills it with hundreds, and
@@ -256,7 +257,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
         // contact chain itself — 585 us for its slowest wavefront, a sequential Gauss-Seidel over the contacts between the joint sweeps)
         // (round 3, phase-word path, contact pass beside / in front of the dynamics: N = 5 8.99 / 8.50 M env-steps/s, N = 6 7.87 / 7.49,
         // N = 7 7.16 / 6.80, N = 8 4.90 / 5.47 — up to seven cars per env it runs beside)
-        h->concurrent_collide = N <= (getenv("MCR_CC_MAXN") ? atoi(getenv("MCR_CC_MAXN")) : 8) && !getenv("MCR_SEQUENTIAL_COLLIDE") && (B * G + 63) / 64 <= h->simd_count && kernels_overlap(h->s_defer, h->s_side);
+        h->concurrent_collide = N <= 8 && !getenv("MCR_SEQUENTIAL_COLLIDE") && (B * G + 63) / 64 <= h->simd_count && kernels_overlap(h->s_defer, h->s_side);
         h->split = true;
       } else (void)hipStreamDestroy(h->s_side);
     }
@@ -383,7 +384,7 @@ static bool stream_bound(const mcr_env* h, hipStream_t st) {
 // of 10 rollouts with ~1000 contact envs: the chain's wavefronts, filling the machine at the step's begin, held the contact pass of the OTHER
 // envs up long enough for a latent race of the contact-pass-beside-the-dynamics mode to show — k_dynamics.h "Parking overwrites", NOTES 11.)
 static bool fused_collide(const mcr_env* h, hipStream_t st) {
-  if (!cc_active(h) || getenv("MCR_UNFUSED_COLLIDE")) return false;
+  if (!cc_active(h) || h->unfused_collide) return false;
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(st, &capturing);
   return h->soft_sync && h->use_graph <= 0 && capturing == hipStreamCaptureStatusNone && stream_bound(h, st);
@@ -393,7 +394,7 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
   const int dyn_blocks = (B * P.G + 63) / 64;
   // list launches (contact / deferred / re-spawned envs): small grids whose workgroups walk the device-side lists
   const int lg_col = std::min(B, MCR_LIST_GRID), lg_dyn = std::min((B + MCR_SIDE_ENVS_PER_WAVE - 1) / MCR_SIDE_ENVS_PER_WAVE, h->chain_grid);
-  const int lg_con = std::min(B, getenv("MCR_CHAIN_GRID") ? atoi(getenv("MCR_CHAIN_GRID")) : 2 * h->chain_grid);             // the contact chain: one env per wavefront
+  const int lg_con = std::min(B, 2 * h->chain_grid);             // the contact chain: one env per wavefront
   const int prev_contacts = std::min(B, (int)((volatile uint32_t*)h->status_host)[MCR_STATUS_WORDS + HC_CONTACT_ENVS]);   // (mapped host word: no synchronisation)
   const bool draw = P.obs != nullptr;
   // (the raster workgroups reset the raster order entries they consume; a step that filled the list of its parity without
@@ -469,10 +470,6 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     if (!cc) LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), st, P, 0);
     hipLaunchKernelGGL(k_await, dim3(1), dim3(64), 0, h->s_side, P, (int)W_BEGIN, -1);
     if (cc && !P.fuse_collide) LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), h->s_side, P, 0);     // (W_COL: posted by the chain that follows)
-    if (cc && P.fuse_collide && getenv("MCR_FUSE_SERIAL")) {          // (experiment: the fused chain behind the main envs' contact pass, as the unfused one)
-      LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), h->s_side, P, 0);
-      hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, h->s_side, P, (int)W_COL);
-    } else
     if (cc && P.fuse_collide) {
       // the contact pass of the main envs on the THIRD stream (idle until the dynamics is through), the contact chain — each workgroup with its
       // env's own contact pass in front — on the side stream from the step's begin: the chain, the step's critical path when cars pile up, no
@@ -488,18 +485,17 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     // (beyond four cars per env the lists hold thousands of cars — ~315 contact envs x 8 at N = 8 — and a few 256-thread workgroups
     // would take them in many rounds at the end of the contact chain, the critical path there; measured N = 2 15.37 -> 15.65 M
     // env-steps/s, N = 4 11.00 -> 11.07, N = 8 5.47 -> 5.44)
-    const int fiv_maxn = getenv("MCR_FIV_MAXN") ? atoi(getenv("MCR_FIV_MAXN")) : 8;
-    const int fiv = (view_flags && draw && N <= fiv_maxn) ? (N <= 2 ? 8 : 64) : 0;
+    const int fiv = (view_flags && draw && N <= 8) ? (N <= 2 ? 8 : 64) : 0;
     // (the contact list's raster and bookkeeping workgroups: sized by the LAST step's list — the lists change slowly — so that a long list,
     // a policy that drives: ~90 envs of 4096, takes one round of workgroups instead of two or three behind the chain, the step's critical path)
-    const int fiv_c = fiv ? std::min(getenv("MCR_FIV_CAP") ? atoi(getenv("MCR_FIV_CAP")) : 512, std::max(fiv, (prev_contacts * (N + 1) + 3) / 4 + 2)) : 0;
+    const int fiv_c = fiv ? std::min(512, std::max(fiv, (prev_contacts * (N + 1) + 3) / 4 + 2)) : 0;
     const int vg_c = std::min(2048, prev_contacts * N + prev_contacts * N / 4 + 8);
     if (view_flags && !fiv) hipLaunchKernelGGL(k_flags_list, dim3(lg_flags), dim3(64), 0, h->s_side, P);
     if (draw) { McrParams Pv = P; Pv.flags_blocks = fiv_c; launch_view(h, 6, P.term_cnt ? 2 * B : B, h->s_side, Pv, 0, nullptr, vg_c); }
     hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, h->s_side, P, (int)W_SIDE);
     P.role = 1;
     P.viewprep_in_flags = (view_flags && draw && h->viewprep_in_flags) ? 1 : 0;
-    const bool flags_on_caller = view_flags && draw && !P.viewprep_in_flags && N <= (getenv("MCR_FOC_MAXN") ? atoi(getenv("MCR_FOC_MAXN")) : 7);   // (N = 8: the raster would share the machine with the bookkeeping: 6.70 -> 6.49 M env-steps/s, round 5)
+    const bool flags_on_caller = view_flags && draw && !P.viewprep_in_flags && N <= 7;   // (N = 8: the raster would share the machine with the bookkeeping: 6.70 -> 6.49 M env-steps/s, round 5)
     LAUNCH(1, k_dynamics<false>, dyn_blocks, 64, st, P, 0);          // (the main envs: no touching car<->car pair)
     P.role = 3;
     {
