@@ -195,11 +195,12 @@ def test_physics_only_b4096_sampled_oracles(torch_cuda, oracle):
     assert n_contacts > 0, "no sampled env ever held a car<->car contact"
 
 
-@pytest.mark.parametrize("knobs, ordering", [({}, 1), ({"MCR_SOFT_SYNC": "0"}, 2), ({"MCR_SOFT_SYNC": "0", "MCR_STOP_EVENTS": "0"}, 0)])
+@pytest.mark.parametrize("knobs, ordering", [({}, 1), ({"MCR_UNFUSED_COLLIDE": "1"}, 1), ({"MCR_SOFT_SYNC": "0"}, 2), ({"MCR_SOFT_SYNC": "0", "MCR_STOP_EVENTS": "0"}, 0)])
 def test_every_stream_ordering_of_the_step_matches_the_oracle(torch_cuda, oracle, monkeypatch, knobs, ordering):
     """The three-chain step orders its streams through phase words in device memory (default where kernels overlap) or through
     events (profilers that serialise kernels, a wait that gave up, graph capture) — completed by the launches they mark or recorded
-    behind them: every variant is the same computation — rear-end collisions, TimeLimit resets and refills included."""
+    behind them; with phase words the contact chain runs its envs' contact pass itself (default) or waits for the all-env pass
+    (MCR_UNFUSED_COLLIDE=1): every variant is the same computation — rear-end collisions, TimeLimit resets and refills included."""
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     import gc
