@@ -20,6 +20,8 @@ pool[:, :, 1, 1] = torch.clamp(pool[:, :, 1, 1] + 0.4, max=1.0) if N > 1 else po
 if int(os.environ.get("DRIVE", "0")): pool[..., 0] *= 0.1; pool[..., 1] = 1.0; pool[..., 2] = 0.0      # bench.py --actions drive: ~1000 contact envs per step
 bad = torch.zeros((), dtype=torch.int64, device="cuda")
 t0 = time.perf_counter(); resets = 0
+from multi_car_racing_amd import _lib
+cnt = np.zeros(B, np.int32); peak = 0; seen = []          # contact envs per step, sampled (how full the contact chain's launch was)
 for k in range(steps):
     act = pool[(k * 7) % 128]
     o1, r1, d1, _ = a.step(act); o2, r2, d2, _ = b.step(act)
@@ -27,10 +29,11 @@ for k in range(steps):
     if k % 64 == 63:
         bad += (o1 != o2).any().to(torch.int64)
         resets += int(d1.sum())
+        _lib.check(a.L.mcr_debug_read_contact_counts(a.h, _lib.ptr(cnt))); n_c = int((cnt > 0).sum()); peak = max(peak, n_c); seen.append(n_c)
         if int(bad) != 0:
             print("MISMATCH by step", k); break
 sa, sb = a.get_state(), b.get_state()
 state_ok = all(np.array_equal(sa[key], sb[key]) for key in sa)
-print(f"N={N} B={B}{' DRIVE' if int(os.environ.get('DRIVE', '0')) else ''}: {k + 1} steps in {time.perf_counter() - t0:.1f} s, mismatching comparisons: {int(bad)}, final state identical: {state_ok}, verdict mismatches: {a.verdict_mismatches()}, counters {a.debug_counters().tolist()}")
+print(f"N={N} B={B}{' DRIVE' if int(os.environ.get('DRIVE', '0')) else ''}: {k + 1} steps in {time.perf_counter() - t0:.1f} s, mismatching comparisons: {int(bad)}, final state identical: {state_ok}, verdict mismatches: {a.verdict_mismatches()}, counters {a.debug_counters().tolist()}, contact envs per sampled step: mean {np.mean(seen) if seen else 0:.0f} peak {peak}")
 a.close(); b.close()
 sys.exit(0 if int(bad) == 0 and state_ok else 1)
