@@ -22,12 +22,15 @@
 
 namespace dyn {
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 struct Joint {
   float ix, iy, iz, im;          // accumulated impulse (x,y,z) + motor impulse (warm start state)
   float motorSpeed;
   int limit;                     // 0 inactive, 1 at lower, 2 at upper
   // per-step temporaries
   float rAx, rAy, rBx, rBy;
+  float nrAy;                    // -rAy: cross(w, rA) = w * (nrAy, rAx) and cross(rA, P) = rAx * Py + nrAy * Px as one packed multiply each
   float exx, eyx, ezx, eyy, ezy, ezz;   // symmetric K (b2Mat33 m_mass): ex=(exx,eyx,ezx) ey=(eyx,eyy,ezy) ez=(ezx,ezy,ezz)
   float motorMass;
   // pieces of b2Mat33::Solve33 / Solve22 that depend on K only: Box2D recomputes them in every call, here they are
@@ -83,7 +86,7 @@ __device__ __forceinline__ void joint_init(Joint& J, Body& A, Body& B, float anc
                                            float mA, float iA, float mB, float iB) {
   Rot qA = rot_of(A.a);
   V2 rA = rmul(qA, v2(anchx, anchy) - v2(lcx, lcy));
-  J.rAx = rA.x; J.rAy = rA.y; J.rBx = 0.0f; J.rBy = 0.0f;
+  J.rAx = rA.x; J.rAy = rA.y; J.rBx = 0.0f; J.rBy = 0.0f; J.nrAy = -rA.y;
   J.exx = mA + mB + J.rAy * J.rAy * iA;
   J.eyx = -J.rAy * J.rAx * iA;
   J.ezx = -J.rAy * iA;
@@ -106,11 +109,19 @@ __device__ __forceinline__ void joint_init(Joint& J, Body& A, Body& B, float anc
 }
 
 // b2RevoluteJoint::SolveVelocityConstraints.  LIMITS = false: for joints whose limit is known to be inactive in every lane of the wavefront
-// (the caller checked: J.limit == 0 — the state is a constant of the step) — the same operations as the !lim path below, without the
-// selects and masks that carry the other path's results along.
+// (the caller checked: J.limit == 0 — the state is a constant of the step).
+// Written on PAIRS of floats (v_pk_mul_f32 / v_pk_add_f32: one issue slot for two lanes of a vector — and issue slots of one wavefront are what
+// the 180 sweeps cost): the same IEEE operations on the same operands as Box2D's scalar code, grouped so that the two components of a
+// vector expression travel together.  What makes the grouping exact:
+//   a - b == a + (-b) == -(b - a),  (-a) * b == a * (-b) == -(a * b),  a * b == b * a,  a + b == b + a   (bit for bit, signs of zeros included);
+//   x + (-0.0f) == x for every x (so a lane without an active limit adds an impulse of -0.0f instead of skipping the addition).
+// Solve33's two cross products and the dot products that consume them run as (cross(b, ez), cross(ey, b)) pairs: with the second halves of
+// the constant pairs NEGATED (E_k = (ez_k, -ey_k)), (p_i, r_i) = s * E_j - t * E_k for scalars s, t out of (bx, by, bz) — plain packed
+// operations with a broadcast scalar, no mixed signs.
 template <bool LIMITS = true>
 __device__ __forceinline__ void joint_velocity(Joint& J, Body& A, Body& B, float mA, float iA, float mB, float iB, float maxImpulse) {
-  float vAx = A.vx, vAy = A.vy, wA = A.w, vBx = B.vx, vBy = B.vy, wB = B.w;
+  f2 vA = {A.vx, A.vy}, vB = {B.vx, B.vy};
+  float wA = A.w, wB = B.w;
   {
     float Cdot = wB - wA - J.motorSpeed;
     float impulse = -J.motorMass * Cdot;
@@ -119,40 +130,54 @@ __device__ __forceinline__ void joint_velocity(Joint& J, Body& A, Body& B, float
     impulse = J.im - old;
     wA -= iA * impulse; wB += iB * impulse;
   }
+  const f2 nr = {J.nrAy, J.rAx};                     // cross(w, rA) = w * nr
   // Cdot1 = vB + cross(wB, rB) - vA - cross(wA, rA)   with rB == 0
-  const float c1x = (vBx - vAx) - (-wA * J.rAy);
-  const float c1y = (vBy - vAy) - (wA * J.rAx);
-  // Box2D's two branches (limit active: 3x3 solve, and a 2x2 re-solve when the limit impulse would change sign; limit
-  // inactive: 2x2 solve) share the 2x2 solve and the application of the impulse here — same expressions and operand
-  // order per lane, but a wavefront whose lanes disagree about the limit state (front wheels of a batch of cars with
-  // random steering: nearly always) no longer runs both copies of them.
-  const bool lim = LIMITS && J.limit != 0;
-  float impx = 0.0f, impy = 0.0f, impz = 0.0f;
-  float rhsx = -c1x, rhsy = -c1y;
-  bool two = !lim;
-  if (lim) {
-    float c2 = wB - wA;
-    float sx, sy, sz; solve33(J, c1x, c1y, c2, sx, sy, sz);
-    impx = -sx; impy = -sy; impz = -sz;
-    float newImpulse = J.iz + impz;
-    bool reduce = (J.limit == 1) ? (newImpulse < 0.0f) : (newImpulse > 0.0f);
-    if (reduce) {
-      rhsx = -c1x + J.iz * J.ezx; rhsy = -c1y + J.iz * J.ezy;
-      impz = -J.iz;
-      J.iz = 0.0f;
-      two = true;
-    } else J.iz += impz;
+  const f2 c1 = (vB - vA) - wA * nr;
+  const f2 kd = {J.eyy, J.exx};
+  f2 imp;
+  float impz = -0.0f;
+  if constexpr (LIMITS) {
+    // Box2D's two branches (limit active: 3x3 solve, and a 2x2 re-solve when the limit impulse would change sign; limit inactive: 2x2 solve)
+    // computed side by side for every lane and selected: lanes are free on a wavefront that is alone on its SIMD, branches are not
+    const bool lim = J.limit != 0;
+    const float bz = wB - wA;
+    const f2 E0 = {J.ezx, -J.eyx}, E1 = {J.ezy, -J.eyy}, E2 = {J.ezz, -J.ezy};
+    const f2 cyz01 = {J.cyz0, J.cyz1};
+    // b2Mat33::Solve33(c1x, c1y, bz)
+    const f2 m = c1 * cyz01;
+    const float sx = J.idet33 * ((m.x + m.y) + bz * J.cyz2);
+    const f2 pr0 = c1.y * E2 - bz * E1;              // (by ez2 - bz ez1, ey1 bz - ey2 by)
+    const f2 pr1 = bz * E0 - c1.x * E2;              // (bz ez0 - bx ez2, ey2 bx - ey0 bz)
+    const f2 pr2 = c1.x * E1 - c1.y * E0;            // (bx ez1 - by ez0, ey0 by - ey1 bx)
+    const f2 syz = J.idet33 * ((J.exx * pr0 + J.eyx * pr1) + J.ezx * pr2);
+    const float newImpulse = J.iz + (-syz.y);
+    // at the lower limit the impulse may not become negative, at the upper one not positive (x < 0 <=> -x > 0: one sign flip, one compare)
+    const bool reduce = lim && __uint_as_float(__float_as_uint(newImpulse) ^ (J.limit == 1 ? 0x80000000u : 0u)) > 0.0f;
+    const f2 ezxy = {J.ezx, J.ezy};
+    const f2 rhsR = -c1 + J.iz * ezxy;
+    const f2 rhs = {reduce ? rhsR.x : -c1.x, reduce ? rhsR.y : -c1.y};
+    // b2Mat22::Solve22(rhs)
+    const f2 s22 = J.idet22 * (kd * rhs - J.eyx * rhs.yx);
+    const bool two = !lim || reduce;
+    imp.x = two ? s22.x : -sx; imp.y = two ? s22.y : -syz.x;
+    impz = lim ? (reduce ? -J.iz : -syz.y) : -0.0f;
+    J.iz = reduce ? 0.0f : J.iz + impz;              // (no limit: 0 + -0 = 0)
+  } else {
+    const f2 rhs = -c1;
+    imp = J.idet22 * (kd * rhs - J.eyx * rhs.yx);
   }
-  if (two) solve22(J, rhsx, rhsy, impx, impy);
-  J.ix += impx; J.iy += impy;
-  vAx = vAx - mA * impx; vAy = vAy - mA * impy;
+  f2 ixy = {J.ix, J.iy};
+  ixy = ixy + imp;
+  J.ix = ixy.x; J.iy = ixy.y;
+  vA = vA - mA * imp;
   {
-    const float t = J.rAx * impy - J.rAy * impx;
-    wA -= iA * (lim ? t + impz : t);
+    const f2 tt = nr * imp;                          // cross(rA, imp) = rAx impy - rAy impx
+    const float t = tt.y + tt.x;
+    wA -= iA * (LIMITS ? t + impz : t);
   }
-  vBx = vBx + mB * impx; vBy = vBy + mB * impy;
-  if (lim) wB += iB * impz;
-  A.vx = vAx; A.vy = vAy; A.w = wA; B.vx = vBx; B.vy = vBy; B.w = wB;
+  vB = vB + mB * imp;
+  if constexpr (LIMITS) wB += iB * impz;
+  A.vx = vA.x; A.vy = vA.y; A.w = wA; B.vx = vB.x; B.vy = vB.y; B.w = wB;
 }
 
 // sin/cos of the hull angle, remembered across joint_position calls: the hull is ~100x heavier than a wheel, so its
