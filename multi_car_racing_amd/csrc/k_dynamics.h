@@ -108,6 +108,57 @@ __device__ __forceinline__ void joint_init(Joint& J, Body& A, Body& B, float anc
   B.w += iB * (J.im + J.iz);
 }
 
+// b2RevoluteJoint::SolveVelocityConstraints, Box2D's scalar form — what the contact chains run: their sweep loops are short of registers and the
+// pairs of joint_velocity (below) push state into scratch there (contact envs' velocity phase 186 -> 197 us measured).  LIMITS = false: for joints whose limit is known to be inactive in every lane of the wavefront
+// (the caller checked: J.limit == 0 — the state is a constant of the step) — the same operations as the !lim path below, without the
+// selects and masks that carry the other path's results along.
+template <bool LIMITS = true>
+__device__ __forceinline__ void joint_velocity_scalar(Joint& J, Body& A, Body& B, float mA, float iA, float mB, float iB, float maxImpulse) {
+  float vAx = A.vx, vAy = A.vy, wA = A.w, vBx = B.vx, vBy = B.vy, wB = B.w;
+  {
+    float Cdot = wB - wA - J.motorSpeed;
+    float impulse = -J.motorMass * Cdot;
+    float old = J.im;
+    J.im = mcr_clamp(J.im + impulse, -maxImpulse, maxImpulse);
+    impulse = J.im - old;
+    wA -= iA * impulse; wB += iB * impulse;
+  }
+  // Cdot1 = vB + cross(wB, rB) - vA - cross(wA, rA)   with rB == 0
+  const float c1x = (vBx - vAx) - (-wA * J.rAy);
+  const float c1y = (vBy - vAy) - (wA * J.rAx);
+  // Box2D's two branches (limit active: 3x3 solve, and a 2x2 re-solve when the limit impulse would change sign; limit
+  // inactive: 2x2 solve) share the 2x2 solve and the application of the impulse here — same expressions and operand
+  // order per lane, but a wavefront whose lanes disagree about the limit state (front wheels of a batch of cars with
+  // random steering: nearly always) no longer runs both copies of them.
+  const bool lim = LIMITS && J.limit != 0;
+  float impx = 0.0f, impy = 0.0f, impz = 0.0f;
+  float rhsx = -c1x, rhsy = -c1y;
+  bool two = !lim;
+  if (lim) {
+    float c2 = wB - wA;
+    float sx, sy, sz; solve33(J, c1x, c1y, c2, sx, sy, sz);
+    impx = -sx; impy = -sy; impz = -sz;
+    float newImpulse = J.iz + impz;
+    bool reduce = (J.limit == 1) ? (newImpulse < 0.0f) : (newImpulse > 0.0f);
+    if (reduce) {
+      rhsx = -c1x + J.iz * J.ezx; rhsy = -c1y + J.iz * J.ezy;
+      impz = -J.iz;
+      J.iz = 0.0f;
+      two = true;
+    } else J.iz += impz;
+  }
+  if (two) solve22(J, rhsx, rhsy, impx, impy);
+  J.ix += impx; J.iy += impy;
+  vAx = vAx - mA * impx; vAy = vAy - mA * impy;
+  {
+    const float t = J.rAx * impy - J.rAy * impx;
+    wA -= iA * (lim ? t + impz : t);
+  }
+  vBx = vBx + mB * impx; vBy = vBy + mB * impy;
+  if (lim) wB += iB * impz;
+  A.vx = vAx; A.vy = vAy; A.w = wA; B.vx = vBx; B.vy = vBy; B.w = wB;
+}
+
 // b2RevoluteJoint::SolveVelocityConstraints.  LIMITS = false: for joints whose limit is known to be inactive in every lane of the wavefront
 // (the caller checked: J.limit == 0 — the state is a constant of the step).
 // Written on PAIRS of floats (v_pk_mul_f32 / v_pk_add_f32: one issue slot for two lanes of a vector — and issue slots of one wavefront are what
@@ -153,13 +204,14 @@ __device__ __forceinline__ void joint_velocity(Joint& J, Body& A, Body& B, float
     const float newImpulse = J.iz + (-syz.y);
     // at the lower limit the impulse may not become negative, at the upper one not positive (x < 0 <=> -x > 0: one sign flip, one compare)
     const bool reduce = lim && __uint_as_float(__float_as_uint(newImpulse) ^ (J.limit == 1 ? 0x80000000u : 0u)) > 0.0f;
+    // the 2x2 solve for BOTH right-hand sides it can get (no limit: -c1; the limit impulse taken back: -c1 + iz (ezx, ezy)) beside the 3x3
+    // solve instead of behind its verdict: eight more packed operations, five fewer on the sweep's dependency chain — which is what a
+    // wavefront alone on its SIMD pays for
     const f2 ezxy = {J.ezx, J.ezy};
-    const f2 rhsR = -c1 + J.iz * ezxy;
-    const f2 rhs = {reduce ? rhsR.x : -c1.x, reduce ? rhsR.y : -c1.y};
-    // b2Mat22::Solve22(rhs)
-    const f2 s22 = J.idet22 * (kd * rhs - J.eyx * rhs.yx);
-    const bool two = !lim || reduce;
-    imp.x = two ? s22.x : -sx; imp.y = two ? s22.y : -syz.x;
+    const f2 rhsN = -c1, rhsR = -c1 + J.iz * ezxy;
+    const f2 s22N = J.idet22 * (kd * rhsN - J.eyx * rhsN.yx), s22R = J.idet22 * (kd * rhsR - J.eyx * rhsR.yx);
+    const f2 base = {lim ? -sx : s22N.x, lim ? -syz.x : s22N.y};
+    imp.x = reduce ? s22R.x : base.x; imp.y = reduce ? s22R.y : base.y;
     impz = lim ? (reduce ? -J.iz : -syz.y) : -0.0f;
     J.iz = reduce ? 0.0f : J.iz + impz;              // (no limit: 0 + -0 = 0)
   } else {
@@ -178,6 +230,13 @@ __device__ __forceinline__ void joint_velocity(Joint& J, Body& A, Body& B, float
   vB = vB + mB * imp;
   if constexpr (LIMITS) wB += iB * impz;
   A.vx = vA.x; A.vy = vA.y; A.w = wA; B.vx = vB.x; B.vy = vB.y; B.w = wB;
+}
+
+// the form a build runs: pairs in the builds without contact code (main launch, resume chain: registers to spare), Box2D's scalar form in the
+// builds that carry the contact chains (dynamics_block<CC = true>: their code generation stays what round 5 tuned)
+template <bool PK, bool LIMITS = true>
+__device__ __forceinline__ void joint_velocity_as(Joint& J, Body& A, Body& B, float mA, float iA, float mB, float iB, float maxImpulse) {
+  if constexpr (PK) joint_velocity<LIMITS>(J, A, B, mA, iA, mB, iB, maxImpulse); else joint_velocity_scalar<LIMITS>(J, A, B, mA, iA, mB, iB, maxImpulse);
 }
 
 // sin/cos of the hull angle, remembered across joint_position calls: the hull is ~100x heavier than a wheel, so its
@@ -948,7 +1007,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
 #pragma unroll
           for (int q = 0; q < 4; ++q) { oi[q * 4] = J[q].ix; oi[q * 4 + 1] = J[q].iy; oi[q * 4 + 2] = J[q].iz; oi[q * 4 + 3] = J[q].im; }
 #pragma unroll
-          for (int q = 3; q >= 0; --q) joint_velocity(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);
+          for (int q = 3; q >= 0; --q) joint_velocity_as<!CC>(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);
 #pragma unroll
           for (int k = 0; k < 5; ++k) changed = changed || ob[k].vx != b[k].vx || ob[k].vy != b[k].vy || ob[k].w != b[k].w;
 #pragma unroll
@@ -961,15 +1020,15 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
       // whose cars has one there runs its 180 sweeps with the limit-free form of those two joints (36 instructions less per sweep).
       if (!__any(J[2].limit != 0 || J[3].limit != 0)) {
         for (int it = 0; it < 180; ++it) {
-          joint_velocity<false>(J[3], b[0], b[4], mH, iH, mW, iW, maxImpulse);
-          joint_velocity<false>(J[2], b[0], b[3], mH, iH, mW, iW, maxImpulse);
-          joint_velocity<true>(J[1], b[0], b[2], mH, iH, mW, iW, maxImpulse);
-          joint_velocity<true>(J[0], b[0], b[1], mH, iH, mW, iW, maxImpulse);
+          joint_velocity_as<!CC, false>(J[3], b[0], b[4], mH, iH, mW, iW, maxImpulse);
+          joint_velocity_as<!CC, false>(J[2], b[0], b[3], mH, iH, mW, iW, maxImpulse);
+          joint_velocity_as<!CC, true>(J[1], b[0], b[2], mH, iH, mW, iW, maxImpulse);
+          joint_velocity_as<!CC, true>(J[0], b[0], b[1], mH, iH, mW, iW, maxImpulse);
         }
       } else {
         for (int it = 0; it < 180; ++it) {
 #pragma unroll
-          for (int q = 3; q >= 0; --q) joint_velocity(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);
+          for (int q = 3; q >= 0; --q) joint_velocity_as<!CC>(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);
         }
       }
     }
@@ -1006,7 +1065,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
           VP_BEGIN();
           if (run) {
 #pragma unroll
-            for (int q = 3; q >= 0; --q) joint_velocity<LIM>(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);
+            for (int q = 3; q >= 0; --q) joint_velocity_scalar<LIM>(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);
           }
           VP_MARK(0);
           if (run) {
@@ -1051,7 +1110,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
       VP_BEGIN();
       if (run) {
 #pragma unroll
-        for (int q = 3; q >= 0; --q) joint_velocity(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);
+        for (int q = 3; q >= 0; --q) joint_velocity_scalar(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);
       }
       VP_MARK(0);
       if (ccn > 0 && !(p.debug & 1024)) {
