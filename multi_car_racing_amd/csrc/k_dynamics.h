@@ -177,7 +177,7 @@ __device__ __forceinline__ void joint_velocity(Joint& J, Body& A, Body& B, float
     float Cdot = wB - wA - J.motorSpeed;
     float impulse = -J.motorMass * Cdot;
     float old = J.im;
-    J.im = mcr_clamp(J.im + impulse, -maxImpulse, maxImpulse);
+    J.im = __builtin_amdgcn_fmed3f(J.im + impulse, -maxImpulse, maxImpulse);   // b2Clamp as ONE instruction: the median of (x, -M, M) is max(-M, min(x, M)) for every x that is a number
     impulse = J.im - old;
     wA -= iA * impulse; wB += iB * impulse;
   }
@@ -1065,7 +1065,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
           VP_BEGIN();
           if (run) {
 #pragma unroll
-            for (int q = 3; q >= 0; --q) joint_velocity_scalar<LIM>(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);
+            for (int q = 3; q >= 0; --q) joint_velocity_as<!LIM, LIM>(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);   // pairs for the limit-free form only: it needs fewer registers than the scalar one
           }
           VP_MARK(0);
           if (run) {
