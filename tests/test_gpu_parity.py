@@ -176,6 +176,47 @@ def test_out_of_playfield_and_done(torch_cuda, oracle):
     env.close()
 
 
+@pytest.mark.parametrize("N", [1, 2])
+def test_wheel_joints_at_their_limits(torch_cuda, oracle, N):
+    """b2RevoluteJoint's limit branches on every joint of a car, rear wheels included (they reach +-0.4 rad in crashes only): wheels teleported
+    beyond either limit, turning into it (3x3 solve, the limit impulse accumulates) and away from it (the impulse would change sign: Box2D takes it
+    back and re-solves 2x2).  The main launch then runs the all-limited form of its packed sweep loop (k_dynamics.h: joint_velocity) — full state,
+    joint impulses and limit states against the oracle's scalar Box2D code for 5 x 6 steps, and every limit state must have occurred on a rear joint."""
+    torch = torch_cuda
+    B, seed = 5, 41 + N
+    env = _make(B, N, seed, contacts=False); env.reset()
+    orcs = _oracles(oracle, B, N, seed, contacts=False)
+    rng = np.random.RandomState(7 + N)
+    for k in range(12):                                             # get the cars moving first
+        a = random_actions(rng, B, N, brake_scale=0.0)
+        env.step(torch.from_numpy(a).cuda())
+        for e, o in enumerate(orcs): o.step(a[e], render=False)
+    cases = {0: [(3, +0.45, +3.0), (4, -0.47, -2.0)],               # rear wheels beyond upper / lower, turning into the limit
+             1: [(1, +0.41, -5.0), (2, -0.41, +5.0)],               # front wheels at a limit, turning away from it: the reduce branch
+             2: [(1, +0.52, +1.0), (2, -0.44, -6.0), (3, -0.43, +4.0), (4, +0.6, -0.5)],
+             3: [(3, +0.4, 0.0), (4, -0.4, 0.0)]}                   # exactly at the limits (>= / <=)
+    seen = set()
+    for rnd in range(5):                                            # (the motors pull the wheels back within two steps: teleport again)
+        st = env.get_state()["bodies"].copy()                       # [env, car, body (hull, front-left, front-right, rear-left, rear-right), (cx cy a vx vy w)]
+        for e, lst in cases.items():
+            for c in range(N):
+                for (k, da, w) in lst:
+                    st[e, c, k, 2] = np.float32(st[e, c, 0, 2] + np.float32(da if rnd % 2 == 0 else -da)); st[e, c, k, 5] = np.float32(w * (1 + rnd))
+                    orcs[e].set_body(c, k, st[e, c, k])
+        env.set_bodies(st)
+        for k in range(6):
+            a = random_actions(rng, B, N, brake_scale=0.2)
+            _, rew, done, _ = env.step(torch.from_numpy(a).cuda())
+            for e, o in enumerate(orcs):
+                _, r, d, _ = o.step(a[e], render=False)
+                assert np.array_equal(r, rew[e].cpu().numpy()) and bool(done[e].item()) == d, f"round {rnd} step {k} env {e}: reward/done differ"
+            _assert_state_equal(env, orcs, f"round {rnd} step {k}")
+            lim = env.get_state()["limit"]                          # [env, car, joint]: 0 inactive, 1 lower, 2 upper
+            seen |= {int(v) for v in np.unique(lim[:, :, 2:])}
+    assert {1, 2} <= seen, f"rear joints never sat at both limits: {seen}"
+    env.close()
+
+
 def test_time_limit_and_auto_reset(torch_cuda, oracle):
     """TimeLimit (init.py:8) + device-side auto-reset: the done step returns the first obs of the next episode,
     and that episode is the next draw of the env's own RNG streams."""
