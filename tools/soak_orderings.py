@@ -16,7 +16,7 @@ oa, ob = a.reset(), b.reset()
 assert torch.equal(oa, ob)
 g = torch.Generator(device="cuda"); g.manual_seed(9)
 pool = torch.rand((128, B, N, 3), device="cuda", generator=g); pool[..., 0] = pool[..., 0] * 2 - 1
-pool[:, :, 1, 1] = torch.clamp(pool[:, :, 1, 1] + 0.4, max=1.0) if N > 1 else pool[:, :, 0, 1]      # car 1 is faster: rear-ends happen
+if N > 1: pool[:, :, 1, 1] = torch.clamp(pool[:, :, 1, 1] + 0.4, max=1.0)      # car 1 is faster: rear-ends happen
 if int(os.environ.get("DRIVE", "0")): pool[..., 0] *= 0.1; pool[..., 1] = 1.0; pool[..., 2] = 0.0      # bench.py --actions drive: ~1000 contact envs per step
 bad = torch.zeros((), dtype=torch.int64, device="cuda")
 t0 = time.perf_counter(); resets = 0
