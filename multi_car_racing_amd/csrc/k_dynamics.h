@@ -1018,7 +1018,15 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
     } else if (run) {
       // The rear wheels (joints 2, 3: not steered, a motor holds them straight) reach their limits in crashes only: a wavefront none of
       // whose cars has one there runs its 180 sweeps with the limit-free form of those two joints (36 instructions less per sweep).
-      if (!__any(J[2].limit != 0 || J[3].limit != 0)) {
+      // ... and a wavefront none of whose cars has ANY joint at a limit (a policy that does not hold the steering at its stop: the steered joints
+      // sit at +-0.4 rad only while |steer| = 1 has been held for ~0.1 s) runs the limit-free form of all four: 111 instructions per sweep
+      // instead of 199.  (Random actions over [-1, 1]: nearly every wavefront of 64 cars holds a steered joint at its stop.)
+      if (!CC && !__any(J[0].limit != 0 || J[1].limit != 0 || J[2].limit != 0 || J[3].limit != 0)) {
+        for (int it = 0; it < 180; ++it) {
+#pragma unroll
+          for (int q = 3; q >= 0; --q) joint_velocity_as<!CC, false>(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);
+        }
+      } else if (!__any(J[2].limit != 0 || J[3].limit != 0)) {
         for (int it = 0; it < 180; ++it) {
           joint_velocity_as<!CC, false>(J[3], b[0], b[4], mH, iH, mW, iW, maxImpulse);
           joint_velocity_as<!CC, false>(J[2], b[0], b[3], mH, iH, mW, iW, maxImpulse);
