@@ -5,10 +5,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "_lib", "libmcr_hip.so")
 # translation units and their extra flags (mcr_view.hip explains why the raster is built without the SLP vectoriser)
-# mcr_hip.hip: the SLP vectoriser's packed f32 forms pay in k_dynamics' velocity sweeps (without it: 135 instead of 118 us), but with the
-# default profitability threshold a seventh of the loop is register shuffling for their operands; sweep on the GPU (dynamics / step):
-# threshold 0: 118.2 us / 14.70 M, 4: 114.6 / 14.91, 5: 112.6 / 15.03, 8: 115.7 / 14.95, 12: 114.1 / 15.04, 16: 122.2 / 14.73, off: 135.3 / 14.15
-SOURCES = [("mcr_hip.hip", ["-mllvm", "-slp-threshold=5"] + os.environ.get("MCR_HIP_CFLAGS", "").split()), ("mcr_view.hip", ["-fno-slp-vectorize"]), ("mcr_host.cpp", []), ("mcr_world.cpp", [])]
+# mcr_hip.hip: rounds 3-4 tuned the SLP vectoriser's threshold for this unit (its packed f32 forms paid in k_dynamics' velocity sweeps: off 135 us,
+# threshold 5 112.6 us).  Since round 5 the sweeps are written on pairs by hand (k_dynamics.h: joint_velocity) and the vectoriser only costs: same
+# box, alternating, threshold 5 / 12 / off: N=2 18.63 / 18.67 / 18.70 M env-steps/s, N=4 12.75 / 12.76 / 13.13, N=8 7.02 / 7.04 / 7.22,
+# --actions drive 5.17 / 5.20 / 5.41 (k_collide 52 / 42 / 42 us, resume chain 72 / 69 / 68 us; the contact chains' scalar sweeps lose their
+# half-packed forms and the register shuffling that came with them).  Same IEEE operations either way (-ffp-contract=off): the parity suite is the proof.
+SOURCES = [("mcr_hip.hip", ["-fno-slp-vectorize"] + os.environ.get("MCR_HIP_CFLAGS", "").split()), ("mcr_view.hip", ["-fno-slp-vectorize"]), ("mcr_host.cpp", []), ("mcr_world.cpp", [])]
 
 
 def deps():

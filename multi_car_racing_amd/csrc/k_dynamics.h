@@ -1073,7 +1073,7 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
           VP_BEGIN();
           if (run) {
 #pragma unroll
-            for (int q = 3; q >= 0; --q) joint_velocity_as<!LIM, LIM>(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);   // pairs for the limit-free form only: it needs fewer registers than the scalar one
+            for (int q = 3; q >= 0; --q) joint_velocity_as<!LIM, LIM>(J[q], b[0], b[q + 1], mH, iH, mW, iW, maxImpulse);   // pairs for the limit-free form only (with limits: N=8 +0.3 %, N=4 -1 %, drive -0.3 %: nothing)
           }
           VP_MARK(0);
           if (run) {
