@@ -10,15 +10,20 @@ reference code that then executes for real is exactly:
   * `MultiCarRacing.reset` spawn logic  multi_car_racing.py:340-406
   * `FrictionDetector._contact`         multi_car_racing.py:88-123
   * `MultiCarRacing.step` bookkeeping   multi_car_racing.py:433-507
+  * `render` / `_render_window`         multi_car_racing.py:511-604   (under RECORDING stubs, see gen_render_stream)
+  * `render_road`, `render_indicators`  multi_car_racing.py:613-674
 
 What the stubs replace (NOT pinned by these goldens): Box2D world/bodies, the gym
-`Car` class, rendering, shapely.  `shapely.geometry.Point.within(Polygon)` is
+`Car` class (incl. `Car.draw`), gym's `rendering.Viewer/Transform`, pyglet's GL
+(what a gl* call DOES: model transform, sampling rule, colour conversion, glyphs), shapely.  `shapely.geometry.Point.within(Polygon)` is
 stubbed by a strict-interior even-odd point-in-polygon test.
 
 Outputs (data only — inputs and expected outputs, never reference source):
   tests/golden/tracks.npz        per-seed track / road_poly / colours / retries
   tests/golden/spawn.json        car order + spawn poses for N x direction x seeds
   tests/golden/bookkeeping.json  scripted contact + pose traces -> rewards/flags
+  tests/golden/render_stream.json + .npz   the call stream of render(mode) on scripted car states: Transform setters,
+                                 viewport, draw order, every glColor4f/glVertex3f, label text, flag triangle
 """
 import sys, os, json, math, types, importlib
 
@@ -108,10 +113,15 @@ def _install_stubs():
             self.color = None
             self.userData = None
 
+    class _Joint:
+        angle = 0.0
+
     class _Wheel:
         def __init__(self):
             self.tiles = set()
             self.userData = self
+            self.omega = 0.0
+            self.joint = _Joint()
 
     class Car:
         created = []
@@ -127,7 +137,11 @@ def _install_stubs():
         def brake(self, b): pass
         def step(self, dt): pass
         def destroy(self): pass
-        def draw(self, *a): pass
+        draw_hook = None                      # gen_render_stream: records (viewer, draw_particles, hull.color) and queues a marker geom
+
+        def draw(self, viewer, draw_particles=True):
+            if Car.draw_hook is not None:
+                Car.draw_hook(self, viewer, draw_particles)
 
     cd = mod("gym.envs.box2d.car_dynamics", SIZE=0.02, WHEEL_W=14,
              WHEELPOS=[(-55, +80), (+55, +80), (-55, -82), (+55, -82)], Car=Car)
@@ -341,6 +355,275 @@ def gen_bookkeeping(mcr, Car):
     return episodes
 
 
+# --------------------------------------------------------------------------- render stream
+class _RenderRecorder:
+    """RECORDING stubs for what `_render_window` / `render_road` / `render_indicators` call (multi_car_racing.py:520-604, 613-674):
+    `pyglet.gl` (glViewport/glBegin/glColor4f/glVertex3f/glEnd), gym's `rendering.Viewer` (window methods, onetime_geoms) and
+    `rendering.Transform` (setters, enable/disable), `pyglet.text.Label`, `pyglet.graphics.draw`, `pyglet.image` read-back (a zero
+    colour buffer of the viewport's size), `Car.draw`.  Every call lands in `self.log` in call order; nothing is drawn."""
+    GL_QUADS, GL_TRIANGLES = 7, 4             # the GL enum values
+
+    def __init__(self, mcr, Car):
+        self.log = []
+        self.viewport = (0, 0, 0, 0)
+        rec = self
+        f32 = lambda v: float(np.float32(v))  # gl*f entry points take C floats (ctypes c_float): what GL receives
+
+        gl = mcr.gl                            # the module object the reference bound at import
+        gl.GL_QUADS, gl.GL_TRIANGLES = self.GL_QUADS, self.GL_TRIANGLES
+        gl.glViewport = lambda x, y, w, h: (setattr(rec, "viewport", (x, y, w, h)), rec.log.append(("viewport", x, y, w, h)))[1]
+        gl.glBegin = lambda mode: rec.log.append(("begin", mode))
+        gl.glEnd = lambda: rec.log.append(("end",))
+        gl.glColor4f = lambda r, g, b, a: rec.log.append(("color", f32(r), f32(g), f32(b), f32(a)))
+        gl.glVertex3f = lambda x, y, z: rec.log.append(("vertex", f32(x), f32(y), f32(z), float(x), float(y)))
+
+        class _Context:                        # no `_nscontext` attribute: pixel_scale stays 1 (:580-583)
+            pass
+
+        class _Window:
+            def __init__(self):
+                self.context = _Context()
+            def set_caption(self, c): rec.log.append(("set_caption", c))
+            def switch_to(self): rec.log.append(("switch_to",))
+            def dispatch_events(self): rec.log.append(("dispatch_events",))
+            def clear(self): rec.log.append(("clear",))
+            def flip(self): rec.log.append(("flip",))
+
+        class Viewer:
+            count = 0
+            def __init__(self, w, h):
+                self.size = (w, h); self.window = _Window(); self.onetime_geoms = []; self.isopen = True
+                self.index = Viewer.count; Viewer.count += 1
+                rec.log.append(("viewer", w, h))
+            def close(self): pass
+
+        class Transform:
+            def set_scale(self, x, y): rec.log.append(("set_scale", float(x), float(y)))
+            def set_translation(self, x, y): rec.log.append(("set_translation", float(x), float(y)))
+            def set_rotation(self, a): rec.log.append(("set_rotation", float(a)))
+            def enable(self): rec.log.append(("enable",))
+            def disable(self): rec.log.append(("disable",))
+
+        self.Viewer = Viewer
+        rendering = types.ModuleType("gym.envs.classic_control.rendering")
+        rendering.Viewer, rendering.Transform = Viewer, Transform
+        cc = types.ModuleType("gym.envs.classic_control"); cc.rendering = rendering
+        sys.modules["gym.envs.classic_control"] = cc
+        sys.modules["gym.envs.classic_control.rendering"] = rendering
+        sys.modules["gym.envs"].classic_control = cc
+
+        class Label:
+            def __init__(self, text, **kw):
+                self.text = text; self.kw = kw
+                rec.log.append(("label_new", text, dict(kw)))
+            def draw(self): rec.log.append(("label_draw", self.text, dict(self.kw)))
+
+        class _ImageData:
+            def get_data(self_inner):
+                rec.log.append(("readback", rec.viewport[2], rec.viewport[3]))
+                return bytes(rec.viewport[2] * rec.viewport[3] * 4)     # pyglet sizes the colour buffer from the viewport
+        class _ColorBuffer:
+            def get_image_data(self_inner): return _ImageData()
+        class _BufferManager:
+            def get_color_buffer(self_inner): return _ColorBuffer()
+
+        pg = mcr.pyglet
+        pg.text = types.SimpleNamespace(Label=Label)
+        pg.graphics = types.SimpleNamespace(draw=lambda n, mode, *data: rec.log.append(("graphics_draw", n, mode, [(d[0], list(d[1])) for d in data])))
+        pg.image = types.SimpleNamespace(get_buffer_manager=lambda: _BufferManager())
+
+        class _Marker:                         # what gym's Car.draw would queue: viewer.draw_polygon(...) appends FilledPolygon geoms
+            def __init__(self, car): self.car = car
+            def render(self): rec.log.append(("car_geoms", self.car))
+
+        def draw_hook(car, viewer, draw_particles):
+            idx = rec.env.cars.index(car)
+            rec.log.append(("car_draw", idx, viewer.index, bool(draw_particles), [float(c) for c in car.hull.color]))
+            viewer.onetime_geoms.append(_Marker(idx))
+        Car.draw_hook = staticmethod(draw_hook)
+        self.Car = Car
+
+    def uninstall(self):
+        self.Car.draw_hook = None
+
+
+def _parse_view(log):
+    """One `_render_window` call's log -> the fixture's record of the view."""
+    ops, quads, groups = [], [], []
+    cur_col, verts, mode = None, [], None
+    out = dict(car_draws=[], hud=[], label=None, flag=None)
+    for e in log:
+        k = e[0]
+        if k == "begin":
+            mode = e[1]; verts = []; cur_col = None; quads = []
+        elif k == "color":
+            cur_col = list(e[1:5])
+        elif k == "vertex":
+            verts.append((cur_col, e[1:4], e[4:6]))
+            if len(verts) == 4:
+                assert all(v[0] == verts[0][0] for v in verts), "one colour per quad"
+                quads.append(dict(color=verts[0][0], v32=[list(v[1]) for v in verts], v64=[list(v[2]) for v in verts]))
+                verts = []
+        elif k == "end":
+            assert not verts and mode == _RenderRecorder.GL_QUADS
+            groups.append(quads); ops.append("quads:%d" % len(quads))
+        elif k == "car_draw":
+            out["car_draws"].append(dict(car=e[1], viewer=e[2], draw_particles=e[3], hull_color=e[4])); ops.append("car_draw")
+        elif k == "car_geoms":
+            ops.append("car_geoms:%d" % e[1])
+        elif k == "viewport":
+            out["viewport"] = list(e[1:5]); ops.append("viewport")
+        elif k == "set_scale":
+            out["scale"] = list(e[1:3]); ops.append(k)
+        elif k == "set_translation":
+            out["translation"] = list(e[1:3]); ops.append(k)
+        elif k == "set_rotation":
+            out["rotation"] = e[1]; ops.append(k)
+        elif k == "label_draw":
+            out["label"] = dict(text=e[1], **{kk: (list(vv) if isinstance(vv, tuple) else vv) for kk, vv in e[2].items()}); ops.append("label_draw")
+        elif k == "graphics_draw":
+            out["flag"] = dict(count=e[1], mode=e[2], data=e[3]); ops.append("graphics_draw")
+        elif k == "readback":
+            out["readback"] = list(e[1:3]); ops.append("readback")
+        elif k in ("viewer", "label_new", "set_caption"):
+            ops.append(k)                      # first use of a viewer (:527-537)
+        else:
+            ops.append(k)
+    assert len(groups) == 2, "render_road's and render_indicators' glBegin/glEnd pairs"
+    out["ops"] = ops
+    road, hud = groups
+    out["hud"] = [dict(color=q["color"], v=q["v64"]) for q in hud]          # window coordinates as computed (f64); GL holds their f32
+    road_arr = np.array([q["color"] + sum(q["v32"], []) for q in road], dtype=np.float32)   # [n, 4 + 12] what GL receives
+    return out, road_arr
+
+
+def gen_render_stream(mcr, Car):
+    """render(mode) of the reference on scripted car states.  Each case: the reference's own reset() (track + spawn), a few scripted
+    steps (contact events + hull poses, as gen_bookkeeping: rewards, touched tiles and the backward flag are the reference's own),
+    then t / wheel omegas / joint angle / hull angular velocity are set and render(mode) runs under the recording stubs."""
+    rec = _RenderRecorder(mcr, Car)
+    rng = np.random.RandomState(77)
+    f32 = lambda v: float(np.float32(v))
+    cases_def = [
+        # N, dir, track_seed, h_ratio, ego, flag, mode, t, steps, speed
+        (2, "CCW", 0, 0.25, False, True, "state_pixels", 0.02, 1, 0.0),
+        (2, "CCW", 0, 0.25, False, True, "state_pixels", 0.5, 6, 0.3),      # below the 0.5 camera threshold
+        (2, "CW", 1, 0.25, False, True, "state_pixels", 1.0, 10, 12.0),
+        (2, "CCW", 0, 0.25, False, True, "state_pixels", 3.0, 14, 30.0),
+        (1, "CCW", 3, 0.25, False, False, "state_pixels", 3.0, 8, 25.0),     # CarRacing-v0 special case: N=1, flag off
+        (2, "CCW", 0, 0.4, False, True, "state_pixels", 1.0, 8, 8.0),
+        (3, "CW", 4, 0.4, True, True, "state_pixels", 2.0, 8, 0.45),
+        (4, "CCW", 2, 0.25, True, False, "state_pixels", 0.5, 8, 5.0),
+        (2, "CCW", 0, 0.25, False, True, "rgb_array", 3.0, 6, 20.0),
+        (2, "CW", 1, 0.3, True, True, "rgb_array", 0.02, 1, 0.0),
+        (2, "CCW", 0, 0.25, False, True, "human", 3.0, 6, 20.0),
+        (8, "CCW", 2, 0.25, False, True, "state_pixels", 1.5, 5, 15.0),
+        (2, "CW", 1, 0.25, False, False, "state_pixels", 0.98, 5, 0.5),      # exactly 0.5: not above the threshold; t just below 1
+        (2, "CCW", 0, 0.25, True, True, "human", 0.5, 4, 3.0),
+    ]
+    cases, arrays = [], {}
+    for ci, (N, direction, tseed, h_ratio, ego, flag, mode, t_final, steps, speed) in enumerate(cases_def):
+        np.random.seed(5)
+        env = mcr.MultiCarRacing(num_agents=N, verbose=0, direction=direction, use_random_direction=False,
+                                 backwards_flag=flag, h_ratio=h_ratio, use_ego_color=ego)
+        rec.env = env
+        rec.Viewer.count = 0
+        env.np_random = np.random.RandomState(tseed)
+        Car.created.clear()
+        env.reset()                            # runs step(None) -> render("state_pixels") for real: the viewers are created here
+        T = len(env.track)
+        track = np.array(env.track)
+        sign = -1 if direction == "CW" else 1
+        script = []
+        prog = [3.0 * c for c in range(N)]
+        for k in range(steps):
+            events, poses = [], []
+            for c in range(N):
+                old = int(prog[c]); prog[c] += 1.0 + 0.5 * c; new = int(prog[c])
+                for ti in range(old, new):
+                    tidx = (sign * ti) % T
+                    w = int(rng.randint(0, 4))
+                    events.append([1, c, w, tidx])
+                    if rng.rand() < 0.5:
+                        events.append([0, c, w, tidx])
+                idx = (sign * new) % T
+                a, b, x, y = track[idx]
+                head = b + (math.pi if direction == "CW" else 0.0)
+                backwards = (c % 2 == 1)       # odd cars drive the wrong way: the flag
+                if backwards:
+                    head += math.pi
+                sp = speed * (1.0 + 0.1 * c)
+                if speed == 0.5:
+                    vx, vy = 0.5, 0.0          # |v| == 0.5 exactly
+                else:
+                    vx, vy = -math.sin(head) * sp, math.cos(head) * sp
+                ang = head + (0.3 if c % 3 == 2 else -0.05)
+                off = [0.0, 1.5, -2.5][c % 3]
+                poses.append([f32(x + off * math.cos(b)), f32(y + off * math.sin(b)), f32(vx), f32(vy), f32(ang)])
+            script.append(dict(events=events, poses=poses))
+        for k, st in enumerate(script):
+            def hook(world, st=st):
+                for begin, c, w, tidx in st["events"]:
+                    ct = _FakeContact(env.road[tidx], env.cars[c].wheels[w])
+                    (env.contactListener_keepref.BeginContact if begin else env.contactListener_keepref.EndContact)(ct)
+            env.world.step_hook = hook
+            for c, (px, py, vx, vy, ang) in enumerate(st["poses"]):
+                h = env.cars[c].hull
+                h.position = (px, py); h.linearVelocity = (vx, vy); h.angle = ang
+                for w in range(4):
+                    env.cars[c].wheels[w].car_id = c
+            env.step(np.zeros((N, 3)))
+        # the state render_indicators reads: gauges incl. negative values
+        car_state = []
+        for c in range(N):
+            hull = env.cars[c].hull
+            hull.angularVelocity = f32([-1.7, 2.3, 0.0, 0.6][c % 4])
+            omegas = [float(v) for v in ([35.5, -12.25, 80.0, 0.0] if c % 2 == 0 else [-40.0, 7.5, 130.0, -3.0])]
+            wheel_angles = [f32(hull.angle + d) for d in ([0.31, -0.2, 0.0, 0.0] if c % 2 == 0 else [-0.4, 0.4, 0.01, -0.01])]
+            for w in range(4):
+                env.cars[c].wheels[w].omega = omegas[w]
+                env.cars[c].wheels[w].joint.angle = float(np.float32(wheel_angles[w]) - np.float32(hull.angle))   # b2RevoluteJoint::GetJointAngle, f32
+            car_state.append(dict(hull=[hull.position[0], hull.position[1], hull.linearVelocity[0], hull.linearVelocity[1], hull.angle,
+                                        hull.angularVelocity], omega=omegas, wheel_angle=wheel_angles,
+                                  joint0_angle=env.cars[c].wheels[0].joint.angle))
+        env.t = t_final
+        views, road_ref = [], None
+        del rec.log[:]
+        if mode == "human":
+            ret = []
+            for a in range(N):
+                ret.append(env._render_window(a, mode))
+            shape = None
+        else:
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")          # np.fromstring's binary mode (:600) is deprecated in numpy 2
+                frames = env.render(mode)
+            shape = list(frames.shape); ret = None
+        # split the log per view: a view starts at its first set_scale
+        starts = [i for i, e in enumerate(rec.log) if e[0] == "set_scale"] + [len(rec.log)]
+        assert len(starts) == N + 1 and starts[0] == 0
+        for a in range(N):
+            v, road = _parse_view(rec.log[starts[a]:starts[a + 1]])
+            if road_ref is None:
+                road_ref = road
+            v["road_same_as_view0"] = bool(road.shape == road_ref.shape and (road == road_ref).all())
+            assert v["road_same_as_view0"]
+            views.append(v)
+        arrays["c%d_road" % ci] = road_ref
+        cases.append(dict(
+            N=N, direction=direction, track_seed=tseed, global_seed=5, h_ratio=h_ratio, use_ego_color=ego, backwards_flag=flag,
+            mode=mode, t=t_final, T=T, script=script, car_state=car_state,
+            reward=[float(v) for v in env.reward], driving_backward=[bool(v) for v in env.driving_backward],
+            touched=[i for i, tl in enumerate(env.road) if tl.color == mcr.ROAD_COLOR],
+            n_road_poly=len(env.road_poly), frames_shape=shape, human_returns=ret,
+            hull_colors_after=[[float(x) for x in car.hull.color] for car in env.cars],
+            views=views))
+        print(f"render case {ci}: N={N} mode={mode} t={t_final} quads={len(road_ref)} flag={[v['flag'] is not None for v in views]}")
+    rec.uninstall()
+    return cases, arrays
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     mcr, Car = load_reference()
@@ -356,6 +639,10 @@ def main():
         json.dump(dict(constants=consts, cases=gen_spawn(mcr, Car)), f)
     with open(os.path.join(OUT, "bookkeeping.json"), "w") as f:
         json.dump(gen_bookkeeping(mcr, Car), f)
+    cases, arrays = gen_render_stream(mcr, Car)
+    with open(os.path.join(OUT, "render_stream.json"), "w") as f:
+        json.dump(cases, f)
+    np.savez_compressed(os.path.join(OUT, "render_stream.npz"), **arrays)
     print("wrote goldens to", os.path.abspath(OUT))
 
 

@@ -455,6 +455,33 @@ class OracleEnv:
         n = self.L.orc_draw_list(self.h, ctypes.c_int(agent), ctypes.c_int(width), ctypes.c_int(height), _p(buf), ctypes.c_int(cap))
         return [(buf[i, 4:4 + 2 * int(buf[i, 0])].reshape(-1, 2).copy(), buf[i, 1:4].astype(np.uint8)) for i in range(n)]
 
+    def render_stream(self, agent=0, width=96, height=96, particles=False, cap=4096):
+        """The frame of `agent` as the reference hands it to GL, before any transform (mcr_oracle.cpp: orc_render_stream):
+        (camera dict, list of (space, tag, xy [n,2] f64, rgb u8))."""
+        cam = np.zeros(21)
+        buf = np.zeros((cap, 24))
+        f = self.L.orc_render_stream
+        f.restype = ctypes.c_int
+        n = f(self.h, ctypes.c_int(agent), ctypes.c_int(width), ctypes.c_int(height), ctypes.c_int(int(particles)), _p(cam), _p(buf), ctypes.c_int(cap))
+        assert n < cap
+        chars = [int(c) for c in cam[5:]]
+        label = bytes(chars[:chars.index(0)]).decode()
+        camera = dict(zoom=float(cam[0]), tx=float(cam[1]), ty=float(cam[2]), angle=float(cam[3]), flag=bool(cam[4]), label=label)
+        prims = [(int(buf[i, 0]), int(buf[i, 1]), buf[i, 6:6 + 2 * int(buf[i, 2])].reshape(-1, 2).copy(), buf[i, 3:6].astype(np.uint8)) for i in range(n)]
+        return camera, prims
+
+    def set_render_state(self, car, hull_w, wheel_angles, omegas, phases=(0, 0, 0, 0)):
+        f = self.L.orc_set_render_state
+        f.restype = None
+        wa = np.ascontiguousarray(wheel_angles, dtype=np.float32); om = np.ascontiguousarray(omegas, dtype=np.float64)
+        ph = np.ascontiguousarray(phases, dtype=np.float64)
+        f(self.h, ctypes.c_int(car), ctypes.c_float(hull_w), _p(wa), _p(om), _p(ph))
+
+    def set_time(self, t):
+        f = self.L.orc_set_time
+        f.restype = None
+        f(self.h, ctypes.c_double(t))
+
     def solve_only(self, steps=1):
         self.L.orc_set_trig_mode(self.trig_mode)
         self.L.orc_solve_only(self.h, ctypes.c_int(steps))

@@ -249,10 +249,16 @@ def test_hud_flag_masks_follow_from_the_triangle():
     """k_view.h composes the HUD rows analytically; the backwards flag (mcr.py:669-674: triangle (W-100,30) (W-75,70) (W-50,30) in
     window units) is a table of byte masks there.  Re-derive the table from the vertices (pixel centres, closed edges) and check
     that no centre is near an edge — the table is then what any correct rasteriser draws."""
+    import json
     import os
     import re
     kx, ky = 96 / 1000.0, 96 / 800.0
-    V = np.array([[900 * kx, 30 * ky], [925 * kx, 70 * ky], [950 * kx, 30 * ky]])
+    # the triangle as the REFERENCE draws it: pyglet.graphics.draw's 'v2i' data recorded from render_indicators (render_stream.json)
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "render_stream.json")))
+    flags = [v["flag"] for c in cases for v in c["views"] if v["flag"] is not None]
+    assert flags and all(f == flags[0] for f in flags) and flags[0]["data"][1] == ["c3B", [0, 0, 255] * 3]
+    V = np.array(flags[0]["data"][0][1], dtype=np.float64).reshape(3, 2) * [kx, ky]
+    assert V.tolist() == [[900 * kx, 30 * ky], [925 * kx, 70 * ky], [950 * kx, 30 * ky]]
     cover, margin = {}, 1e9
     for row in range(12):
         for x in range(96):
