@@ -126,6 +126,8 @@ def main():
     ap.add_argument("--rccl", action="store_true", help="with --gpus 1: initialise a 1-rank RCCL (\"nccl\") process group anyway, so that the metric all-reduce of "
                     "sharded.reduce_metrics and the step's phase-word ordering run beside a live RCCL communicator on the one GPU a box has")
     ap.add_argument("--terminal-obs", type=int, default=0, help="1: also hand out the last frame of every episode that ends (info['terminal_observation'], include/mcr.h: mcr_set_terminal_obs)")
+    ap.add_argument("--fresh-world", type=int, default=0, help="0 (default): ONE b2World per env across its episodes, as the reference keeps it (csrc/k_world.h); "
+                    "1: every episode the first of a fresh world (rounds 1-5's definition)")
     ap.add_argument("--graph", type=int, default=0, help="1: mcr_step replays a hipGraph of the step (bypassed while kernels are timed; measured gain 0.4 %%); 0 (default): plain launches")
     args = ap.parse_args()
 
@@ -186,7 +188,7 @@ def main():
         extra["gen_threads"] = max(1, total // args.emulate_world)     # what VecMultiCarRacing gives a rank of a W-rank job
         emu = {"world": args.emulate_world, "cores_allowed_to_the_job": total, "cores_this_rank": share, "gen_threads": extra["gen_threads"]}
     env = ShardedVecEnv(B * world, N, seed=0, rank=rank, world_size=world, device=dev, obs=bool(args.obs),
-                        auto_reset=True, use_random_direction=True, streams=args.streams, graph=bool(args.graph), terminal_obs=bool(args.terminal_obs), **extra)
+                        auto_reset=True, use_random_direction=True, streams=args.streams, graph=bool(args.graph), terminal_obs=bool(args.terminal_obs), fresh_world=bool(args.fresh_world), **extra)
     env.reset()
     # synthetic actions, generated ON THE DEVICE by a counter-based stream keyed (seed, global env, agent, t):
     # i.i.d. steer~U(-1,1), gas~U(0,1), brake~U(0,1); one small kernel per ACT_BLOCK steps inside the timed region (the
@@ -320,6 +322,7 @@ def main():
                        "touch_verdict_mismatches_rank0": env.env.verdict_mismatches(),
                        "status_words_rank0": {k: int(v) for k, v in zip(("waits_given_up", "verdict_mismatches", "manifold_overflows", "event_overflows", "envs_frozen"), env.env.status_words()[:5])},
                        "contact_pass_beside_dynamics": bool(env.env.L.mcr_concurrent_collide(env.env.h)),
+                       "world": "fresh world per episode (rounds 1-5)" if args.fresh_world else "one b2World per env across its episodes (the reference; csrc/k_world.h)",
                        "contact_envs_per_step_rank0": float(env.env.debug_counters()[2] - ctr0[2]) / K,
                        "deferred_envs_per_step_rank0": float(env.env.debug_counters()[0] - ctr0[0]) / K},
             "roofline": roofline,

@@ -51,7 +51,11 @@ typedef struct mcr_config {
   double h_ratio;            /* :159 */
   int32_t skid_particles;    /* 1: keep the skid particles of gym car_dynamics.Car (step(): "Skid trace", _create_particle) so that
                               * mcr_render can draw them (Car.draw(viewer, True), :564); 0: not tracked (observations never show them) */
-  int32_t reserved0;
+  int32_t fresh_world;       /* 0 (default): ONE b2World per env for the env's life, as the reference keeps it (:138; _destroy :173-181, reset :341): from an
+                              * env's second episode on the fixtures' proxy ids come off the world's free list, which orders same-step tile events
+                              * (:113-120: who is a tile's first visitor) and names fixtureA of a car<->car contact.  The ids' rule needs no tree
+                              * (csrc/k_world.h): a per-env stack of free leaf ids, advanced by the env's reset pass on the device.
+                              * 1: every episode is the first episode of a fresh world (rounds 1-5; the oracle's world mode 0) */
 } mcr_config;
 
 const char* mcr_last_error(void);
@@ -247,6 +251,10 @@ int mcr_debug_read_partition(mcr_env* h, uint8_t* part_out, int32_t* clist_out);
 int mcr_debug_next_verdicts(mcr_env* h, int fill_value, uint8_t* out_or_null);
 /* number of touching car<->car fixture pairs (stored manifolds) per env after the last collide pass */
 int mcr_debug_read_contact_counts(mcr_env* h, int32_t* out /*[num_envs]*/);
+/* fresh_world = 0: the broadphase proxy ids of env `env`'s live episode on its one world (csrc/k_world.h) — out[0 .. T) tiles in track order,
+ * then num_agents * 8 car fixtures (car * 8 + fixture; 0..3 hull polygons, 4..7 wheels); returns the count written; synchronises.  Tests
+ * hold it against the oracle's literal b2DynamicTree (what mcr_world_proxy_ids is for the host-side twin). */
+int mcr_debug_read_proxy_ids(mcr_env* h, int env, int32_t* out, int cap);
 /* Conditions reported by the kernels in mapped host memory (counted on the device, stored with system scope: no PCIe atomics needed),
  * read by mcr_step without synchronising (a condition raised by a step still in flight surfaces one call later).  Words:
  * [0] a bounded in-kernel wait gave up (the main dynamics for the contact pass of an env, any kernel for a phase word),

@@ -18,7 +18,7 @@ class Config(ctypes.Structure):
                 ("obs_enabled", ctypes.c_int32), ("auto_reset", ctypes.c_int32), ("backwards_flag", ctypes.c_int32),
                 ("use_ego_color", ctypes.c_int32), ("car_contacts", ctypes.c_int32), ("max_episode_steps", ctypes.c_int32),
                 ("num_streams", ctypes.c_int32), ("h_ratio", ctypes.c_double),
-                ("skid_particles", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
+                ("skid_particles", ctypes.c_int32), ("fresh_world", ctypes.c_int32)]
 
 
 # every symbol include/mcr.h declares: name -> (restype, argtypes)
@@ -55,6 +55,7 @@ SYMBOLS = {
     "mcr_read_rollout_stats": (_i, [_vp, _vp, _i]),
     "mcr_render": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mcr_debug_read_contact_counts": (_i, [_vp, _vp]),
+    "mcr_debug_read_proxy_ids": (_i, [_vp, _i, _vp, _i]),
     "mcr_debug_read_env_records": (_i, [_vp, _vp, _i]),
     "mcr_debug_read_partition": (_i, [_vp, _vp, _vp]),
     "mcr_debug_next_verdicts": (_i, [_vp, _i, _vp]),

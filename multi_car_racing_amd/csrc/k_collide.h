@@ -19,6 +19,7 @@
 #include "mcr_kernels.h"
 #include "k_carcontacts.h"
 #include "k_gjk.h"
+#include "k_world.h"
 
 namespace col {
 
@@ -125,8 +126,9 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   const int T = ((const McrSlotHeader*)slot)->T;
   // broadphase proxy ids: a fresh world's ascend in creation order (tile t -> t, car fixture pf -> TILE_CAP + pf sorts the same way); an episode
   // slot that carries tables (the facade's world across reset(), mcr_world.cpp) has its own
-  const bool has_pid = ((const McrSlotHeader*)slot)->pad0 != 0;
-  const uint16_t* __restrict__ TPID = (const uint16_t*)(slot + MCR_OFF_TPID); const uint16_t* __restrict__ FPID = (const uint16_t*)(slot + MCR_OFF_FPID);
+  const McrPidTables pidt = mcr_pid_tables(p, env, slot);
+  const bool has_pid = pidt.has;
+  const uint16_t* TPID = pidt.tile; const uint16_t* FPID = pidt.fix;
   auto tile_pid = [&](int t) -> uint32_t { return has_pid ? (uint32_t)TPID[t] : (uint32_t)t; };
   auto fix_pid = [&](int pf) -> uint32_t { return has_pid ? (uint32_t)FPID[pf] : (uint32_t)(MCR_TILE_CAP + pf); };
   // (asked for now, used after the fixtures are built: the boxes of the track's tile blocks; the cars' reward / visit-count accumulators)
@@ -163,6 +165,8 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   __shared__ __attribute__((aligned(16))) unsigned long long evq[EVQ_CAP];   // begin events of this pass: stamp << 14 | tile << 5 | car * 4 + wheel
   __shared__ __attribute__((aligned(16))) uint16_t tfl16[MCR_TILE_CAP];      // flags word of the tiles that take a begin event
   __shared__ int evn;
+  // reset() on the env's one world (k_world.h): _destroy + the new episode's fixtures re-issue the proxy ids before this pass looks one up
+  if (pass == 1 && p.pid_tab) mcr_world_reissue_ids(p, env, T, (uint16_t*)tres);
   // the fat AABB of EVERY car fixture (hull polygons as well): needed by the car<->car broadphase contacts, which are settled right
   // after the proxies — before the tile phases first write the two arrays these alias
   float (* const cfat8)[4] = (float (*)[4])cand;                  // per car: union of the fat AABBs of all 8 fixtures (which car pairs can hold contacts); dead before the candidate list is first written

@@ -7,6 +7,7 @@
 // bookkeeping kernels of step t (k_flags.h; the list chains) evaluate it for step t+1.
 #pragma once
 #include "k_carcontacts.h"
+#include "k_world.h"
 
 // whole wavefront (64 lanes, lane = car * 8 + fixture as in k_collide); returns the wave-uniform verdict
 __device__ __forceinline__ bool mcr_touch_verdict(const McrParams& p, const int env) {
@@ -69,6 +70,9 @@ __device__ __forceinline__ bool mcr_touch_verdict(const McrParams& p, const int 
     const float b0 = __shfl(cb0, lb), b1 = __shfl(cb1, lb), b2 = __shfl(cb2, lb), b3 = __shfl(cb3, lb);
     pmask = __ballot(is_pair && !(a0 > b2 || a2 < b0 || a1 > b3 || a3 < b1));
   }
+  // fixtureA of a pair is the fixture with the lower proxy id (k_collide.h: `flipped`), and b2CollidePolygons is not symmetric in its
+  // arguments (the reference-face tie-break 0.98 * sepA + 0.0005): the verdict has to ask in the order the contact pass will
+  const McrPidTables pidt = mcr_pid_tables(p, env, p.slots + ((size_t)env * 2 + p.env[env].slot) * MCR_SLOT_BYTES);
   // the fixture pairs of the car pairs whose boxes overlap, 8 x 8 at a time (lane = fixture of a * 8 + fixture of b).  "Does any
   // pair touch" does not depend on the order the pairs are looked at: k_collide, which also has to ORDER its manifolds, walks the
   // pairs differently and must arrive at the same answer (it counts the envs where it does not).
@@ -90,7 +94,7 @@ __device__ __forceinline__ bool mcr_touch_verdict(const McrParams& p, const int 
       Xf xa, xb;
       xa.p = v2(ta.x, ta.y); xa.q.s = ta.z; xa.q.c = ta.w; xb.p = v2(tb.x, tb.y); xb.q.s = tb.z; xb.q.c = tb.w;
       cc::Manifold M; M.n = 0; M.type = 0; M.pl[0] = M.pl[1] = v2(0.0f, 0.0f); M.id[0] = M.id[1] = 0; M.localNormal = M.localPoint = v2(0.0f, 0.0f);
-      cc::collide_polygons(M, pa_, xa, pb_, xb);
+      if (pidt.has && pidt.fix[ib] < pidt.fix[ia]) cc::collide_polygons(M, pb_, xb, pa_, xa); else cc::collide_polygons(M, pa_, xa, pb_, xb);
       hit = M.n > 0;
     }
     if (__any(hit)) return true;

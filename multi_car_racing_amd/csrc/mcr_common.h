@@ -81,6 +81,11 @@ struct McrSlotHeader {
 #define MCR_OFF_FPID (MCR_OFF_TPID + 2 * MCR_TILE_CAP)                // u16 [MAX_AGENTS * 8]    car * 8 + fixture
 #define MCR_PID_LIMIT 4096                                            // ids are node indices of the tree: < 2 * (TILE_CAP + 64) rounded up to its pool size
 #define MCR_SLOT_BYTES (MCR_OFF_FPID + 2 * MCR_MAX_AGENTS * 8)
+// One b2World per env for the env's life (k_world.h): the live episode's proxy ids [MCR_PID_TAB] u16 (laid out like the slot's TPID | FPID
+// region), the LIFO of free LEAF ids of the world's tree [MCR_PID_STACK] u16 and {stack height, fresh leaves handed out, tiles of the live
+// episode (0: no episode yet), spare} [4] i32
+#define MCR_PID_TAB (MCR_TILE_CAP + MCR_MAX_AGENTS * 8)
+#define MCR_PID_STACK MCR_PID_TAB
 
 // quad colour ids (u8 RGB after the GL float->unorm8 conversion)
 enum { MCR_COL_ROAD0 = 0, MCR_COL_ROAD1 = 1, MCR_COL_ROAD2 = 2, MCR_COL_KERB_WHITE = 3, MCR_COL_KERB_RED = 4 };

@@ -174,6 +174,10 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   const size_t o_carpoly = carve(sizeof(float) * MCR_CARPOLY_FLOATS * BN);
   const size_t o_vscratch = carve(sizeof(unsigned long long) * 16 * BN);
   const size_t o_particles = carve(cfg->skid_particles ? sizeof(uint32_t) * MCR_PART_WORDS * BN : 0);
+  const bool one_world = cfg->fresh_world == 0;      // (k_world.h: the env's b2World across its episodes, the reference's semantics; zero-initialised = an empty world)
+  const size_t o_pidtab = carve(one_world ? sizeof(uint16_t) * MCR_PID_TAB * (size_t)B : 0);
+  const size_t o_pidstk = carve(one_world ? sizeof(uint16_t) * MCR_PID_STACK * (size_t)B : 0);
+  const size_t o_pidmeta = carve(one_world ? sizeof(int32_t) * 4 * (size_t)B : 0);
   const size_t o_slots = carve((size_t)B * 2 * MCR_SLOT_BYTES);
   h->slab_bytes = off;
   if (hipMalloc(&h->slab, off) != hipSuccess) { g_err = "hipMalloc failed"; delete h; return MCR_ERR_HIP; }
@@ -187,6 +191,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   P.carf = (float*)(base + o_carf); P.card = (double*)(base + o_card); P.caru = (uint32_t*)(base + o_caru);
   P.env = (McrEnvState*)(base + o_env); P.tile_touch = (uint32_t*)(base + o_touch); P.tile_flags = (uint16_t*)(base + o_tflags);
   P.cc_store = (uint32_t*)(base + o_cc); P.bpf = (float4*)(base + o_bpf); P.cc_stamp = (uint32_t*)(base + o_ccstamp); P.bp_stamp = (uint32_t*)(base + o_bpstamp); P.shapes = (const McrShapes*)(base + o_shapes); P.slots = base + o_slots;
+  P.pid_tab = one_world ? (uint16_t*)(base + o_pidtab) : nullptr; P.pid_stack = one_world ? (uint16_t*)(base + o_pidstk) : nullptr; P.pid_meta = one_world ? (int32_t*)(base + o_pidmeta) : nullptr;
   h->view_stamps = (unsigned long long*)(base + o_vscratch);
   P.viewp = (float*)(base + o_viewp);
   P.part = base + o_part; P.dpart = base + o_dpart; P.collide_epoch = (int32_t*)(base + o_epoch); h->dev_step_ctr = P.collide_epoch + B; P.sync_words = (int32_t*)(base + o_sync); P.dlist = (int32_t*)(base + o_dlist); P.rlist = (int32_t*)(base + o_rlist); P.defer_state = base + o_dstate; P.counters = (unsigned long long*)(base + o_counters); P.status_dev = (uint32_t*)(base + o_statusdev); P.stats = (double*)(base + o_stats);
@@ -411,7 +416,16 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     P.next_counts[0] = h->P.dlist + oth * (B + 1); P.next_counts[1] = h->P.rlist + oth * (B + 1);
     P.next_counts[2] = h->P.vcount + oth * (B + 2); P.next_counts[3] = P.next_counts[2] + 1;
     if (h->term_slab && P.obs && P.actions) { P.term_cnt = h->term_cnt2 + par * 4; P.term_cnt_next = h->term_cnt2 + oth * 4; P.term_list = h->term_list2 + par * 2 * (size_t)P.term_cap; }
-    else { P.term_cnt = P.term_cnt_next = nullptr; P.term_idx = nullptr; }
+    else {
+      // a step that draws no terminal frames (no actions: frame skip, step(None); no observation buffer) still flips the parity: it zeroes
+      // the counters the NEXT step starts from in the drawing step's stead, and reports "no entries" (the next terminal step of
+      // that parity started from the counts of two steps back)
+      if (h->term_slab) {
+        (void)hipMemsetAsync(h->term_cnt2 + oth * 4, 0, sizeof(int32_t) * 4, st);
+        if (P.term_count_out) (void)hipMemsetAsync(P.term_count_out, 0, sizeof(int32_t), st);
+      }
+      P.term_cnt = P.term_cnt_next = nullptr; P.term_idx = nullptr;
+    }
     h->step_parity ^= 1;
   }
   if (!h->split) {
@@ -650,6 +664,9 @@ extern "C" int mcr_step(mcr_env* h, const float* d_actions, uint8_t* d_obs, doub
   // give-up — is treated like stale verdicts one way, and empties the half-made list the other way)
   const bool fz = fused_collide(h, st);
   if (h->last_fused && !fz) (void)hipMemsetAsync(h->P.clist + (size_t)h->step_parity * (P.B + 1), 0, sizeof(int32_t), st);
+  // ... and into fused mode: this step's verdict writers APPEND to the other parity's list, which a fused dynamics no longer zeroes and
+  // which an unfused step's contact pass filled two steps ago and nobody emptied (the next step's chain re-stepped stale envs)
+  if (cc_active(h) && fz && !h->last_fused) (void)hipMemsetAsync(h->P.clist + (size_t)(h->step_parity ^ 1) * (P.B + 1), 0, sizeof(int32_t), st);
   if (cc_active(h) && (!h->verdict_fresh || (fz && !h->last_fused))) {   // after reset() / reset_envs() / a state restore / a step without actions: which envs hold a touching car<->car pair?
     McrParams Pt = P; Pt.role = 0; Pt.part = h->P.part + (size_t)h->step_parity * P.B;
     Pt.fuse_collide = fused_collide(h, st) ? 1 : 0; Pt.clist = h->P.clist + (size_t)h->step_parity * (P.B + 1);
@@ -889,7 +906,7 @@ extern "C" int mcr_get_env_state(mcr_env* h, double* reward, int32_t* tvc, uint8
 
 // ---------------------------------------------------------------------------- full state snapshot / restore
 namespace {
-struct BlobLayout { size_t carf, card, caru, es, touch, tflags, cc, viewp, carpoly, bpf, stamp, ccstamp, slot, particles, total; };
+struct BlobLayout { size_t carf, card, caru, es, touch, tflags, cc, viewp, carpoly, bpf, stamp, ccstamp, slot, world, particles, total; };
 BlobLayout blob_layout(int N, bool with_particles) {
   BlobLayout L; size_t o = 16;                                         // header: magic (carries the layout version), N, flags (bit 0: particles), total bytes
   L.carf = o; o += sizeof(float) * CF_COUNT * N;
@@ -905,11 +922,12 @@ BlobLayout blob_layout(int N, bool with_particles) {
   L.stamp = o; o += sizeof(uint32_t) * MCR_TILE_CAP * 4 * N;
   L.ccstamp = o; o += sizeof(uint32_t) * mcr_cc_stamp_words(N);
   o = (o + 15) & ~(size_t)15; L.slot = o; o += MCR_SLOT_BYTES;
+  L.world = o; o += sizeof(uint16_t) * (MCR_PID_TAB + MCR_PID_STACK) + sizeof(int32_t) * 4;      // the env's b2World (k_world.h): ids, free leaf stack, meta
   L.particles = o; if (with_particles) o += sizeof(uint32_t) * MCR_PART_WORDS * N;
   L.total = o;
   return L;
 }
-const uint32_t BLOB_MAGIC = 0x3452434du;   // "MCR4": bumped whenever the layout of a blob (McrEnvState, slot image, field lists) changes
+const uint32_t BLOB_MAGIC = 0x3552434du;   // "MCR5": bumped whenever the layout of a blob (McrEnvState, slot image, field lists) changes
 }  // namespace
 
 extern "C" size_t mcr_state_blob_bytes(const mcr_env* h) { return h ? blob_layout(h->P.N, h->P.particles != nullptr).total : 0; }
@@ -923,7 +941,7 @@ extern "C" int mcr_get_state_blob(mcr_env* h, int env, void* blob_out) {
   const BlobLayout L = blob_layout(N, P.particles != nullptr);
   uint8_t* b = (uint8_t*)blob_out;
   memset(b, 0, L.total);
-  ((uint32_t*)b)[0] = BLOB_MAGIC; ((uint32_t*)b)[1] = (uint32_t)N; ((uint32_t*)b)[2] = P.particles ? 1u : 0u; ((uint32_t*)b)[3] = (uint32_t)L.total;
+  ((uint32_t*)b)[0] = BLOB_MAGIC; ((uint32_t*)b)[1] = (uint32_t)N; ((uint32_t*)b)[2] = (P.particles ? 1u : 0u) | (P.pid_tab ? 2u : 0u); ((uint32_t*)b)[3] = (uint32_t)L.total;
   HIPCHK(hipMemcpy2D(b + L.carf, sizeof(float) * N, P.carf + (size_t)env * N, sizeof(float) * BN, sizeof(float) * N, CF_COUNT, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy2D(b + L.card, sizeof(double) * N, P.card + (size_t)env * N, sizeof(double) * BN, sizeof(double) * N, CD_COUNT, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy2D(b + L.caru, sizeof(uint32_t) * N, P.caru + (size_t)env * N, sizeof(uint32_t) * BN, sizeof(uint32_t) * N, CU_COUNT, hipMemcpyDeviceToHost));
@@ -941,6 +959,11 @@ extern "C" int mcr_get_state_blob(mcr_env* h, int env, void* blob_out) {
   HIPCHK(hipMemcpy(b + L.stamp, P.bp_stamp + (size_t)env * MCR_TILE_CAP * 4 * N, sizeof(uint32_t) * MCR_TILE_CAP * 4 * N, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(b + L.slot, P.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES, MCR_SLOT_BYTES, hipMemcpyDeviceToHost));
   if (P.particles) HIPCHK(hipMemcpy(b + L.particles, P.particles + (size_t)env * N * MCR_PART_WORDS, sizeof(uint32_t) * MCR_PART_WORDS * N, hipMemcpyDeviceToHost));
+  if (P.pid_tab) {
+    HIPCHK(hipMemcpy(b + L.world, P.pid_tab + (size_t)env * MCR_PID_TAB, sizeof(uint16_t) * MCR_PID_TAB, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(b + L.world + sizeof(uint16_t) * MCR_PID_TAB, P.pid_stack + (size_t)env * MCR_PID_STACK, sizeof(uint16_t) * MCR_PID_STACK, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(b + L.world + sizeof(uint16_t) * (MCR_PID_TAB + MCR_PID_STACK), P.pid_meta + (size_t)env * 4, sizeof(int32_t) * 4, hipMemcpyDeviceToHost));
+  }
   return MCR_OK;
 }
 
@@ -951,7 +974,7 @@ extern "C" int mcr_set_state_blob(mcr_env* h, int env, const void* blob) {
   const uint8_t* b = (const uint8_t*)blob;
   const BlobLayout L = blob_layout(N, P.particles != nullptr);
   if (((const uint32_t*)b)[0] != BLOB_MAGIC || ((const uint32_t*)b)[1] != (uint32_t)N) { g_err = "not a state blob of this build and num_agents"; return MCR_ERR_ARG; }
-  if (((const uint32_t*)b)[2] != (P.particles ? 1u : 0u) || ((const uint32_t*)b)[3] != (uint32_t)L.total) { g_err = "state blob was taken from a handle with another skid_particles setting"; return MCR_ERR_ARG; }
+  if (((const uint32_t*)b)[2] != ((P.particles ? 1u : 0u) | (P.pid_tab ? 2u : 0u)) || ((const uint32_t*)b)[3] != (uint32_t)L.total) { g_err = "state blob was taken from a handle with another skid_particles or fresh_world setting"; return MCR_ERR_ARG; }
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy2D(P.carf + (size_t)env * N, sizeof(float) * BN, b + L.carf, sizeof(float) * N, sizeof(float) * N, CF_COUNT, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy2D(P.card + (size_t)env * N, sizeof(double) * BN, b + L.card, sizeof(double) * N, sizeof(double) * N, CD_COUNT, hipMemcpyHostToDevice));
@@ -974,6 +997,11 @@ extern "C" int mcr_set_state_blob(mcr_env* h, int env, const void* blob) {
   HIPCHK(hipMemcpy(P.bp_stamp + (size_t)env * MCR_TILE_CAP * 4 * N, b + L.stamp, sizeof(uint32_t) * MCR_TILE_CAP * 4 * N, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(P.slots + ((size_t)env * 2 + cur.slot) * MCR_SLOT_BYTES, b + L.slot, MCR_SLOT_BYTES, hipMemcpyHostToDevice));
   if (P.particles) HIPCHK(hipMemcpy(P.particles + (size_t)env * N * MCR_PART_WORDS, b + L.particles, sizeof(uint32_t) * MCR_PART_WORDS * N, hipMemcpyHostToDevice));
+  if (P.pid_tab) {
+    HIPCHK(hipMemcpy(P.pid_tab + (size_t)env * MCR_PID_TAB, b + L.world, sizeof(uint16_t) * MCR_PID_TAB, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(P.pid_stack + (size_t)env * MCR_PID_STACK, b + L.world + sizeof(uint16_t) * MCR_PID_TAB, sizeof(uint16_t) * MCR_PID_STACK, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(P.pid_meta + (size_t)env * 4, b + L.world + sizeof(uint16_t) * (MCR_PID_TAB + MCR_PID_STACK), sizeof(int32_t) * 4, hipMemcpyHostToDevice));
+  }
   h->any_reset = true; h->verdict_fresh = false;
   return MCR_OK;
 }
@@ -1074,6 +1102,19 @@ extern "C" int mcr_debug_read_contact_counts(mcr_env* h, int32_t* out) {
   const size_t stride = MCR_CC_MAX * MCR_CC_WORDS + 4;
   HIPCHK(hipMemcpy2D(out, sizeof(int32_t), h->P.cc_store, stride * sizeof(uint32_t), sizeof(int32_t), h->cfg.num_envs, hipMemcpyDeviceToHost));
   return MCR_OK;
+}
+extern "C" int mcr_debug_read_proxy_ids(mcr_env* h, int env, int32_t* out, int cap) {
+  if (!h || !out || env < 0 || env >= h->cfg.num_envs) return MCR_ERR_ARG;
+  if (!h->P.pid_tab) { g_err = "mcr_debug_read_proxy_ids: the handle was created with fresh_world = 1 (ids ascend in creation order)"; return MCR_ERR_STATE; }
+  HIPCHK(hipDeviceSynchronize());
+  std::vector<uint16_t> tab(MCR_PID_TAB); int32_t meta[4];
+  HIPCHK(hipMemcpy(tab.data(), h->P.pid_tab + (size_t)env * MCR_PID_TAB, sizeof(uint16_t) * MCR_PID_TAB, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(meta, h->P.pid_meta + (size_t)env * 4, sizeof(meta), hipMemcpyDeviceToHost));
+  const int T = meta[2], F = 8 * h->cfg.num_agents;
+  int n = 0;
+  for (int t = 0; t < T && n < cap; ++t) out[n++] = tab[t];
+  for (int f = 0; f < F && n < cap; ++f) out[n++] = tab[MCR_TILE_CAP + f];
+  return n;
 }
 extern "C" int mcr_debug_read_dynamics_stamps(mcr_env* h, uint64_t* out, int n_u64) {
   if (!h || !out) return MCR_ERR_ARG;

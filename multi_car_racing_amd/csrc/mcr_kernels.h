@@ -97,6 +97,10 @@ struct McrParams {
   float* term_viewp; float* term_carpoly; uint16_t* term_tflags;   // [term_cap * N][..], [term_cap * N][..], [term_cap][MCR_TILE_CAP]
   McrTermEnv* term_env;         // [term_cap]
   const uint8_t* reset_mask;    // [B] or null (k_install)
+  // one b2World per env across its episodes (k_world.h); null: every episode is the first of a fresh world (mcr_config::fresh_world)
+  uint16_t* pid_tab;            // [B][MCR_PID_TAB] proxy ids of the live episode's fixtures: tile t, then car * 8 + fixture
+  uint16_t* pid_stack;          // [B][MCR_PID_STACK] free leaf ids of the world's tree, last freed on top
+  int32_t* pid_meta;            // [B][4] stack height, fresh leaves issued, tiles of the live episode, spare
   int32_t auto_reset, max_steps, car_contacts, backwards_flag, use_ego_color;
   int32_t debug;                // ablation switches for profiling (0 in production)
   unsigned long long* dbg_stamps; // [2][dyn_blocks][8] phase clocks of k_dynamics (debug bit 8)

@@ -4,10 +4,11 @@ kwargs and defaults, `seed/reset/step/render/close`, obs (num_agents,96,96,3) ui
 the C-ABI; nothing is simulated on the host.
 
 Like the reference, the env keeps ONE b2World for its life (multi_car_racing.py:138; _destroy :173-181, reset :341): from the second
-episode on Box2D's broadphase proxy ids — the tie-break between cars that reach a tile in the same step, :113-120 — come off the dynamic
-tree's free list.  The world's tree lives on the host (include/mcr.h: mcr_world_*, csrc/mcr_world.cpp): `reset()` destroys and re-creates
-its proxies in the reference's order and hands their ids to the device with the episode, every `step()` moves the car fixtures' proxies as
-b2World::Solve does.  (The batched VecMultiCarRacing defines every episode as the first of a fresh world instead: vec_env.py.)
+episode on Box2D's broadphase proxy ids — the tie-break between cars that reach a tile in the same step, :113-120, and fixtureA of a
+car<->car contact — come off the world's free list.  The handle carries the world on the device (include/mcr.h: mcr_config::fresh_world = 0,
+csrc/k_world.h: the ids follow from a stack of free leaf ids, no tree), exactly as the batched VecMultiCarRacing does.  (Rounds 4-5 kept a
+literal b2DynamicTree on the host for this and synchronised every step to advance it: include/mcr.h mcr_world_*, still there as a CPU twin the
+tests hold against the stack rule.)
 
 RNG parity with the reference: the track comes from `self.np_random` (a numpy RandomState, gym seeding), the
 direction and the car order from the *global* `np.random` stream, drawn in the reference's order
@@ -94,8 +95,6 @@ class MultiCarRacing:
         self._done = torch.zeros((1,), dtype=torch.uint8, device=self._dev)
         self._act = torch.zeros((1, N, 3), dtype=torch.float32, device=self._dev)
         self._blob = np.zeros(_lib.episode_bytes(), np.uint8)
-        self._world = ctypes.c_void_p(self.L.mcr_world_create(N))             # the env's b2World across reset(): its broadphase tree (host)
-        self._bodies = np.zeros((1, N, 5, 6), np.float32)
         self._was_reset = False
         self.state = None
         self.track = None
@@ -134,22 +133,15 @@ class MultiCarRacing:
             print("Track generation: -> %i-tiles track" % int(info[0]))
         ep = _lib.unpack_episode(self._blob)
         self.track = [(float(a), float(b), float(x), float(y)) for a, (x, y, b) in zip(ep["alpha"], ep["track"])]
-        # _destroy() + _create_track() + the cars on the env's one world: the new fixtures' proxy ids travel with the episode
-        _lib.check(self.L.mcr_world_reset(self._world, _lib.ptr(self._blob)), "mcr_world_reset")
+        # (_destroy() + _create_track() + the cars on the env's ONE world: the reset pass re-issues the proxy ids on the device, k_world.h)
         st = self._torch.cuda.current_stream(self._dev)
         one = np.zeros(1, np.int32)
         _lib.check(self.L.mcr_stage_episodes(self._h, _lib.ptr(one), 1, _lib.ptr(self._blob), ctypes.c_void_p(st.cuda_stream)), "stage")
         _lib.check(self.L.mcr_reset(self._h, None, ctypes.c_void_p(self._obs.data_ptr()), ctypes.c_void_p(st.cuda_stream)), "mcr_reset")
         self._was_reset = True
-        self._sync_world()                                                     # (reset ends with a world step, :408)
         self.state = self._obs[0].cpu().numpy()
         self.t = 1.0 / FPS
         return self.state
-
-    def _sync_world(self):
-        """b2Body::SynchronizeFixtures of the world step that just ran: the car fixtures' proxies move in the host's tree"""
-        _lib.check(self.L.mcr_get_state(self._h, _lib.ptr(self._bodies), None, None, None, None, None), "mcr_get_state")
-        _lib.check(self.L.mcr_world_step(self._world, _lib.ptr(self._bodies)), "mcr_world_step")
 
     def step(self, action):
         if not self._was_reset:
@@ -163,7 +155,6 @@ class MultiCarRacing:
             a_ptr = ctypes.c_void_p(self._act.data_ptr())
         _lib.check(self.L.mcr_step(self._h, a_ptr, ctypes.c_void_p(self._obs.data_ptr()), ctypes.c_void_p(self._rew.data_ptr()),
                                    ctypes.c_void_p(self._done.data_ptr()), None, ctypes.c_void_p(st.cuda_stream)), "mcr_step")
-        self._sync_world()
         self.state = self._obs[0].cpu().numpy()
         step_reward = self._rew[0].cpu().numpy().copy()
         done = bool(self._done[0].item())
@@ -195,9 +186,6 @@ class MultiCarRacing:
         if getattr(self, "_h", None):
             self.L.mcr_destroy(self._h)
             self._h = None
-        if getattr(self, "_world", None):
-            self.L.mcr_world_destroy(self._world)
-            self._world = None
 
     def __del__(self):
         try:

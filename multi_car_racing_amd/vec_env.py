@@ -8,13 +8,14 @@ its `done` row is 1) — the convention of baselines-style VecEnvs; with `termin
 episode (what the reference returns with done = True, multi_car_racing.py:431, :509) is handed out as well, as
 info["terminal_observation"][i] for env info["terminal_env_ids"][i], i < info["terminal_count"].
 
-Every episode is the FIRST episode of a fresh b2World.  The reference reuses one world across reset() (multi_car_racing.py:138,
-341): Box2D's proxy ids — which order same-step tile events, i.e. which of two cars that reach a tile in the same step is its first
-visitor (`1000/T` vs `(1 - 1/N)·1000/T`, :113-120) — then come off the b2DynamicTree's free list in an order that depends on every
-proxy move of the episodes before.  Measured with the oracle's literal tree (tools/world_reuse_effect.py, 1,000 second episodes):
-the spawn-step reward of 58 % (N=2) of the (episode, car) pairs differs from the fresh-world order; which tiles are visited, when,
-and every pose are identical.  Reproducing it would put a serial 300-insert tree rebuild (~1 ms on one lane) into the auto-reset
-inside `step`, whose whole reset pass takes 25-48 us.
+Like the reference, every env keeps ONE b2World for its life (multi_car_racing.py:138; _destroy :173-181, reset :341): from an env's second
+episode on the fixtures' broadphase proxy ids come off the world's free list — they order same-step tile events, i.e. which of two cars that
+reach a tile in the same step is its first visitor (`1000/T` vs `(1 - 1/N)·1000/T`, :113-120), and name fixtureA of a car<->car contact (the
+manifold's reference face: poses once cars touch).  The ids need no tree on the device: leaf ids never depend on the tree's shape, a per-env
+stack of free leaf ids reproduces them (csrc/k_world.h), advanced by the env's reset pass inside `step`.  `fresh_world=True` is rounds 1-5's
+definition instead — every episode the first episode of a fresh world —; measured against the reference's semantics on the oracle
+(profiles/r06_world_reuse_effect.txt, 5 episodes back to back): 50-64 % of the (env, car) pairs of an even episode see a different reward in
+some step, and with a policy that drives the tile-visit counts of 4-17 % of the envs differ at the end of episodes 2-5.
 
 Determinism: env with global index g uses two numpy-compatible MT19937 streams,
   track stream  RandomState(seed + g)                (the reference's `env.np_random`)
@@ -60,7 +61,7 @@ class VecMultiCarRacing:
                  use_random_direction=True, backwards_flag=True, h_ratio=0.25, use_ego_color=False,
                  obs=True, auto_reset=True, max_episode_steps=1000, car_contacts=True,
                  gen_threads=None, async_refill=True, streams=None, refill_lag=64, world_size=1, graph=None,
-                 skid_particles=False, terminal_obs=False, terminal_cap=None):
+                 skid_particles=False, terminal_obs=False, terminal_cap=None, fresh_world=False):
         if not torch.cuda.is_available():
             raise _lib.McrError("VecMultiCarRacing needs a HIP device: the step path has no CPU fallback")
         self.L = _lib.load()
@@ -93,7 +94,8 @@ class VecMultiCarRacing:
         self.hold_refills = False     # tests: withhold staging to exercise the freeze/thaw path
         cfg = _lib.Config(self.B, self.N, self.device.index or 0, int(self.obs_enabled), int(self.auto_reset),
                           int(backwards_flag), int(use_ego_color), int(car_contacts), int(max_episode_steps), int(streams),
-                          float(h_ratio), int(bool(skid_particles)), 0)
+                          float(h_ratio), int(bool(skid_particles)), int(bool(fresh_world)))
+        self.fresh_world = bool(fresh_world)
         self.h = ctypes.c_void_p()
         _lib.check(self.L.mcr_create(ctypes.byref(cfg), ctypes.byref(self.h)), "mcr_create")
         self._status_now = np.zeros(8, np.uint32); self._status_seen = np.zeros(8, np.uint32)

@@ -257,12 +257,12 @@ def step_batch(envs, actions, render_mask=None, threads=None):
     L = lib()
     n = len(envs); N = envs[0].N
     hs = (ctypes.c_void_p * n)(*[e.h for e in envs])
-    a = np.ascontiguousarray(actions, np.float32)
+    a = None if actions is None else np.ascontiguousarray(actions, np.float32)      # None: the reference's step(None) for every env
     rm = None if render_mask is None else np.ascontiguousarray(render_mask, np.uint8)
     obs = np.zeros((n, N, 96, 96, 3), np.uint8); amb = np.zeros((n, N, 96, 96), np.uint8)
     rew = np.zeros((n, N)); done = np.zeros(n, np.uint8)
     L.orc_step_batch.restype = None
-    L.orc_step_batch(hs, ctypes.c_int(n), _p(a), _p(rm) if rm is not None else None, _p(obs), _p(amb), _p(rew), _p(done),
+    L.orc_step_batch(hs, ctypes.c_int(n), _p(a) if a is not None else None, _p(rm) if rm is not None else None, _p(obs), _p(amb), _p(rew), _p(done),
                      ctypes.c_int(threads or os.cpu_count() or 1))
     return obs, amb, rew, done.astype(bool)
 
@@ -313,13 +313,14 @@ class OracleEnv:
     reward (N,) f64, done bool)."""
 
     def __init__(self, num_agents=2, h_ratio=0.25, backwards_flag=True, use_ego_color=False,
-                 car_contacts=True, trig_mode=0):
+                 car_contacts=True, trig_mode=0, world_mode=1):
         self.N = num_agents
         self.L = lib()
         self.trig_mode = trig_mode
         self.h = ctypes.c_void_p(self.L.orc_create(num_agents, float(h_ratio), int(backwards_flag),
                                                    int(use_ego_color), int(car_contacts)))
         self.T = 0
+        self.L.orc_set_world_mode(self.h, int(world_mode))     # the reference's semantics by default: ONE b2World for the life of the env
 
     def close(self):
         if self.h:
@@ -327,9 +328,9 @@ class OracleEnv:
             self.h = None
 
     def set_world_mode(self, mode):
-        """0 (default, what the kernels implement): every episode is the first episode of a fresh b2World; 1: one world for the life of
-        this env, as the reference keeps it across reset() (multi_car_racing.py:138, 341) — proxy ids come off the b2DynamicTree's free
-        list (mcr_oracle.cpp: DynTree).  Call before the first reset."""
+        """1 (default, the reference, what the kernels implement since round 6): one world for the life of this env, as the reference keeps
+        it across reset() (multi_car_racing.py:138, 341) — proxy ids come off the b2DynamicTree's free list (mcr_oracle.cpp: DynTree, a
+        literal tree); 0: every episode is the first episode of a fresh b2World (mcr_config::fresh_world = 1).  Call before the first reset."""
         self.L.orc_set_world_mode(self.h, int(mode))
 
     def set_island_order(self, mode):

@@ -25,7 +25,7 @@ def test_version_and_sizes(lib):
     L = lib.load()
     assert b"gfx950" in L.mcr_version()
     assert lib.episode_bytes() % 16 == 0 and lib.episode_bytes() > 80000
-    assert ctypes.sizeof(lib.Config) == 56          # include/mcr.h: 10 x int32, double h_ratio, skid_particles, reserved0
+    assert ctypes.sizeof(lib.Config) == 56          # include/mcr.h: 10 x int32, double h_ratio, skid_particles, fresh_world
 
 
 def test_library_contains_gfx950_code_object():

@@ -242,9 +242,9 @@ def test_time_limit_and_auto_reset(torch_cuda, oracle):
     for e in range(B):
         s = (seed + e) % 2 ** 32
         tr, gr = np.random.RandomState(s), np.random.RandomState((s + 2 ** 31) % 2 ** 32)
-        oracle.new_episode(N, tr, gr, use_random_direction=True)
+        ep1 = oracle.new_episode(N, tr, gr, use_random_direction=True)
         ep2 = oracle.new_episode(N, tr, gr, use_random_direction=True)
-        o = oracle.OracleEnv(N, car_contacts=False); o2 = o.reset(ep2)
+        o = oracle.OracleEnv(N, car_contacts=False); o.reset(ep1, render=False); o2 = o.reset(ep2)     # (the env's second episode on its one world)
         amb = o.last_amb
         d = (o2 != obs[e].cpu().numpy()).any(-1)
         assert (d & (amb == 0)).sum() == 0
@@ -549,7 +549,7 @@ def test_facade_reset_reset_is_reward_exact_on_one_world(torch_cuda, oracle, N):
     env.seed(9)
     rs, _ = seeding.np_random(9)
     o1 = oracle.OracleEnv(N); o1.set_world_mode(1)                 # one world across the resets
-    o0 = oracle.OracleEnv(N)                                       # every episode the first of a fresh world
+    o0 = oracle.OracleEnv(N, world_mode=0)                         # every episode the first of a fresh world
     rng = np.random.RandomState(2)
     fresh_differs = 0
     for epi in range(4):
@@ -1082,3 +1082,47 @@ def test_a_busy_caller_stream_is_waited_out_not_reported(torch_cuda, lib):
     assert held > 3.6, f"the caller's stream was only busy for {held:.1f} s: the test did not exercise the long wait"
     env.step(a); torch.cuda.synchronize()                    # no error pending
     env.close(); ref.close()
+
+
+def test_switching_between_unfused_and_fused_steps_with_touching_cars(torch_cuda, oracle, lib):
+    """ADVICE r05 (mcr_hip.hip: the contact list of a fused step is made a step ahead): a step on a caller stream that was never bound runs on
+    events with the contact pass as a launch of its own (it fills this step's list itself); the next step on a BOUND stream runs fused — its
+    verdict writers append to the other parity's list, which then still held the unfused pass's entries of two steps back, and the step after
+    that re-stepped stale envs.  Cars touching throughout, the caller alternating between an unbound and a bound stream and through
+    mcr_set_step_graph(1) / (0): rewards every step and the whole state bit-exact with the oracle."""
+    torch = torch_cuda
+    B, N, seed = 6, 2, 9100
+    env = _make(B, N, seed, contacts=True, streams=2); env.reset()
+    orcs = _oracles(oracle, B, N, seed, contacts=True)
+    _rear_end_setup(env, orcs)
+    L = lib.load()
+    unbound, bound = torch.cuda.Stream(), torch.cuda.Stream()
+    env._bound_streams.add(unbound.cuda_stream)                       # VecMultiCarRacing.step will not hand this one to mcr_bind_stream
+    rng = np.random.RandomState(12)
+    touched = 0
+    modes = set()
+    for k in range(240):
+        phase = (k // 7) % 4                                          # 7 steps each: unbound, bound, bound + graph replay, bound again
+        st = unbound if phase == 0 else bound
+        if k % 7 == 0 and phase in (2, 3):
+            torch.cuda.synchronize()
+            assert L.mcr_set_step_graph(env.h, 1 if phase == 2 else 0) == 0
+        a = random_actions(rng, B, N, 0.0)
+        a[:, 0, 1] = 0.0; a[:, 0, 2] = 0.8 if k < 80 else 0.0
+        a[:, 1, 0] *= 0.2; a[:, 1, 1] = 1.0
+        with torch.cuda.stream(st):
+            _, rew, _, _ = env.step(torch.from_numpy(a).cuda())
+            rw = rew.cpu().numpy()
+        modes.add((phase, int(L.mcr_step_ordering_for(env.h, ctypes.c_void_p(st.cuda_stream))) & 1))
+        for e, o in enumerate(orcs):
+            _, r, _, _ = o.step(a[e], render=False)
+            touched += o.num_car_contacts()
+            assert np.array_equal(r, rw[e]), f"step {k} (phase {phase}) env {e}"
+        if k % 14 == 13:
+            torch.cuda.synchronize(); _assert_state_equal(env, orcs, f"mode switches, step {k}")
+    torch.cuda.synchronize()
+    _assert_state_equal(env, orcs, "mode switches, end")
+    assert touched > 100, "the scenario produced too few car<->car contacts"
+    assert (0, 0) in modes and (1, 1) in modes, f"the caller never saw both orderings: {modes}"
+    assert env.verdict_mismatches() == 0 and env.status_words()[:2].tolist() == [0, 0]
+    env.close()

@@ -134,3 +134,45 @@ def test_terminal_frames_b4096_sampled(torch_cuda, oracle):
         obs, rew, done, info = env.step(acts(k)[:256])
     assert int(info["terminal_count"].item()) == 0 and int(env.debug_counters()[3]) == 0
     env.close()
+
+
+def test_steps_without_terminal_frames_between_terminal_steps(torch_cuda, oracle):
+    """the terminal entries' counters are double-buffered by step parity and zeroed a step ahead by the step that draws; a step
+    that draws none (step(None): no actions) flips the parity without zeroing, and the next terminal step of that parity started from the
+    counts of two steps back — stale entries, stale terminal_count after the step(None) itself.  An action-less step after EVERY ending step
+    (and elsewhere): the ending steps list exactly the envs that ended, each frame the oracle's last one; after step(None) the count reads 0."""
+    torch = torch_cuda
+    from multi_car_racing_amd.vec_env import VecMultiCarRacing
+    B, N, seed, max_steps = 48, 2, 77, 12
+    env = VecMultiCarRacing(B, N, seed=seed, use_random_direction=True, auto_reset=True, max_episode_steps=max_steps, car_contacts=True,
+                            async_refill=True, streams=2, terminal_obs=True)
+    env.reset()
+    fol = [_Follower(oracle, N, seed, g, max_steps) for g in range(B)]
+    g = torch.Generator(device="cuda"); g.manual_seed(9)
+    endings = 0
+    for k in range(5 * max_steps + 3):
+        a = torch.rand((B, N, 3), device="cuda", generator=g); a[..., 0] = a[..., 0] * 2 - 1; a[..., 2] *= 0.2
+        obs, rew, done, info = env.step(a)
+        ids_t, frames_t = env.terminal_observations()
+        ids = ids_t.cpu().numpy(); dn = done.cpu().numpy().astype(bool)
+        assert sorted(ids.tolist()) == np.nonzero(dn)[0].tolist(), f"step {k}: entries {sorted(ids.tolist())[:8]} vs done rows {np.nonzero(dn)[0][:8]}"
+        rm = np.array([1 if f.steps + 1 >= max_steps else 0 for f in fol], np.uint8)
+        o_obs, o_amb, _, o_done = oracle.step_batch([f.o for f in fol], a.cpu().numpy(), rm, threads=os.cpu_count() or 1)
+        frames = frames_t.cpu().numpy() if len(ids) else None
+        where = {int(e): i for i, e in enumerate(ids)}
+        ended = False
+        for j, f in enumerate(fol):
+            d, _ = f.after_step(bool(o_done[j]))
+            assert d == dn[j], (k, j)
+            if d:
+                _cmp_pixels(frames[where[j]], o_obs[j], o_amb[j], f"step {k} env {j} terminal frame")
+                f.new_episode(); ended = True; endings += 1
+        if ended or k % 5 == 2:
+            # the reference's step(None) (mcr.py:410-431 with action None: no controls, no reward decrement, the world still steps)
+            _, rew0, done0, info0 = env.step(None)
+            assert int(info0["terminal_count"].item()) == 0, f"step {k}: an action-less step reports {int(info0['terminal_count'].item())} terminal entries"
+            assert not bool(done0.any())
+            oracle.step_batch([f.o for f in fol], None, None, threads=os.cpu_count() or 1)      # (not a TimeLimit step: k_dynamics counts steps with actions, as gym's wrapper counts step() calls of the agent)
+    assert endings == 5 * B
+    assert int(env.debug_counters()[3]) == 0
+    env.close()

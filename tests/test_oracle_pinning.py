@@ -291,7 +291,7 @@ def test_world_reuse_tree_ids(oracle):
     (c) visits (which tile, which car, when) do not depend on ids — the order of same-step events does, and (through fixtureA of a car<->car
     contact = the lower id) the manifold of two cars that touch."""
     N = 2
-    a, b = oracle.OracleEnv(N), oracle.OracleEnv(N)
+    a, b = oracle.OracleEnv(N, world_mode=0), oracle.OracleEnv(N)
     b.set_world_mode(1)
     ep = oracle_episode(oracle, N, 31, 0, use_random_direction=True)
     a.reset(ep, render=False); b.reset(ep, render=False)

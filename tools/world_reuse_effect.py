@@ -1,52 +1,64 @@
-"""The reference calls reset() on ONE b2World (multi_car_racing.py:138, 341); the build treats every episode as the first episode of a
-fresh world.  What does that change?  CPU only: the oracle with a literal b2DynamicTree carried through the resets of an env
-(orc_set_world_mode 1: proxy ids come off the tree's free list) against the oracle in the mode the kernels implement (mode 0), on the SAME
-second episode: first episode = `first_steps` steps of driving on track A, then reset() onto track B and `steps` steps with identical
-actions.  Not a test.   python tools/world_reuse_effect.py [episodes] [N]"""
+"""The reference calls reset() on ONE b2World (multi_car_racing.py:138, 173-181, 341); VecMultiCarRacing's default treats every episode as the
+first episode of a fresh world.  What does that change?  CPU only: the oracle with a literal b2DynamicTree carried through the resets of an
+env (orc_set_world_mode 1: proxy ids come off the tree's free list, mcr.py:113-120 then sees Box2D's callback order and a car<->car contact
+its fixtureA) against the oracle in fresh-world mode (mode 0), same tracks, same actions, FULL episodes (TimeLimit `steps`), episodes 1..5
+back to back as an auto-resetting VecEnv runs them.  Not a test.
+   python tools/world_reuse_effect.py [envs] [N] [policy: drive|random] [steps]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from oracle import oracle as O
 from tests.util import oracle_episode
 
-episodes = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+envs_n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-first_steps, steps = 150, 120
-rng = np.random.RandomState(7)
-n_spawn = n_ret = n_visit = n_scr_car = n_scr_mixed = n_t_shorter = 0
-for e in range(episodes):
-    epA, epB = oracle_episode(O, N, 20000, e, use_random_direction=True), oracle_episode(O, N, 60000, e, use_random_direction=True)
-    envs = []
-    for mode in (0, 1):
-        o = O.OracleEnv(N); o.set_world_mode(mode); envs.append(o)
-        o.reset(epA, render=False)
-    r = np.random.RandomState(1000 + e)
-    for k in range(first_steps):
-        a = np.stack([r.uniform(-0.4, 0.4, N), np.ones(N), np.zeros(N)], -1).astype(np.float32)
-        for o in envs: o.step(a, render=False)
-    # second episode
-    sp = []
-    for o in envs:
-        o.reset(epB, render=False)
-        sp.append(o.env_state()["reward"].copy())
-    tid, fid = envs[1].proxy_ids()
-    flat = fid.ravel()
-    if not np.all(np.diff(flat) > 0): n_scr_car += 1
-    if tid.max() > flat.min(): n_scr_mixed += 1
-    if len(epB["track"]) < len(epA["track"]): n_t_shorter += 1
-    ret = [np.zeros(N), np.zeros(N)]
-    vis = [None, None]
+policy = sys.argv[3] if len(sys.argv) > 3 else "drive"
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 1000
+EPISODES = 5
+thr = os.cpu_count() or 1
+
+
+def actions(r, k):
+    if policy == "drive":                   # bench.py --actions drive: gas 1, brake 0, steering noise +-0.1
+        return np.stack([r.uniform(-0.1, 0.1, (envs_n, N)), np.ones((envs_n, N)), np.zeros((envs_n, N))], -1).astype(np.float32)
+    return np.stack([r.uniform(-1, 1, (envs_n, N)), r.uniform(0, 1, (envs_n, N)), r.uniform(0, 1, (envs_n, N))], -1).astype(np.float32)
+
+
+worlds = []
+for mode in (0, 1):
+    es = []
+    for e in range(envs_n):
+        o = O.OracleEnv(N); o.set_world_mode(mode); es.append(o)
+    worlds.append(es)
+print(f"# tools/world_reuse_effect.py: {envs_n} envs x {EPISODES} episodes of <= {steps} steps, N={N}, policy {policy}; oracle world mode 1 (one b2World, the reference) vs mode 0 (fresh world per episode)")
+print("# episode | (env, car) step rewards that ever differ | (env,car) returns differing | envs: tile_visited_count differs at the end | done step differs | final poses differ | envs with a car<->car contact (mode 1)")
+for ep in range(EPISODES):
+    for es in worlds:
+        for e, o in enumerate(es):
+            o.reset(oracle_episode(O, N, 20000 + 7919 * ep, e, use_random_direction=True), render=False)
+    r = np.random.RandomState(100 + ep)
+    ret = [np.zeros((envs_n, N)), np.zeros((envs_n, N))]
+    rdiff = np.zeros((envs_n, N), bool)
+    done_at = [np.full(envs_n, steps), np.full(envs_n, steps)]
+    contact = np.zeros(envs_n, bool)
+    alive = [np.ones(envs_n, bool), np.ones(envs_n, bool)]
+    final = [None, None]
     for k in range(steps):
-        a = np.stack([r.uniform(-0.4, 0.4, N), np.ones(N), np.zeros(N)], -1).astype(np.float32)
-        for i, o in enumerate(envs):
-            _, rw, d, _ = o.step(a, render=False); ret[i] += rw
-    st = [o.env_state() for o in envs]
-    n_spawn += int(np.sum(np.asarray(sp[0]) != np.asarray(sp[1])))
-    n_ret += int(np.sum(ret[0] != ret[1]))
-    n_visit += int(not np.array_equal(st[0]["tile_visited_count"], st[1]["tile_visited_count"]))
-    for o in envs: o.close()
-print(f"second episodes: {episodes} at N={N}  (track B shorter than track A: {n_t_shorter})")
-print(f"  car proxy ids not ascending in creation order: {n_scr_car}   some tile id above some car id: {n_scr_mixed}")
-print(f"  (episode, car) pairs whose spawn-step reward differs from the fresh-world oracle: {n_spawn} of {episodes * N}")
-print(f"  (episode, car) pairs whose {steps}-step return differs: {n_ret} of {episodes * N}")
-print(f"  episodes whose tile_visited_count differs after {steps} steps: {n_visit}")
+        a = actions(r, k)
+        rw = []
+        for i, es in enumerate(worlds):
+            _, _, rew, done = O.step_batch(es, a, None, threads=thr)
+            rew = np.where(alive[i][:, None], rew, 0.0)          # an env that is done stays where it is (the oracle has no auto-reset): ignore it
+            ret[i] += rew
+            newly = done & alive[i]
+            done_at[i][newly] = k
+            alive[i] &= ~done
+            rw.append(rew)
+        rdiff |= (rw[0] != rw[1]) & (alive[0] | alive[1])[:, None]
+        if k % 10 == 0:
+            contact |= np.array([o.num_car_contacts() > 0 for o in worlds[1]])
+    st = [[o.env_state() for o in es] for es in worlds]
+    bodies = [[o.state()["bodies"] for o in es] for es in worlds]
+    tvc = sum(int(not np.array_equal(a_["tile_visited_count"], b_["tile_visited_count"])) for a_, b_ in zip(*st))
+    poses = sum(int(not np.array_equal(a_, b_)) for a_, b_ in zip(*bodies))
+    print(f"  {ep + 1} | {int(rdiff.sum())} of {envs_n * N} | {int((ret[0] != ret[1]).sum())} | {tvc} of {envs_n} | {int((done_at[0] != done_at[1]).sum())} | {poses} | {int(contact.sum())}", flush=True)
