@@ -126,6 +126,8 @@ def main():
     ap.add_argument("--rccl", action="store_true", help="with --gpus 1: initialise a 1-rank RCCL (\"nccl\") process group anyway, so that the metric all-reduce of "
                     "sharded.reduce_metrics and the step's phase-word ordering run beside a live RCCL communicator on the one GPU a box has")
     ap.add_argument("--terminal-obs", type=int, default=0, help="1: also hand out the last frame of every episode that ends (info['terminal_observation'], include/mcr.h: mcr_set_terminal_obs)")
+    ap.add_argument("--refill", choices=["native", "python"], default="native", help="native (default): the handle's own host thread polls, generates and stages the "
+                    "consumed episodes (include/mcr.h: mcr_refill_start); python: rounds 2-5's worker thread in vec_env.py")
     ap.add_argument("--fresh-world", type=int, default=0, help="0 (default): ONE b2World per env across its episodes, as the reference keeps it (csrc/k_world.h); "
                     "1: every episode the first of a fresh world (rounds 1-5's definition)")
     ap.add_argument("--graph", type=int, default=0, help="1: mcr_step replays a hipGraph of the step (bypassed while kernels are timed; measured gain 0.4 %%); 0 (default): plain launches")
@@ -188,7 +190,7 @@ def main():
         extra["gen_threads"] = max(1, total // args.emulate_world)     # what VecMultiCarRacing gives a rank of a W-rank job
         emu = {"world": args.emulate_world, "cores_allowed_to_the_job": total, "cores_this_rank": share, "gen_threads": extra["gen_threads"]}
     env = ShardedVecEnv(B * world, N, seed=0, rank=rank, world_size=world, device=dev, obs=bool(args.obs),
-                        auto_reset=True, use_random_direction=True, streams=args.streams, graph=bool(args.graph), terminal_obs=bool(args.terminal_obs), fresh_world=bool(args.fresh_world), **extra)
+                        auto_reset=True, use_random_direction=True, streams=args.streams, graph=bool(args.graph), terminal_obs=bool(args.terminal_obs), fresh_world=bool(args.fresh_world), async_refill=(True if args.refill == "native" else "python"), **extra)
     env.reset()
     # synthetic actions, generated ON THE DEVICE by a counter-based stream keyed (seed, global env, agent, t):
     # i.i.d. steer~U(-1,1), gas~U(0,1), brake~U(0,1); one small kernel per ACT_BLOCK steps inside the timed region (the

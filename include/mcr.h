@@ -83,6 +83,10 @@ int mcr_episode_generate(uint32_t* mt_track, int num_agents, int cw, const int32
  * then the track from mt_track[i].  direction_mode: 0 'CCW', 1 'CW', 2 random per episode. */
 int mcr_episodes_generate(uint32_t* mt_track, uint32_t* mt_global, int n, int num_agents,
                           int direction_mode, void* blobs_out, int32_t* info_out, int num_threads);
+/* ... for rows ids[0 .. n) of PER-ENV arrays (mt_track_all / mt_global_all [num_envs][MCR_MT_WORDS], blobs_all [num_envs][mcr_episode_bytes()],
+ * info_all [num_envs][12] or NULL), in place. */
+int mcr_episodes_generate_rows(uint32_t* mt_track_all, uint32_t* mt_global_all, const int32_t* ids, int n, int num_agents,
+                               int direction_mode, void* blobs_all, int32_t* info_all, int num_threads);
 /* Read-only views into a blob (tests / facade attributes such as env.track). */
 int mcr_episode_unpack(const void* blob, int32_t* T, int32_t* P, int32_t* cw, double* track_xyb /*[T*3]*/,
                        float* quads /*[P*8]*/, uint32_t* quad_meta /*[P]*/, double* spawn /*[8*3]*/,
@@ -151,6 +155,22 @@ int mcr_set_step_graph(mcr_env* h, int enable);
  * synchronisation, `stream` is unused; an install whose kernel has not finished yet shows up in a later poll.
  * Writes up to `cap` env ids; returns the count (>=0) or an error. */
 int mcr_poll_consumed(mcr_env* h, int32_t* env_ids_out, int cap, void* stream);
+/* The refill service: ONE host thread owned by the handle does what a stepping loop would do with the three calls above after every step —
+ * poll the consumed-episode counters, generate the next episode of every env that re-spawned from ITS rows of the caller's RNG-state arrays
+ * (mt_track / mt_draw [num_envs][MCR_MT_WORDS], advanced in place), write the blob into ITS row of blobs_pinned [num_envs][mcr_episode_bytes()]
+ * (page-locked host memory: the staging source) and episode_info [num_envs][12] (T, P, retries, cw, car_order[8]; may be NULL), stage it.
+ * The reference generates a track inside reset() on the stepping thread (:359-364); here that work is off the stepping loop, in native
+ * code (no interpreter: bench.py --emulate-world).  The arrays belong to the caller and must outlive the service; while it runs,
+ * mcr_poll_consumed is refused and the caller must not call mcr_stage_episodes.  mcr_destroy stops it.
+ * mcr_refill_wait: every consumption visible now is staged on return (synchronise the stepping stream first to mean "all").
+ * mcr_refill_lag: steps launched since the oldest not-yet-staged consumption was noticed (0: none) — a stepping loop that finds it near
+ * the shortest possible episode should wait instead of letting an env freeze.  mcr_refill_hold(1): the service ignores consumptions (tests). */
+int mcr_refill_start(mcr_env* h, uint32_t* mt_track, uint32_t* mt_draw, int direction_mode, int gen_threads, void* blobs_pinned, int32_t* episode_info);
+int mcr_refill_stop(mcr_env* h);
+int mcr_refill_wait(mcr_env* h);
+int mcr_refill_lag(mcr_env* h);
+int mcr_refill_hold(mcr_env* h, int hold);
+long long mcr_refill_generated(mcr_env* h);
 
 /* ---- state access for differential tests / facade attributes (synchronous) */
 /* bodies [B,N,5,6] f32 (c.x c.y angle v.x v.y w; body 0 hull, 1..4 wheels FL FR RL RR)

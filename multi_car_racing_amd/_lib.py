@@ -35,11 +35,18 @@ SYMBOLS = {
     "mcr_mt_car_order": (None, [_vp, _i, _vp]),
     "mcr_episode_generate": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "mcr_episodes_generate": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i]),
+    "mcr_episodes_generate_rows": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i]),
     "mcr_episode_unpack": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mcr_stage_episodes": (_i, [_vp, _vp, _i, _vp, _vp]),
     "mcr_reset": (_i, [_vp, _vp, _vp, _vp]),
     "mcr_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mcr_poll_consumed": (_i, [_vp, _vp, _i, _vp]),
+    "mcr_refill_start": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "mcr_refill_stop": (_i, [_vp]),
+    "mcr_refill_wait": (_i, [_vp]),
+    "mcr_refill_lag": (_i, [_vp]),
+    "mcr_refill_hold": (_i, [_vp, _i]),
+    "mcr_refill_generated": (ctypes.c_longlong, [_vp]),
     "mcr_get_state": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mcr_set_bodies": (_i, [_vp, _vp]),
     "mcr_get_env_state": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

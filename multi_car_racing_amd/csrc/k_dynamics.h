@@ -1095,6 +1095,22 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
           else if constexpr (CNT == 2) { cc_velocity_bl(CM, cur, meta0, cimp, 0, lane, cx, cy, cw); cc_velocity_bl(CM, second, meta1, cimp, 1, lane, cx, cy, cw); }
           else if constexpr (CNT == 3) { cc_velocity_bl(CM, cur, meta0, cimp, 0, lane, cx, cy, cw); cc_velocity_bl(CM, second, meta1, cimp, 1, lane, cx, cy, cw); cc_velocity_bl(CM, third, meta2, cimp, 2, lane, cx, cy, cw); }
           else if constexpr (CNT == 4) { cc_velocity_bl(CM, cur, meta0, cimp, 0, lane, cx, cy, cw); cc_velocity_bl(CM, second, meta1, cimp, 1, lane, cx, cy, cw); cc_velocity_bl(CM, third, meta2, cimp, 2, lane, cx, cy, cw); cc_velocity_bl(CM, fourth, meta3, cimp, 3, lane, cx, cy, cw); }
+          else if constexpr (CNT == 5) {
+            // three or more manifolds: their constants are RE-READ from LDS in every sweep, three manifolds at a time (15 ds_read_b128 in front
+            // of the first one, no rotation, nothing about them lives across the joints) instead of staying in registers for the phase —
+            // with them resident the joints' state travelled through AGPRs inside the loop (round 5: 680-1190 ticks per manifold against
+            // 540 with one or two)
+            for (int base = 0; base < ccnu; base += 3) {
+              asm volatile("" ::: "memory");                       // (the records are loop-invariant: keep the loads in the loop)
+              const int m = ccnu - base;
+              const VcRec ra = vc_load(vcpool[base]);
+              const VcRec rb = vc_load(vcpool[m > 1 ? base + 1 : base]);
+              const VcRec rc = vc_load(vcpool[m > 2 ? base + 2 : base]);
+              cc_velocity_bl(CM, ra, __builtin_amdgcn_readlane(cmeta, base), cimp, base, lane, cx, cy, cw);
+              if (m > 1) cc_velocity_bl(CM, rb, __builtin_amdgcn_readlane(cmeta, base + 1), cimp, base + 1, lane, cx, cy, cw);
+              if (m > 2) cc_velocity_bl(CM, rc, __builtin_amdgcn_readlane(cmeta, base + 2), cimp, base + 2, lane, cx, cy, cw);
+            }
+          }
           else
           for (int i = 0; i < ccnu; ++i) {
             const VcRec nxt = vc_load(vcpool[i + 1 == ccnu ? 0 : i + 1]);     // the next manifold's constants, a manifold ahead of their use
@@ -1115,8 +1131,10 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
       for (int q = 0; q < 4; ++q) any_limit = any_limit || J[q].limit != 0;
       const bool lim_any = __any(any_limit) != 0;
       using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
+      using I5 = std::integral_constant<int, 5>;
       if (ccnu == 1) { if (lim_any) sweeps(std::true_type{}, I1{}); else sweeps(std::false_type{}, I1{}); }
       else if (ccnu == 2) { if (lim_any) sweeps(std::true_type{}, I2{}); else sweeps(std::false_type{}, I2{}); }
+      else if (!(p.debug & 524288)) { if (lim_any) sweeps(std::true_type{}, I5{}); else sweeps(std::false_type{}, I5{}); }      // (debug bit 19: round 5's forms below, for the A/B)
       else if (ccnu == 3) { if (lim_any) sweeps(std::true_type{}, I3{}); else sweeps(std::false_type{}, I3{}); }
       else if (ccnu == 4) { if (lim_any) sweeps(std::true_type{}, I4{}); else sweeps(std::false_type{}, I4{}); }
       else { if (lim_any) sweeps(std::true_type{}, I0{}); else sweeps(std::false_type{}, I0{}); }

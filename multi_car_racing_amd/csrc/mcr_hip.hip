@@ -79,6 +79,7 @@ struct mcr_env {
   void* term_slab = nullptr;  // terminal observations (mcr_set_terminal_obs): entry state, view records, per-parity counters and lists
   int32_t* term_cnt2 = nullptr;   // [2][4] counters by step parity
   int32_t* term_list2 = nullptr;  // [2][2][cap] entry lists by step parity and chain
+  struct RefillSvc* svc = nullptr;  // mcr_refill_start: the handle's own host thread that generates and stages consumed episodes
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -273,8 +274,10 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
   return MCR_OK;
 }
 
+extern "C" int mcr_refill_stop(mcr_env* h);
 extern "C" int mcr_destroy(mcr_env* h) {
   if (!h) return MCR_ERR_ARG;
+  (void)mcr_refill_stop(h);
   if (h->soft_token) { std::lock_guard<std::mutex> lk(g_soft_mu); g_soft_list.erase(std::remove(g_soft_list.begin(), g_soft_list.end(), h), g_soft_list.end()); }
   (void)hipSetDevice(h->cfg.device);
   (void)hipDeviceSynchronize();
@@ -821,6 +824,7 @@ extern "C" int mcr_set_episode_stats(mcr_env* h, double* d_ep_return, int32_t* d
 
 extern "C" int mcr_poll_consumed(mcr_env* h, int32_t* env_ids_out, int cap, void* stream) {
   if (!h) return MCR_ERR_ARG;
+  if (h->svc) { g_err = "mcr_poll_consumed: the handle's refill service owns the counters (mcr_refill_start)"; return MCR_ERR_STATE; }
   (void)stream;   // counters live in mapped host memory: no device synchronisation needed
   int n = 0;
   const int B = h->cfg.num_envs;
@@ -833,6 +837,117 @@ extern "C" int mcr_poll_consumed(mcr_env* h, int32_t* env_ids_out, int cap, void
   }
   return n;
 }
+
+// ---------------------------------------------------------------------------- the refill service
+// What VecMultiCarRacing's Python worker did every step — poll the consumed-episode counters, generate the next episode of every env that
+// re-spawned (its own RNG streams), stage it — as ONE native thread of the handle: no interpreter, no GIL hand-offs, no gather / scatter of
+// RNG states, no bounce buffer (the env's row of the caller's pinned blob array is the staging source).  Host share of a rank: bench.py
+// --emulate-world 8.  The arrays belong to the caller and must outlive the service.
+#include <thread>
+#include <condition_variable>
+#include <atomic>
+#include <unistd.h>
+#include <sys/prctl.h>
+extern "C" int mcr_episodes_generate_rows(uint32_t*, uint32_t*, const int32_t*, int, int, int, void*, int32_t*, int);   // mcr_host.cpp
+struct RefillSvc {
+  std::thread th;
+  std::mutex m;                        // one refill cycle at a time (the thread's, or a caller's inside mcr_refill_wait)
+  std::atomic<bool> stop{false}, hold{false};
+  uint32_t* mt_track; uint32_t* mt_draw; int direction_mode, gen_threads;
+  uint8_t* blobs; int32_t* info;
+  hipStream_t st = nullptr; hipEvent_t ev = nullptr;
+  std::vector<int32_t> ids;
+  std::atomic<long long> generated{0};
+  std::atomic<int32_t> pending_since{0}; std::atomic<bool> pending{false};
+  std::atomic<int> err{0}; std::string err_msg;
+};
+// one cycle: returns the number of episodes staged (< 0: error, message in s->err_msg).  Caller holds s->m.
+static int refill_cycle(mcr_env* h, RefillSvc* s) {
+  const int B = h->cfg.num_envs;
+  int n = 0;
+  for (int e = 0; e < B; ++e) {
+    const int32_t c = ((volatile int32_t*)h->consumed_host)[e];
+    if (c != h->consumed_seen[e]) { h->consumed_seen[e] = c; s->ids[n++] = e; }
+  }
+  if (n == 0) return 0;
+  if (!s->pending.exchange(true)) s->pending_since.store(h->step_count);
+  int rc = mcr_episodes_generate_rows(s->mt_track, s->mt_draw, s->ids.data(), n, h->cfg.num_agents, s->direction_mode, s->blobs, s->info, s->gen_threads);
+  if (rc != MCR_OK) { s->err_msg = "track generation failed (capacity: MCR_TILE_CAP / MCR_QUAD_CAP)"; s->err.store(rc); return rc; }
+  auto fail = [&](const char* what, hipError_t e) { s->err_msg = std::string(what) + ": " + hipGetErrorString(e); s->err.store(MCR_ERR_HIP); return (int)MCR_ERR_HIP; };
+  for (int i = 0; i < n; ++i) {
+    const int e = s->ids[i];
+    const int32_t installs = ((volatile int32_t*)h->consumed_host)[e];
+    uint8_t* dst = h->P.slots + ((size_t)e * 2 + ((installs & 1) ^ 1)) * MCR_SLOT_BYTES;
+    const hipError_t er = hipMemcpyAsync(dst, s->blobs + (size_t)e * MCR_SLOT_BYTES, MCR_SLOT_BYTES, hipMemcpyHostToDevice, s->st);
+    if (er != hipSuccess) return fail("hipMemcpyAsync (episode)", er);
+  }
+  hipError_t er = hipMemcpyAsync(h->stage_ids, s->ids.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s->st);
+  if (er != hipSuccess) return fail("hipMemcpyAsync (ids)", er);
+  hipLaunchKernelGGL(k_mark_staged, dim3((n + 255) / 256), dim3(256), 0, s->st, h->P, (const int32_t*)h->stage_ids, n);
+  if ((er = hipEventRecord(s->ev, s->st)) != hipSuccess) return fail("hipEventRecord", er);
+  // (polled with a sleep in between: hipEventSynchronize / hipStreamSynchronize spin on this runtime — 0.8 of a core, measured in round 3 —
+  // and a spinning thread takes a core from the track generator where the ranks of a node share few)
+  for (;;) { er = hipEventQuery(s->ev); if (er == hipSuccess) break; if (er != hipErrorNotReady) return fail("hipEventQuery", er); usleep(40); }
+  s->generated.fetch_add(n);
+  s->pending.store(false);
+  return n;
+}
+static void refill_main(mcr_env* h, RefillSvc* s) {
+  (void)prctl(PR_SET_NAME, "mcr-refill", 0, 0, 0);
+  (void)hipSetDevice(h->cfg.device);
+  while (!s->stop.load()) {
+    int n = 0;
+    if (!s->hold.load() && s->err.load() == 0) { std::lock_guard<std::mutex> lk(s->m); n = refill_cycle(h, s); }
+    if (n <= 0) usleep(150);           // (a step takes 0.2 ms and an env needs hundreds of steps to end its next episode: nothing is urgent here)
+  }
+}
+extern "C" int mcr_refill_start(mcr_env* h, uint32_t* mt_track, uint32_t* mt_draw, int direction_mode, int gen_threads, void* blobs_pinned, int32_t* episode_info) {
+  if (!h || !mt_track || !mt_draw || !blobs_pinned) { g_err = "mcr_refill_start: null argument"; return MCR_ERR_ARG; }
+  if (h->svc) { g_err = "mcr_refill_start: already running"; return MCR_ERR_STATE; }
+  HIPCHK(hipSetDevice(h->cfg.device));
+  RefillSvc* s = new RefillSvc();
+  s->mt_track = mt_track; s->mt_draw = mt_draw; s->direction_mode = direction_mode; s->gen_threads = std::max(1, gen_threads);
+  s->blobs = (uint8_t*)blobs_pinned; s->info = episode_info; s->ids.resize(h->cfg.num_envs);
+  if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) != hipSuccess) { delete s; g_err = "mcr_refill_start: stream / event"; return MCR_ERR_HIP; }
+  h->svc = s;
+  s->th = std::thread(refill_main, h, s);
+  return MCR_OK;
+}
+extern "C" int mcr_refill_stop(mcr_env* h) {
+  if (!h) return MCR_ERR_ARG;
+  RefillSvc* s = h->svc;
+  if (!s) return MCR_OK;
+  s->stop.store(true);
+  if (s->th.joinable()) s->th.join();
+  (void)hipSetDevice(h->cfg.device);
+  (void)hipStreamSynchronize(s->st);
+  (void)hipStreamDestroy(s->st); (void)hipEventDestroy(s->ev);
+  h->svc = nullptr;
+  delete s;
+  return MCR_OK;
+}
+// every consumption visible NOW is staged when this returns (the caller synchronised the stepping stream first if it needs "all of them");
+// honours the hold switch (tests: an env that finds no staged episode freezes)
+extern "C" int mcr_refill_wait(mcr_env* h) {
+  if (!h) return MCR_ERR_ARG;
+  RefillSvc* s = h->svc;
+  if (!s) return MCR_OK;
+  if (s->err.load()) { g_err = "the refill service failed: " + s->err_msg; return s->err.load(); }
+  if (s->hold.load()) return MCR_OK;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  std::lock_guard<std::mutex> lk(s->m);
+  for (;;) { const int n = refill_cycle(h, s); if (n < 0) { g_err = "the refill service failed: " + s->err_msg; return n; } if (n == 0) break; }
+  return MCR_OK;
+}
+// steps launched since the oldest consumption that is not staged yet was noticed (0: nothing pending); < 0: the service failed
+extern "C" int mcr_refill_lag(mcr_env* h) {
+  if (!h || !h->svc) return 0;
+  RefillSvc* s = h->svc;
+  if (s->err.load()) { g_err = "the refill service failed: " + s->err_msg; return s->err.load(); }
+  return s->pending.load() ? std::max(0, (int32_t)((uint32_t)h->step_count - (uint32_t)s->pending_since.load())) : 0;
+}
+extern "C" int mcr_refill_hold(mcr_env* h, int hold) { if (!h || !h->svc) return MCR_ERR_STATE; h->svc->hold.store(hold != 0); return MCR_OK; }
+extern "C" long long mcr_refill_generated(mcr_env* h) { return (h && h->svc) ? h->svc->generated.load() : 0; }
 
 // ---------------------------------------------------------------------------- state access (synchronous)
 extern "C" int mcr_get_state(mcr_env* h, float* bodies, float* joints, double* wheels, int32_t* limit, uint8_t* on_road, float* sleep) {

@@ -549,6 +549,34 @@ extern "C" int mcr_episodes_generate(uint32_t* mt_track, uint32_t* mt_global, in
   return err.load();
 }
 
+// the same for rows ids[0..n) of PER-ENV arrays, in place: what the refill service (mcr_hip.hip) asks for — no gather / scatter of RNG states
+extern "C" int mcr_episodes_generate_rows(uint32_t* mt_track_all, uint32_t* mt_global_all, const int32_t* ids, int n, int num_agents,
+                                          int direction_mode, void* blobs_all, int32_t* info_all, int num_threads) {
+  if (!mt_track_all || !mt_global_all || !blobs_all || !ids || n < 0) return MCR_ERR_ARG;
+  if (num_threads < 1) num_threads = 1;
+  if (num_threads > n) num_threads = n > 0 ? n : 1;
+  std::atomic<int> next(0), err(0);
+  auto work = [&]() {
+    for (;;) {
+      const int i = next.fetch_add(1);
+      if (i >= n) break;
+      const size_t e = (size_t)ids[i];
+      uint32_t* g = mt_global_all + e * MCR_MT_WORDS;
+      int cw = direction_mode == 1;
+      if (direction_mode == 2) cw = mcr_mt_choice_cw(g);              // :351-352
+      int32_t order[MCR_MAX_AGENTS];
+      mcr_mt_car_order(g, num_agents, order);                          // :355-357
+      int32_t info[4];
+      const int rc = mcr_episode_generate(mt_track_all + e * MCR_MT_WORDS, num_agents, cw, order, (uint8_t*)blobs_all + e * MCR_SLOT_BYTES, info);
+      if (rc != MCR_OK) err.store(rc);
+      if (info_all) { int32_t* o = info_all + e * 12; for (int k = 0; k < 4; ++k) o[k] = info[k]; for (int k = 0; k < 8; ++k) o[4 + k] = k < num_agents ? order[k] : -1; }
+    }
+  };
+  const std::function<void()> job = work;
+  gen_pool().run(num_threads - 1, job);
+  return err.load();
+}
+
 extern "C" int mcr_episode_unpack(const void* blob_in, int32_t* T, int32_t* P, int32_t* cw, double* track_xyb,
                                   float* quads, uint32_t* quad_meta, double* spawn, double* track_alpha) {
   if (!blob_in) return MCR_ERR_ARG;

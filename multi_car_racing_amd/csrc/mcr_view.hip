@@ -1,9 +1,8 @@
 // mcr_view.hip — the raster kernel (k_view.h) as a translation unit of its own: it is built with -fno-slp-vectorize.
 // The SLP vectoriser pairs independent f32 operations into v_pk_* instructions, which on gfx950 issue at 0.55x the rate of
 // the scalar forms (profiles/r02_ubench_issue_rates.txt) and need their operands in adjacent registers: for the raster
-// that costs 6 VGPRs it does not have (168 + 40 B of scratch vs 162 and none) and 5 us per launch.  The rigid-body
-// kernels keep the default (k_dynamics is 7 us FASTER with the packed forms: fewer instructions on a single wavefront
-// per SIMD).  build.py carries the per-file flags.
+// that costs 6 VGPRs it does not have (168 + 40 B of scratch vs 162 and none) and 5 us per launch.  (mcr_hip.hip is built the same way since
+// round 5: its velocity sweeps are written on pairs of floats by hand, and the vectoriser's own pairs only cost there — build.py has the numbers.)
 #include "mcr_kernels.h"
 #define MCR_DEVICE_FUNCTIONS_ONLY          // k_flags.h / k_touch.h: the device functions, not the kernels (they live in mcr_hip.hip)
 #include "k_flags.h"

@@ -91,7 +91,7 @@ class VecMultiCarRacing:
         self._pending = collections.deque()      # step index at which each queued refill batch was queued
         self._pending_lock = threading.Lock()
         self._worker_exc = None
-        self.hold_refills = False     # tests: withhold staging to exercise the freeze/thaw path
+        self._hold_refills = False    # tests: withhold staging to exercise the freeze/thaw path
         cfg = _lib.Config(self.B, self.N, self.device.index or 0, int(self.obs_enabled), int(self.auto_reset),
                           int(backwards_flag), int(use_ego_color), int(car_contacts), int(max_episode_steps), int(streams),
                           float(h_ratio), int(bool(skid_particles)), int(bool(fresh_world)))
@@ -141,10 +141,15 @@ class VecMultiCarRacing:
         self._refill_pin = None       # pinned bounce buffer of the refill thread (grown on demand)
         self.episode_info = np.zeros((self.B, 12), np.int32)      # T, P, retries, cw, car_order[8] of the newest generated episode
         self._ids = np.zeros(self.B, np.int32)
-        self.episodes_generated = 0
+        self._episodes_generated = 0
         self._copy_stream = torch.cuda.Stream(device=self.device)
         self._copy_done = torch.cuda.Event(blocking=True)
+        # async_refill: True (default) — the handle's own native thread polls, generates and stages (include/mcr.h: mcr_refill_start; no
+        # interpreter in the loop: 2.1 -> 1.x host cores per rank, bench.py --emulate-world); "python" — rounds 2-5's worker thread in this
+        # module (kept for comparison); False — synchronously inside step() (tests that need the staging at a known point)
         self._async = bool(async_refill)
+        self._native = async_refill is True or async_refill == "native"
+        self._svc = False             # the native service is running
         self._q = None
         self._worker = None
         self._closed = False
@@ -174,7 +179,7 @@ class VecMultiCarRacing:
         self.episode_info[ids] = info
         if n != self.B:
             self._blobs_np[ids] = blobs              # per-env copy for introspection (current_episode / facade env.track)
-        self.episodes_generated += n
+        self._episodes_generated += n
         return blobs
 
     def _stage(self, ids, rows, stream):
@@ -237,7 +242,29 @@ class VecMultiCarRacing:
             exc, self._worker_exc = self._worker_exc, None
             raise _lib.McrError(f"episode refill thread failed: {exc!r}") from exc
 
+    @property
+    def episodes_generated(self):
+        return self._episodes_generated + (int(self.L.mcr_refill_generated(self.h)) if self._svc else 0)
+
+    @property
+    def hold_refills(self):
+        return self._hold_refills
+
+    @hold_refills.setter
+    def hold_refills(self, v):
+        self._hold_refills = bool(v)
+        if self._svc:
+            _lib.check(self.L.mcr_refill_hold(self.h, int(self._hold_refills)), "mcr_refill_hold")
+
     def _poll_and_refill(self):
+        if self._native:
+            if not self._svc:         # (started after the first reset()'s own staging: from here on the RNG states and the blob rows are the service's)
+                _lib.check(self.L.mcr_refill_start(self.h, _lib.ptr(self.mt_track), _lib.ptr(self.mt_draw), self.direction_mode, self.gen_threads,
+                                                   ctypes.c_void_p(self._blobs.data_ptr()), _lib.ptr(self.episode_info)), "mcr_refill_start")
+                self._svc = True
+                if self._hold_refills:
+                    _lib.check(self.L.mcr_refill_hold(self.h, 1), "mcr_refill_hold")
+            return 0
         if self.hold_refills:
             return 0
         n = self.L.mcr_poll_consumed(self.h, _lib.ptr(self._ids), self.B, None)
@@ -257,6 +284,9 @@ class VecMultiCarRacing:
         return n
 
     def wait_refills(self):
+        if self._svc:
+            _lib.check(self.L.mcr_refill_wait(self.h), "mcr_refill_wait")
+            return
         if self._q is not None:
             self._q.join()
         self._raise_worker_error()
@@ -309,8 +339,14 @@ class VecMultiCarRacing:
         """actions: float32 device tensor [B,N,3] (steer, gas, brake) or None. Returns (obs, reward, done, info)."""
         st = torch.cuda.current_stream(self.device)
         self._raise_worker_error()
-        with self._pending_lock:              # (the refill worker pops entries under the same lock)
-            behind = bool(self._pending) and self._step_idx - self._pending[0] >= self.refill_lag
+        if self._svc:
+            lag = int(self.L.mcr_refill_lag(self.h))
+            if lag < 0:
+                _lib.check(lag, "mcr_refill_lag")
+            behind = lag >= max(1, self.refill_lag - 4)      # (the service notices a consumption up to a few steps after it happened)
+        else:
+            with self._pending_lock:          # (the refill worker pops entries under the same lock)
+                behind = bool(self._pending) and self._step_idx - self._pending[0] >= self.refill_lag
         if behind:
             t0 = time.perf_counter()
             self.wait_refills()               # the host fell behind: block instead of letting an env freeze
@@ -477,6 +513,9 @@ class VecMultiCarRacing:
         if self._worker is not None:
             self._q.put(None)
             self._worker.join()
+        if self._svc and self.h:
+            self.L.mcr_refill_stop(self.h)
+            self._svc = False
         if self.h:
             self.L.mcr_destroy(self.h)
             self.h = None

@@ -1126,3 +1126,34 @@ def test_switching_between_unfused_and_fused_steps_with_touching_cars(torch_cuda
     assert (0, 0) in modes and (1, 1) in modes, f"the caller never saw both orderings: {modes}"
     assert env.verdict_mismatches() == 0 and env.status_words()[:2].tolist() == [0, 0]
     env.close()
+
+
+def test_configs0_flags_on_the_hip_path(torch_cuda, oracle):
+    """BASELINE configs[0] (README: the CarRacing-v0 special case): num_agents=1, use_random_direction=False, backwards_flag=False — on the HIP
+    path, frames every step while the car spins into driving backwards: `driving_backward` is tracked but its HUD triangle (:669-674) is never
+    drawn; an env beside it with the flag ON differs from it in exactly that triangle."""
+    torch = torch_cuda
+    B, N, seed = 3, 1, 310
+    env = _make(B, N, seed, contacts=True, backwards_flag=False, use_random_direction=False, direction="CCW"); env.reset()
+    shown = _make(B, N, seed, contacts=True, backwards_flag=True, use_random_direction=False, direction="CCW"); shown.reset()
+    orcs = _oracles(oracle, B, N, seed, contacts=True, backwards_flag=False, direction="CCW")
+    rng = np.random.RandomState(6)
+    backward_steps = flag_pixels = 0
+    for k in range(150):
+        a = random_actions(rng, B, N, 0.0); a[..., 0] = 1.0 if k > 40 else a[..., 0]       # full lock: the car turns around
+        at = torch.from_numpy(a).cuda()
+        obs, rew, done, _ = env.step(at); obs2, _, _, _ = shown.step(at)
+        es = env.get_env_state()
+        for e, o in enumerate(orcs):
+            _, r, d, _ = o.step(a[e], render=True)
+            assert np.array_equal(r, rew[e].cpu().numpy()) and bool(done[e].item()) == d, (k, e)
+            assert np.array_equal(es["driving_backward"][e], o.env_state()["driving_backward"]), (k, e)
+            backward_steps += int(o.env_state()["driving_backward"].any())
+        ob = obs.cpu().numpy()
+        _assert_pixels(ob, orcs, budget=40)
+        diff = (ob != obs2.cpu().numpy()).any(-1)                     # [B, N, 96, 96]
+        flag_pixels += int(diff.sum())
+        assert not diff[:, :, :84].any() and not diff[:, :, :, :84].any(), "the two envs may differ in the flag's pixels only (rows 88..91, columns 87..90)"
+    _assert_state_equal(env, orcs, "configs[0] flags, end")
+    assert backward_steps > 20 and flag_pixels > 0, (backward_steps, flag_pixels)
+    env.close(); shown.close()
