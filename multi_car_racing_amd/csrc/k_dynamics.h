@@ -1067,7 +1067,10 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
       // the whole phase: 530-570 ticks per manifold and sweep with one or two, 680-810 with three or four (registers run out: the joints' state
       // starts to travel through AGPRs); beyond four they rotate through a record loaded a manifold ahead (960-1190 ticks: ~26 register moves,
       // 12 LDS reads and ~40 AGPR moves per manifold).  Measured and not kept: two records used alternately instead of the rotation (1080
-      // ticks), the constants in lane registers read out with v_readlane (slower than the LDS prefetch).  tools/posloop_profile.py VEL=1)
+      // ticks), the constants in lane registers read out with v_readlane (slower than the LDS prefetch); round 6: for three or more manifolds the
+      // constants RE-READ from LDS in every sweep, three manifolds at a time, nothing of them live across the joints — the loop's AGPR moves fall
+      // from 124 to 14 per sweep (ISA) and --actions drive from 5.56 to 5.21 M env-steps/s (same box, alternating, twice): the reads' latency
+      // sits on the chain.  tools/posloop_profile.py VEL=1)
       auto sweeps = [&](auto lim_tag, auto cnt_tag) {
         constexpr bool LIM = decltype(lim_tag)::value;
         constexpr int CNT = decltype(cnt_tag)::value;     // 1 .. 4: exactly that many manifolds; 0: any number
@@ -1095,22 +1098,6 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
           else if constexpr (CNT == 2) { cc_velocity_bl(CM, cur, meta0, cimp, 0, lane, cx, cy, cw); cc_velocity_bl(CM, second, meta1, cimp, 1, lane, cx, cy, cw); }
           else if constexpr (CNT == 3) { cc_velocity_bl(CM, cur, meta0, cimp, 0, lane, cx, cy, cw); cc_velocity_bl(CM, second, meta1, cimp, 1, lane, cx, cy, cw); cc_velocity_bl(CM, third, meta2, cimp, 2, lane, cx, cy, cw); }
           else if constexpr (CNT == 4) { cc_velocity_bl(CM, cur, meta0, cimp, 0, lane, cx, cy, cw); cc_velocity_bl(CM, second, meta1, cimp, 1, lane, cx, cy, cw); cc_velocity_bl(CM, third, meta2, cimp, 2, lane, cx, cy, cw); cc_velocity_bl(CM, fourth, meta3, cimp, 3, lane, cx, cy, cw); }
-          else if constexpr (CNT == 5) {
-            // three or more manifolds: their constants are RE-READ from LDS in every sweep, three manifolds at a time (15 ds_read_b128 in front
-            // of the first one, no rotation, nothing about them lives across the joints) instead of staying in registers for the phase —
-            // with them resident the joints' state travelled through AGPRs inside the loop (round 5: 680-1190 ticks per manifold against
-            // 540 with one or two)
-            for (int base = 0; base < ccnu; base += 3) {
-              asm volatile("" ::: "memory");                       // (the records are loop-invariant: keep the loads in the loop)
-              const int m = ccnu - base;
-              const VcRec ra = vc_load(vcpool[base]);
-              const VcRec rb = vc_load(vcpool[m > 1 ? base + 1 : base]);
-              const VcRec rc = vc_load(vcpool[m > 2 ? base + 2 : base]);
-              cc_velocity_bl(CM, ra, __builtin_amdgcn_readlane(cmeta, base), cimp, base, lane, cx, cy, cw);
-              if (m > 1) cc_velocity_bl(CM, rb, __builtin_amdgcn_readlane(cmeta, base + 1), cimp, base + 1, lane, cx, cy, cw);
-              if (m > 2) cc_velocity_bl(CM, rc, __builtin_amdgcn_readlane(cmeta, base + 2), cimp, base + 2, lane, cx, cy, cw);
-            }
-          }
           else
           for (int i = 0; i < ccnu; ++i) {
             const VcRec nxt = vc_load(vcpool[i + 1 == ccnu ? 0 : i + 1]);     // the next manifold's constants, a manifold ahead of their use
@@ -1131,10 +1118,8 @@ __device__ __forceinline__ void dynamics_block(const McrParams& p, const int mod
       for (int q = 0; q < 4; ++q) any_limit = any_limit || J[q].limit != 0;
       const bool lim_any = __any(any_limit) != 0;
       using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
-      using I5 = std::integral_constant<int, 5>;
       if (ccnu == 1) { if (lim_any) sweeps(std::true_type{}, I1{}); else sweeps(std::false_type{}, I1{}); }
       else if (ccnu == 2) { if (lim_any) sweeps(std::true_type{}, I2{}); else sweeps(std::false_type{}, I2{}); }
-      else if (!(p.debug & 524288)) { if (lim_any) sweeps(std::true_type{}, I5{}); else sweeps(std::false_type{}, I5{}); }      // (debug bit 19: round 5's forms below, for the A/B)
       else if (ccnu == 3) { if (lim_any) sweeps(std::true_type{}, I3{}); else sweeps(std::false_type{}, I3{}); }
       else if (ccnu == 4) { if (lim_any) sweeps(std::true_type{}, I4{}); else sweeps(std::false_type{}, I4{}); }
       else { if (lim_any) sweeps(std::true_type{}, I0{}); else sweeps(std::false_type{}, I0{}); }
@@ -1838,6 +1823,15 @@ __global__ __launch_bounds__(64) void k_dynamics(McrParams p, int mode) {
     if (p.term_cnt_next) { p.term_cnt_next[0] = 0; p.term_cnt_next[1] = 0; p.term_cnt_next[2] = 0; }
   }
   dynamics_block<CC>(p, mode, (int)blockIdx.x);
+  if (mode == 0 && p.post_dyn) {
+    // W_DYN from inside the kernel: every workgroup (= wavefront) releases what it stored (agent scope: its XCD's L2 is written back), then
+    // counts itself; the last one posts.  The HIP memory model's release pattern — the consumer's kernels behind k_await start with the usual acquire.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (threadIdx.x == 0) {
+      const int done = __hip_atomic_fetch_add(&p.sync_words[W_DYN_COUNT * 16], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+      if (done == (int)gridDim.x) { __hip_atomic_store(&p.sync_words[W_DYN_COUNT * 16], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); mcr_post(p, W_DYN); }
+    }
+  }
 }
 
 __global__ void k_mark_staged(McrParams p, const int32_t* __restrict__ ids, int n) {

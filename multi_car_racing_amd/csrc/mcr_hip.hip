@@ -75,6 +75,7 @@ struct mcr_env {
   bool soft_sync = false;     // the step's streams meet through phase words in device memory (mcr_kernels.h: mcr_post / mcr_await) instead of events
   bool stop_events = true;    // events completed by the launches they mark (hipExtLaunchKernelGGL) instead of marker packets behind them
   int chain_grid;             // workgroups of a list chain launch (each walks the list, 2 envs at a time)
+  bool post_dyn = true;       // the main dynamics posts its own completion (McrParams::post_dyn; MCR_POST_DYN=0, read at create: the kernel behind it does, as in rounds 3-5)
   bool vorder_dirty[2];       // the raster order list of that step parity was filled by a step that did not draw
   void* term_slab = nullptr;  // terminal observations (mcr_set_terminal_obs): entry state, view records, per-parity counters and lists
   int32_t* term_cnt2 = nullptr;   // [2][4] counters by step parity
@@ -237,6 +238,7 @@ extern "C" int mcr_create(const mcr_config* cfg, mcr_env** out) {
         // (the switches of the environment — MCR_SOFT_SYNC=0, MCR_STOP_EVENTS=0, MCR_SEQUENTIAL_COLLIDE=1 — select paths that exist for
         // environments where the default cannot run: profilers that serialise kernels, graph capture; the parity suite covers each)
         if (const char* g = getenv("MCR_STOP_EVENTS")) h->stop_events = atoi(g) != 0;
+        if (const char* g = getenv("MCR_POST_DYN")) h->post_dyn = atoi(g) != 0;
         h->soft_sync = kernels_overlap(h->s_defer, h->s_side);     // (a waiting kernel needs the kernels it waits for to run beside it)
         if (const char* g = getenv("MCR_SOFT_SYNC")) h->soft_sync = h->soft_sync && atoi(g) != 0;
         // One handle per device and process at a time: the side stream's wait for "begin" is enqueued BEFORE the kernel that posts it.
@@ -511,9 +513,11 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     if (draw) { McrParams Pv = P; Pv.flags_blocks = fiv_c; launch_view(h, 6, P.term_cnt ? 2 * B : B, h->s_side, Pv, 0, nullptr, vg_c); }
     hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, h->s_side, P, (int)W_SIDE);
     P.role = 1;
+    P.post_dyn = h->post_dyn ? 1 : 0;
     P.viewprep_in_flags = (view_flags && draw && h->viewprep_in_flags) ? 1 : 0;
     const bool flags_on_caller = view_flags && draw && !P.viewprep_in_flags && N <= 7;   // (N = 8: the raster would share the machine with the bookkeeping: 6.70 -> 6.49 M env-steps/s, round 5)
     LAUNCH(1, k_dynamics<false>, dyn_blocks, 64, st, P, 0);          // (the main envs: no touching car<->car pair)
+    P.post_dyn = 0;
     P.role = 3;
     {
       const int ga = std::min(lg_dyn, MCR_LIST_GRID / 2), gb = P.auto_reset ? lg_col : 0;

@@ -55,6 +55,8 @@ struct McrParams {
                                 // of events (marker and barrier packets that the command processor evaluates: 4-17 us each on the critical path)
   int32_t flags_blocks;         // list raster launches: the last `flags_blocks` workgroups of the grid do the bookkeeping (k_flags.h) of the list's cars, a
                                 // wavefront per car, beside the workgroups that draw them — a launch of its own for them sat between a chain and its raster
+  int32_t post_dyn;             // soft_sync, main dynamics: the LAST workgroup to finish posts W_DYN itself (a release fence per workgroup + one counter) instead of the
+                                // first thread of the kernel behind it in the stream (3-4 us later, after the dynamics' drain)
   int32_t await_tail;           // soft_sync, list raster at the tail of the caller's stream: its first workgroup ends by awaiting W_SIDE and W_MAIN — the
                                 // launch completes when the whole step has (a kernel of its own for that costs 5-7 us beside the main raster)
   int32_t cc_mode;              // 1: the main k_dynamics runs CONCURRENTLY with k_collide pass 0 (three-chain step): it finds the envs whose
@@ -144,6 +146,7 @@ enum { W_BEGIN = 0,    // the caller's stream reached this step's main dynamics 
        W_DYN = 2,      // the main dynamics is complete
        W_SIDE = 3,     // the side stream's part of the step is complete
        W_MAIN = 4,     // the third stream's part of the step is complete
+       W_DYN_COUNT = 5,// (not a phase word: workgroups of the main dynamics that are through — post_dyn)
        MCR_SYNC_WORDS = 8 };
 __device__ __forceinline__ void mcr_post(const McrParams& p, int w) {
   __hip_atomic_store(&p.sync_words[w * 16], mcr_epoch(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

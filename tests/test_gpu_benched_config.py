@@ -166,10 +166,10 @@ def _run_sampled(torch, O, B, N, seed, steps, n_sample, max_steps, masked_reset_
 
 def test_benched_config_b4096_sampled_oracles(torch_cuda, oracle):
     """bench.py's default workload (BASELINE configs[1]) for 1,100 steps: crosses TimeLimit(1000) -> 4096 device-side
-    auto-resets in one step + host refill, plus two masked resets; 64 sampled envs == their oracles throughout."""
-    n_resets, n_contacts, frozen = _run_sampled(torch_cuda, oracle, B=4096, N=2, seed=20, steps=1100, n_sample=64,
+    auto-resets in one step + host refill, plus two masked resets; 48 sampled envs == their oracles throughout."""
+    n_resets, n_contacts, frozen = _run_sampled(torch_cuda, oracle, B=4096, N=2, seed=20, steps=1100, n_sample=48,
                                                 max_steps=1000, masked_reset_at=(333, 720))
-    assert n_resets >= 64, n_resets
+    assert n_resets >= 48, n_resets
     assert frozen == 0, f"{frozen} env-steps frozen waiting for the host"
 
 
@@ -195,7 +195,7 @@ def test_physics_only_b4096_sampled_oracles(torch_cuda, oracle):
     assert n_contacts > 0, "no sampled env ever held a car<->car contact"
 
 
-@pytest.mark.parametrize("knobs, ordering", [({}, 1), ({"MCR_UNFUSED_COLLIDE": "1"}, 1), ({"MCR_SOFT_SYNC": "0"}, 2), ({"MCR_SOFT_SYNC": "0", "MCR_STOP_EVENTS": "0"}, 0)])
+@pytest.mark.parametrize("knobs, ordering", [({}, 1), ({"MCR_UNFUSED_COLLIDE": "1", "MCR_POST_DYN": "0"}, 1), ({"MCR_SOFT_SYNC": "0"}, 2), ({"MCR_SOFT_SYNC": "0", "MCR_STOP_EVENTS": "0"}, 0)])
 def test_every_stream_ordering_of_the_step_matches_the_oracle(torch_cuda, oracle, monkeypatch, knobs, ordering):
     """The three-chain step orders its streams through phase words in device memory (default where kernels overlap) or through
     events (profilers that serialise kernels, a wait that gave up, graph capture) — completed by the launches they mark or recorded

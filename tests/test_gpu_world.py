@@ -41,7 +41,7 @@ def _drive(torch, gen, B, N, k, L=110):
     return a
 
 
-@pytest.mark.parametrize("B,N,n_sample,max_steps", [(4096, 2, 24, 110), (512, 8, 10, 110), (256, 4, 12, 110)])
+@pytest.mark.parametrize("B,N,n_sample,max_steps", [(4096, 2, 14, 110), (512, 8, 7, 110)])
 def test_auto_reset_episodes_on_one_world(torch_cuda, oracle, lib, B, N, n_sample, max_steps):
     """B = 4096 (N = 2), sampled: 4 consecutive episodes per env (TimeLimit), driving policy with pile-ups; rewards and done every step, the
     whole state every 55 steps and the proxy ids of every episode equal to the one-world oracle; a fresh-world oracle beside it disagrees."""
