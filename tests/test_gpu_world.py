@@ -28,23 +28,23 @@ def _device_ids(env, lib, g):
     return out[:n]
 
 
-def _drive(torch, gen, B, N, k, L=110):
-    """a policy that drives INTO its neighbours (bench.py --actions drive plus a bias): gas 1, steering noise +-0.05; in the first 45 steps of
+def _drive(torch, gen, B, N, k, L=84):
+    """a policy that drives INTO its neighbours (bench.py --actions drive plus a bias): gas 1, steering noise +-0.05; in the first 40 steps of
     an episode of L steps the even cars steer one way and the odd cars the other (the grid's pairs converge in half of the envs), then the
-    even cars brake for 45 steps (whoever is behind runs into them)"""
+    even cars brake for 35 steps (whoever is behind runs into them)"""
     a = torch.zeros((B, N, 3), device="cuda")
     a[..., 0] = torch.rand((B, N), device="cuda", generator=gen) * 0.1 - 0.05
     a[..., 1] = 1.0
     ke = k % L
-    if ke < 45: a[:, ::2, 0] += 0.12; a[:, 1::2, 0] -= 0.12
-    if 45 <= ke < 90: a[:, ::2, 1] = 0.0; a[:, ::2, 2] = 0.9
+    if ke < 40: a[:, ::2, 0] += 0.12; a[:, 1::2, 0] -= 0.12
+    if 40 <= ke < 75: a[:, ::2, 1] = 0.0; a[:, ::2, 2] = 0.9
     return a
 
 
-@pytest.mark.parametrize("B,N,n_sample,max_steps", [(4096, 2, 14, 110), (512, 8, 7, 110)])
+@pytest.mark.parametrize("B,N,n_sample,max_steps", [(4096, 2, 14, 84), (512, 8, 7, 84)])
 def test_auto_reset_episodes_on_one_world(torch_cuda, oracle, lib, B, N, n_sample, max_steps):
     """B = 4096 (N = 2), sampled: 4 consecutive episodes per env (TimeLimit), driving policy with pile-ups; rewards and done every step, the
-    whole state every 55 steps and the proxy ids of every episode equal to the one-world oracle; a fresh-world oracle beside it disagrees."""
+    whole state every 42 steps and the proxy ids of every episode equal to the one-world oracle; a fresh-world oracle beside it disagrees."""
     torch = torch_cuda
     from multi_car_racing_amd.vec_env import VecMultiCarRacing
     seed, episodes = 600 + N, 4
@@ -53,7 +53,8 @@ def test_auto_reset_episodes_on_one_world(torch_cuda, oracle, lib, B, N, n_sampl
     env.reset()
     idx = np.sort(np.random.RandomState(seed).choice(B, n_sample, replace=False)); idx_t = torch.from_numpy(idx).cuda()
     fol = [_Follower(oracle, N, seed, int(g), max_steps) for g in idx]                        # one world per oracle: the reference
-    fresh = [_Follower(oracle, N, seed, int(g), max_steps) for g in idx]                      # rounds 1-5: a fresh world per episode
+    control = N == 2                                                                          # (the negative control doubles the oracle work: one configuration carries it)
+    fresh = [_Follower(oracle, N, seed, int(g), max_steps) for g in idx] if control else []   # rounds 1-5: a fresh world per episode
     for f in fresh: f.o.set_world_mode(0)
     gen = torch.Generator(device="cuda"); gen.manual_seed(seed)
     thr = os.cpu_count() or 1
@@ -63,21 +64,25 @@ def test_auto_reset_episodes_on_one_world(torch_cuda, oracle, lib, B, N, n_sampl
         _, rew, done, _ = env.step(a)
         a_s = a[idx_t].cpu().numpy(); rw = rew[idx_t].cpu().numpy(); dn = done[idx_t].cpu().numpy().astype(bool)
         _, _, o_rew, o_done = oracle.step_batch([f.o for f in fol], a_s, None, threads=thr)
-        _, _, f_rew, f_done = oracle.step_batch([f.o for f in fresh], a_s, None, threads=thr)
+        if control:
+            _, _, f_rew, f_done = oracle.step_batch([f.o for f in fresh], a_s, None, threads=thr)
         ended = []
-        for j, (f, z) in enumerate(zip(fol, fresh)):
-            d, _ = f.after_step(bool(o_done[j])); z.after_step(bool(f_done[j]))
+        for j, f in enumerate(fol):
+            d, _ = f.after_step(bool(o_done[j]))
             assert np.array_equal(o_rew[j], rw[j]), f"step {k} env {f.g}: reward {rw[j]} vs the one-world oracle {o_rew[j]}"
             assert d == dn[j], f"step {k} env {f.g}: done"
-            fresh_reward_differs += int(not np.array_equal(f_rew[j], rw[j]))
+            if control:
+                fresh[j].after_step(bool(f_done[j]))
+                fresh_reward_differs += int(not np.array_equal(f_rew[j], rw[j]))
             contacts += f.o.num_car_contacts() > 0
             if d: ended.append(j)
-        if k % 55 == 54 and not ended:
+        if k % 42 == 41 and not ended:
             _cmp_state(env, fol, idx, f"step {k}")
             st = env.get_state()["bodies"]
             fresh_state_differs += sum(int(not np.array_equal(st[z.g], z.o.state()["bodies"])) for z in fresh)
         for j in ended:
-            fol[j].new_episode(); fresh[j].new_episode()
+            fol[j].new_episode()
+            if control: fresh[j].new_episode()
             tid, fid = fol[j].o.proxy_ids()
             want = np.concatenate([tid, fid.ravel()])
             got = _device_ids(env, lib, fol[j].g)
@@ -87,7 +92,7 @@ def test_auto_reset_episodes_on_one_world(torch_cuda, oracle, lib, B, N, n_sampl
     env.close()
     assert ids_not_ascending >= n_sample, "second and later episodes must draw their ids off the free list"
     assert contacts > 20, "the driving policy produced no car<->car contacts"
-    assert fresh_reward_differs > 0 and fresh_state_differs > 0, "a fresh-world oracle agreed throughout: the test did not exercise the world's ids"
+    assert not control or (fresh_reward_differs > 0 and fresh_state_differs > 0), "a fresh-world oracle agreed throughout: the test did not exercise the world's ids"
 
 
 def test_masked_reset_and_snapshot_keep_the_world(torch_cuda, oracle, lib):

@@ -8,7 +8,8 @@ from multi_car_racing_amd.vec_env import VecMultiCarRacing
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
-kw = dict(seed=77, use_random_direction=True, auto_reset=True, max_episode_steps=250, car_contacts=True, async_refill=False)
+# ASYNC=1: both handles with the native refill service (the default of VecMultiCarRacing) instead of staging inside step()
+kw = dict(seed=77, use_random_direction=True, auto_reset=True, max_episode_steps=250, car_contacts=True, async_refill=bool(int(os.environ.get("ASYNC", "0"))))
 a = VecMultiCarRacing(B, N, streams=2, **kw)
 b = VecMultiCarRacing(B, N, streams=1, **kw)
 print("ordering of the three-chain handle:", a.L.mcr_step_ordering(a.h), "contact pass beside the dynamics:", a.L.mcr_concurrent_collide(a.h))
