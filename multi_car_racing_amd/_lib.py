@@ -3,7 +3,7 @@ import ctypes, os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "_lib", "libmcr_hip.so")
+LIB_PATH = os.environ.get("MCR_LIB_PATH") or os.path.join(HERE, "_lib", "libmcr_hip.so")      # (MCR_LIB_PATH: another build of the same ABI, for A/B measurements)
 
 MAX_AGENTS = 8
 TILE_CAP = 512
