@@ -307,7 +307,7 @@ def main():
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": "k_view", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                    "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": avg_ms, "launches": int(nl[2]), "timed": "every %dth step of the timed region" % TIME_EVERY,
+                    "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": avg_ms, "launches": int(nl[2]), "timed": "every %dth step of the timed region; HIP events that take the dispatch's own begin / end timestamps (hipExtLaunchKernelGGL start / stop events on the launch stream)" % TIME_EVERY,
                     "algorithmic_bytes_per_launch": bytes_per_env_step * main_envs, "envs_per_launch": main_envs}
     if rank == 0:
         out = {

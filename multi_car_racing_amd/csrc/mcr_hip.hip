@@ -351,19 +351,24 @@ static hipEvent_t get_event(mcr_env* h) {
 // a launch of the dynamics over all envs: with or without the contact code (k_dynamics.h)
 #define LAUNCH_DYN(kid_, cc_, grid, st, ...) do { if (cc_) LAUNCH(kid_, k_dynamics<true>, grid, 64, st, __VA_ARGS__); else LAUNCH(kid_, k_dynamics<false>, grid, 64, st, __VA_ARGS__); } while (0)
 
-void mcr_view_launch(int variant, int grid, hipStream_t st, const McrParams& P, unsigned long long* stamps, int only_just_reset, hipEvent_t stop);   // mcr_view.hip
+void mcr_view_launch(int variant, int grid, hipStream_t st, const McrParams& P, unsigned long long* stamps, int only_just_reset, hipEvent_t stop, hipEvent_t start);   // mcr_view.hip
 // raster launch (k_view.h).  Main launches: one workgroup per work slot.  List launches (role >= 2): MCR_LIST_GRID
 // persistent workgroups that walk the list (lane k of a wavefront holds a workgroup's k-th env, so never fewer than
 // slots / 64 workgroups).
 static int list_grid(int slots, int want) { return std::min(slots, std::max(want, (slots + 63) / 64)); }
 static void launch_view(mcr_env* h, int kid, int slots, hipStream_t st, const McrParams& P, int only_just_reset, hipEvent_t stop = nullptr, int want_grid = 0) {
   TimedLaunch tl; const bool tm = (h->timing >> kid) & 1;
-  if (tm) { tl.id = kid; tl.a = get_event(h); tl.b = get_event(h); (void)hipEventRecord(tl.a, st); }
+  // mcr_timing: where the launch has no stop event of the step's own, the two timing events ARE the dispatch's begin / end timestamps
+  // (hipExtLaunchKernelGGL's start and stop events: the kernel's duration as a kernel trace reports it, no marker packets around the launch —
+  // records in front of and behind the launch add the gap to the kernel before it: 85.2 against the trace's 82.6 us, round 6)
+  const bool own_ts = tm && stop == nullptr;
+  hipEvent_t start = nullptr;
+  if (tm) { tl.id = kid; tl.a = get_event(h); tl.b = get_event(h); if (own_ts) { start = tl.a; stop = tl.b; } else (void)hipEventRecord(tl.a, st); }
   // (list launches: with more than two cars per env the contact list is long — N = 8: ~340 envs x 8 views per step — and 128
   // workgroups would draw ~20 views each, one after the other, at the end of the side stream's chain)
-  if (P.role >= 2) { McrParams Q = P; Q.split_views = 1; mcr_view_launch(2, list_grid(slots * (Q.split_views ? P.N : 1), std::max(h->list_view_grid, want_grid)) + Q.flags_blocks, st, Q, h->view_stamps, only_just_reset, stop); }
-  else mcr_view_launch((P.debug & 32) ? 1 : 0, slots, st, P, h->view_stamps, only_just_reset, stop);
-  if (tm) { (void)hipEventRecord(tl.b, st); h->pending.push_back(tl); }
+  if (P.role >= 2) { McrParams Q = P; Q.split_views = 1; mcr_view_launch(2, list_grid(slots * (Q.split_views ? P.N : 1), std::max(h->list_view_grid, want_grid)) + Q.flags_blocks, st, Q, h->view_stamps, only_just_reset, stop, start); }
+  else mcr_view_launch((P.debug & 32) ? 1 : 0, slots, st, P, h->view_stamps, only_just_reset, stop, start);
+  if (tm) { if (!own_ts) (void)hipEventRecord(tl.b, st); h->pending.push_back(tl); }
 }
 
 // reset(): install -> collide(1) -> dynamics(1) -> view, in order on one stream
@@ -848,14 +853,22 @@ extern "C" int mcr_poll_consumed(mcr_env* h, int32_t* env_ids_out, int cap, void
 // RNG states, no bounce buffer (the env's row of the caller's pinned blob array is the staging source).  Host share of a rank: bench.py
 // --emulate-world 8.  The arrays belong to the caller and must outlive the service.
 #include <thread>
+#include <deque>
 #include <condition_variable>
 #include <atomic>
 #include <unistd.h>
 #include <sys/prctl.h>
 extern "C" int mcr_episodes_generate_rows(uint32_t*, uint32_t*, const int32_t*, int, int, int, void*, int32_t*, int);   // mcr_host.cpp
 struct RefillSvc {
-  std::thread th;
-  std::mutex m;                        // one refill cycle at a time (the thread's, or a caller's inside mcr_refill_wait)
+  std::thread th;                      // polls the counters, hands env ids to the generators, stages what they finished
+  std::vector<std::thread> gens;       // generator threads: one track at a time each, off a queue — AWAKE while there is work (they poll with
+                                       // short sleeps and back off when idle): a batch handed to sleeping helpers through a condition variable
+                                       // cost the wake-up latency of the slowest helper per batch, and when the helpers woke late the calling
+                                       // thread generated every track itself, 0.1 ms each against 4 consumptions per 0.22 ms step — a 20-step
+                                       // bench run then ended with 8 ms of host backlog (round 6, profiles/r06_driver_style_runs.txt)
+  std::mutex m;                        // one service cycle at a time (the thread's, or a caller's inside mcr_refill_wait)
+  std::mutex qm;                       // todo / done / inflight
+  std::deque<int32_t> todo; std::vector<int32_t> done; int inflight = 0;
   std::atomic<bool> stop{false}, hold{false};
   uint32_t* mt_track; uint32_t* mt_draw; int direction_mode, gen_threads;
   uint8_t* blobs; int32_t* info;
@@ -865,7 +878,32 @@ struct RefillSvc {
   std::atomic<int32_t> pending_since{0}; std::atomic<bool> pending{false};
   std::atomic<int> err{0}; std::string err_msg;
 };
-// one cycle: returns the number of episodes staged (< 0: error, message in s->err_msg).  Caller holds s->m.
+// one track: env e's next episode from ITS rows of the caller's arrays (mcr_host.cpp; num_threads 1: on this thread)
+static bool refill_generate_one(mcr_env* h, RefillSvc* s, int32_t e) {
+  const int rc = mcr_episodes_generate_rows(s->mt_track, s->mt_draw, &e, 1, h->cfg.num_agents, s->direction_mode, s->blobs, s->info, 1);
+  if (rc != MCR_OK) { std::lock_guard<std::mutex> lk(s->qm); s->err_msg = "track generation failed (capacity: MCR_TILE_CAP / MCR_QUAD_CAP)"; s->err.store(rc); return false; }
+  return true;
+}
+// take one env off the queue and generate its track; false: nothing to do
+static bool refill_work_one(mcr_env* h, RefillSvc* s) {
+  int32_t e = -1;
+  { std::lock_guard<std::mutex> lk(s->qm); if (!s->todo.empty()) { e = s->todo.front(); s->todo.pop_front(); ++s->inflight; } }
+  if (e < 0) return false;
+  const bool ok = refill_generate_one(h, s, e);
+  { std::lock_guard<std::mutex> lk(s->qm); --s->inflight; if (ok) s->done.push_back(e); }
+  return true;
+}
+static void refill_gen_main(mcr_env* h, RefillSvc* s) {
+  (void)prctl(PR_SET_NAME, "mcr-gen", 0, 0, 0);
+  int idle = 0;
+  while (!s->stop.load()) {
+    if (refill_work_one(h, s)) { idle = 0; continue; }
+    ++idle;
+    usleep(idle < 400 ? 50 : 500);     // (20 ms without work: an idle env costs its generators next to nothing)
+  }
+}
+// one cycle of the service: new consumptions -> the generators' queue; finished tracks -> their envs' staged slots.  Returns what is still
+// pending afterwards (queued + being generated + consumptions not yet seen: 0 = all caught up), < 0: error.  Caller holds s->m.
 static int refill_cycle(mcr_env* h, RefillSvc* s) {
   const int B = h->cfg.num_envs;
   int n = 0;
@@ -873,36 +911,48 @@ static int refill_cycle(mcr_env* h, RefillSvc* s) {
     const int32_t c = ((volatile int32_t*)h->consumed_host)[e];
     if (c != h->consumed_seen[e]) { h->consumed_seen[e] = c; s->ids[n++] = e; }
   }
-  if (n == 0) return 0;
-  if (!s->pending.exchange(true)) s->pending_since.store(h->step_count);
-  int rc = mcr_episodes_generate_rows(s->mt_track, s->mt_draw, s->ids.data(), n, h->cfg.num_agents, s->direction_mode, s->blobs, s->info, s->gen_threads);
-  if (rc != MCR_OK) { s->err_msg = "track generation failed (capacity: MCR_TILE_CAP / MCR_QUAD_CAP)"; s->err.store(rc); return rc; }
-  auto fail = [&](const char* what, hipError_t e) { s->err_msg = std::string(what) + ": " + hipGetErrorString(e); s->err.store(MCR_ERR_HIP); return (int)MCR_ERR_HIP; };
-  for (int i = 0; i < n; ++i) {
-    const int e = s->ids[i];
-    const int32_t installs = ((volatile int32_t*)h->consumed_host)[e];
-    uint8_t* dst = h->P.slots + ((size_t)e * 2 + ((installs & 1) ^ 1)) * MCR_SLOT_BYTES;
-    const hipError_t er = hipMemcpyAsync(dst, s->blobs + (size_t)e * MCR_SLOT_BYTES, MCR_SLOT_BYTES, hipMemcpyHostToDevice, s->st);
-    if (er != hipSuccess) return fail("hipMemcpyAsync (episode)", er);
+  int m = 0, left = 0;
+  {
+    std::lock_guard<std::mutex> lk(s->qm);
+    for (int i = 0; i < n; ++i) s->todo.push_back(s->ids[i]);
+    m = (int)s->done.size();
+    for (int i = 0; i < m; ++i) s->ids[i] = s->done[i];
+    s->done.clear();
+    left = (int)s->todo.size() + s->inflight;
   }
-  hipError_t er = hipMemcpyAsync(h->stage_ids, s->ids.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s->st);
-  if (er != hipSuccess) return fail("hipMemcpyAsync (ids)", er);
-  hipLaunchKernelGGL(k_mark_staged, dim3((n + 255) / 256), dim3(256), 0, s->st, h->P, (const int32_t*)h->stage_ids, n);
-  if ((er = hipEventRecord(s->ev, s->st)) != hipSuccess) return fail("hipEventRecord", er);
-  // (polled with a sleep in between: hipEventSynchronize / hipStreamSynchronize spin on this runtime — 0.8 of a core, measured in round 3 —
-  // and a spinning thread takes a core from the track generator where the ranks of a node share few)
-  for (;;) { er = hipEventQuery(s->ev); if (er == hipSuccess) break; if (er != hipErrorNotReady) return fail("hipEventQuery", er); usleep(40); }
-  s->generated.fetch_add(n);
-  s->pending.store(false);
-  return n;
+  if (n > 0 && !s->pending.exchange(true)) s->pending_since.store(h->step_count);
+  if (s->err.load()) return s->err.load();
+  if (m > 0) {
+    auto fail = [&](const char* what, hipError_t e) { s->err_msg = std::string(what) + ": " + hipGetErrorString(e); s->err.store(MCR_ERR_HIP); return (int)MCR_ERR_HIP; };
+    for (int i = 0; i < m; ++i) {
+      const int e = s->ids[i];
+      const int32_t installs = ((volatile int32_t*)h->consumed_host)[e];
+      uint8_t* dst = h->P.slots + ((size_t)e * 2 + ((installs & 1) ^ 1)) * MCR_SLOT_BYTES;
+      const hipError_t er = hipMemcpyAsync(dst, s->blobs + (size_t)e * MCR_SLOT_BYTES, MCR_SLOT_BYTES, hipMemcpyHostToDevice, s->st);
+      if (er != hipSuccess) return fail("hipMemcpyAsync (episode)", er);
+    }
+    hipError_t er = hipMemcpyAsync(h->stage_ids, s->ids.data(), sizeof(int32_t) * (size_t)m, hipMemcpyHostToDevice, s->st);
+    if (er != hipSuccess) return fail("hipMemcpyAsync (ids)", er);
+    hipLaunchKernelGGL(k_mark_staged, dim3((m + 255) / 256), dim3(256), 0, s->st, h->P, (const int32_t*)h->stage_ids, m);
+    if ((er = hipEventRecord(s->ev, s->st)) != hipSuccess) return fail("hipEventRecord", er);
+    // (polled with a sleep in between: hipEventSynchronize / hipStreamSynchronize spin on this runtime — 0.8 of a core, measured in round 3 —
+    // and a spinning thread takes a core from the track generators where the ranks of a node share few)
+    for (;;) { er = hipEventQuery(s->ev); if (er == hipSuccess) break; if (er != hipErrorNotReady) return fail("hipEventQuery", er); usleep(30); }
+    s->generated.fetch_add(m);
+  }
+  if (left == 0 && n == 0) {           // nothing queued, nothing in flight, nothing new: caught up (a track that finished meanwhile shows up in `done` next cycle)
+    std::lock_guard<std::mutex> lk(s->qm);
+    if (s->todo.empty() && s->inflight == 0 && s->done.empty()) s->pending.store(false);
+    else left = 1;
+  }
+  return left;
 }
 static void refill_main(mcr_env* h, RefillSvc* s) {
   (void)prctl(PR_SET_NAME, "mcr-refill", 0, 0, 0);
   (void)hipSetDevice(h->cfg.device);
   while (!s->stop.load()) {
-    int n = 0;
-    if (!s->hold.load() && s->err.load() == 0) { std::lock_guard<std::mutex> lk(s->m); n = refill_cycle(h, s); }
-    if (n <= 0) usleep(150);           // (a step takes 0.2 ms and an env needs hundreds of steps to end its next episode: nothing is urgent here)
+    if (!s->hold.load() && s->err.load() == 0) { std::lock_guard<std::mutex> lk(s->m); (void)refill_cycle(h, s); }
+    usleep(100);                       // (a step takes 0.2 ms and an env needs hundreds of steps to end its next episode: nothing is urgent here)
   }
 }
 extern "C" int mcr_refill_start(mcr_env* h, uint32_t* mt_track, uint32_t* mt_draw, int direction_mode, int gen_threads, void* blobs_pinned, int32_t* episode_info) {
@@ -915,6 +965,8 @@ extern "C" int mcr_refill_start(mcr_env* h, uint32_t* mt_track, uint32_t* mt_dra
   if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) != hipSuccess) { delete s; g_err = "mcr_refill_start: stream / event"; return MCR_ERR_HIP; }
   h->svc = s;
   s->th = std::thread(refill_main, h, s);
+  const int ngen = std::max(1, std::min(s->gen_threads, 6));       // (19 k tracks/s at B = 4096, N = 2 are two of them busy; 30 k at B = 32768 three)
+  for (int i = 0; i < ngen; ++i) s->gens.emplace_back(refill_gen_main, h, s);
   return MCR_OK;
 }
 extern "C" int mcr_refill_stop(mcr_env* h) {
@@ -923,6 +975,7 @@ extern "C" int mcr_refill_stop(mcr_env* h) {
   if (!s) return MCR_OK;
   s->stop.store(true);
   if (s->th.joinable()) s->th.join();
+  for (auto& g : s->gens) if (g.joinable()) g.join();
   (void)hipSetDevice(h->cfg.device);
   (void)hipStreamSynchronize(s->st);
   (void)hipStreamDestroy(s->st); (void)hipEventDestroy(s->ev);
@@ -940,7 +993,12 @@ extern "C" int mcr_refill_wait(mcr_env* h) {
   if (s->hold.load()) return MCR_OK;
   HIPCHK(hipSetDevice(h->cfg.device));
   std::lock_guard<std::mutex> lk(s->m);
-  for (;;) { const int n = refill_cycle(h, s); if (n < 0) { g_err = "the refill service failed: " + s->err_msg; return n; } if (n == 0) break; }
+  for (;;) {
+    const int left = refill_cycle(h, s);
+    if (left < 0) { g_err = "the refill service failed: " + s->err_msg; return left; }
+    if (left == 0) break;
+    if (!refill_work_one(h, s)) usleep(20);       // the waiting thread generates too: progress does not depend on how fast a sleeping generator wakes
+  }
   return MCR_OK;
 }
 // steps launched since the oldest consumption that is not staged yet was noticed (0: nothing pending); < 0: the service failed

@@ -12,8 +12,9 @@
 // variant: 0 main launch, 1 main launch with the per-phase clocks (debug bit 5), 2 list launch (persistent workgroups that walk a list)
 // stop: an event the launch itself completes (hipExtLaunchKernelGGL: the dispatch packet's completion signal — no marker packet
 // behind the kernel, which costs ~3 us in-stream and ~3.5 us more on a stream hop; tools/ubench/event_gap.hip), or nullptr
-void mcr_view_launch(int variant, int grid, hipStream_t st, const McrParams& P, unsigned long long* stamps, int only_just_reset, hipEvent_t stop) {
-  if (variant == 2) hipExtLaunchKernelGGL((k_view<false, true>), dim3(grid), dim3(VIEW_THREADS), 0, st, nullptr, stop, 0, P, stamps, only_just_reset);
-  else if (variant == 1) hipExtLaunchKernelGGL((k_view<true, false>), dim3(grid), dim3(VIEW_THREADS), 0, st, nullptr, stop, 0, P, stamps, only_just_reset);
-  else hipExtLaunchKernelGGL((k_view<false, false>), dim3(grid), dim3(VIEW_THREADS), 0, st, nullptr, stop, 0, P, stamps, only_just_reset);
+// start: an event that takes the dispatch's own BEGIN timestamp (with `stop`: the kernel's duration as the profiler sees it — mcr_timing), or nullptr
+void mcr_view_launch(int variant, int grid, hipStream_t st, const McrParams& P, unsigned long long* stamps, int only_just_reset, hipEvent_t stop, hipEvent_t start) {
+  if (variant == 2) hipExtLaunchKernelGGL((k_view<false, true>), dim3(grid), dim3(VIEW_THREADS), 0, st, start, stop, 0, P, stamps, only_just_reset);
+  else if (variant == 1) hipExtLaunchKernelGGL((k_view<true, false>), dim3(grid), dim3(VIEW_THREADS), 0, st, start, stop, 0, P, stamps, only_just_reset);
+  else hipExtLaunchKernelGGL((k_view<false, false>), dim3(grid), dim3(VIEW_THREADS), 0, st, start, stop, 0, P, stamps, only_just_reset);
 }
