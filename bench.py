@@ -263,11 +263,18 @@ def main():
                     time.sleep(1e-4)                #  that the track generator needs when a rank has two of them — query + sleep: 0.02)
             evs[j].record()
     torch.cuda.synchronize()
+    t_gpu_done = time.perf_counter()
     env.wait_refills()
+    closing_wait = time.perf_counter() - t_gpu_done      # the host's last tracks: the window is charged with every track its own resets consumed
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    closing_detail = None
+    if args.refill == "native":
+        dbg = np.zeros(8, np.int64)
+        if env.env.L.mcr_refill_debug(env.env.h, dbg.ctypes.data_as(ctypes.c_void_p)) == 0:
+            closing_detail = dict(zip(("queued", "in_flight", "done_unstaged", "cycles", "generated_by_waiter", "us_in_cycles", "us_total", "generator_threads"), (int(v) for v in dbg)))
     host_cores = (time.process_time() - cpu0) / elapsed
     thr1 = thread_cpu()
     me = str(threading.get_native_id())
@@ -330,6 +337,9 @@ def main():
             "roofline": roofline,
         }
         out["config"]["step_blocked_on_refill_s_rank0"] = env.env.blocked_s - blocked0
+        out["config"]["closing_wait_for_host_tracks_ms_rank0"] = round(closing_wait * 1e3, 3)
+        if closing_detail is not None:
+            out["config"]["closing_wait_detail_rank0"] = closing_detail
         out["config"]["host_threads_busy_rank0"] = host_threads               # by thread name (python = the step loop and the refill thread)
         out["config"]["host_cores_busy_rank0"] = round(host_cores, 2)      # CPU time / wall time of the timed region: what one rank asks of the host
         out["config"]["stream_ordering"] = {1: "phase words", 3: "phase words", 2: "events (stop events)", 0: "events", 4: "events (queues shared with another handle)", 6: "events (stop events; queues shared with another handle)"}.get(int(env.env.L.mcr_step_ordering_for(env.env.h, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))), "?") if args.streams != 1 else "single stream"

@@ -171,6 +171,9 @@ int mcr_refill_wait(mcr_env* h);
 int mcr_refill_lag(mcr_env* h);
 int mcr_refill_hold(mcr_env* h, int hold);
 long long mcr_refill_generated(mcr_env* h);
+/* diagnostics of the last mcr_refill_wait: tracks queued / being generated / finished-but-unstaged at entry, service cycles run, tracks the waiting
+ * thread generated itself, microseconds inside the cycles (polling + staging), microseconds in total, generator threads */
+int mcr_refill_debug(mcr_env* h, long long* out8);
 
 /* ---- state access for differential tests / facade attributes (synchronous) */
 /* bodies [B,N,5,6] f32 (c.x c.y angle v.x v.y w; body 0 hull, 1..4 wheels FL FR RL RR)

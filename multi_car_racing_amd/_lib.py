@@ -47,6 +47,7 @@ SYMBOLS = {
     "mcr_refill_lag": (_i, [_vp]),
     "mcr_refill_hold": (_i, [_vp, _i]),
     "mcr_refill_generated": (ctypes.c_longlong, [_vp]),
+    "mcr_refill_debug": (_i, [_vp, _vp]),
     "mcr_get_state": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mcr_set_bodies": (_i, [_vp, _vp]),
     "mcr_get_env_state": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

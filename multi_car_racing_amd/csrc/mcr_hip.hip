@@ -492,6 +492,11 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     P.soft_sync = 1;
     const int lg_flags = std::min(B * N, (N <= 2 ? 4 : 32) * MCR_LIST_GRID);
     if (!cc) LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), st, P, 0);
+    // The step's critical kernel goes out FIRST (round 6): everything the other two streams run in this step waits for a word the dynamics posts
+    // (BEGIN from its first thread), so the order of enqueueing across the streams is free — and behind a host synchronisation (an RL loop
+    // reads its observations every step) the seven launches that used to precede it cost the step their enqueue time, ~45 us.
+    const int vif = (view_flags && draw && h->viewprep_in_flags) ? 1 : 0;
+    { McrParams Pd = P; Pd.split = 0; Pd.role = 1; Pd.post_dyn = h->post_dyn ? 1 : 0; Pd.viewprep_in_flags = vif; LAUNCH(1, k_dynamics<false>, dyn_blocks, 64, st, Pd, 0); }          // (the main envs: no touching car<->car pair)
     hipLaunchKernelGGL(k_await, dim3(1), dim3(64), 0, h->s_side, P, (int)W_BEGIN, -1);
     if (cc && !P.fuse_collide) LAUNCH_LDS(0, k_collide, B, 64, col::lds_bytes(N), h->s_side, P, 0);     // (W_COL: posted by the chain that follows)
     if (cc && P.fuse_collide) {
@@ -518,11 +523,8 @@ static void launch_step(mcr_env* h, McrParams P, hipStream_t st, int view_flags)
     if (draw) { McrParams Pv = P; Pv.flags_blocks = fiv_c; launch_view(h, 6, P.term_cnt ? 2 * B : B, h->s_side, Pv, 0, nullptr, vg_c); }
     hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, h->s_side, P, (int)W_SIDE);
     P.role = 1;
-    P.post_dyn = h->post_dyn ? 1 : 0;
-    P.viewprep_in_flags = (view_flags && draw && h->viewprep_in_flags) ? 1 : 0;
+    P.viewprep_in_flags = vif;
     const bool flags_on_caller = view_flags && draw && !P.viewprep_in_flags && N <= 7;   // (N = 8: the raster would share the machine with the bookkeeping: 6.70 -> 6.49 M env-steps/s, round 5)
-    LAUNCH(1, k_dynamics<false>, dyn_blocks, 64, st, P, 0);          // (the main envs: no touching car<->car pair)
-    P.post_dyn = 0;
     P.role = 3;
     {
       const int ga = std::min(lg_dyn, MCR_LIST_GRID / 2), gb = P.auto_reset ? lg_col : 0;
@@ -877,6 +879,7 @@ struct RefillSvc {
   std::atomic<long long> generated{0};
   std::atomic<int32_t> pending_since{0}; std::atomic<bool> pending{false};
   std::atomic<int> err{0}; std::string err_msg;
+  long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // last mcr_refill_wait: queued / in flight / done at entry, cycles, tracks the waiter generated, us staging, us total, generator threads
 };
 // one track: env e's next episode from ITS rows of the caller's arrays (mcr_host.cpp; num_threads 1: on this thread)
 static bool refill_generate_one(mcr_env* h, RefillSvc* s, int32_t e) {
@@ -904,7 +907,7 @@ static void refill_gen_main(mcr_env* h, RefillSvc* s) {
 }
 // one cycle of the service: new consumptions -> the generators' queue; finished tracks -> their envs' staged slots.  Returns what is still
 // pending afterwards (queued + being generated + consumptions not yet seen: 0 = all caught up), < 0: error.  Caller holds s->m.
-static int refill_cycle(mcr_env* h, RefillSvc* s) {
+static int refill_cycle(mcr_env* h, RefillSvc* s, bool urgent = false) {
   const int B = h->cfg.num_envs;
   int n = 0;
   for (int e = 0; e < B; ++e) {
@@ -937,7 +940,8 @@ static int refill_cycle(mcr_env* h, RefillSvc* s) {
     if ((er = hipEventRecord(s->ev, s->st)) != hipSuccess) return fail("hipEventRecord", er);
     // (polled with a sleep in between: hipEventSynchronize / hipStreamSynchronize spin on this runtime — 0.8 of a core, measured in round 3 —
     // and a spinning thread takes a core from the track generators where the ranks of a node share few)
-    for (;;) { er = hipEventQuery(s->ev); if (er == hipSuccess) break; if (er != hipErrorNotReady) return fail("hipEventQuery", er); usleep(30); }
+    // (urgent — a caller waits in mcr_refill_wait: poll without sleeping for the first 100 us; the copies are 0.1 MB each)
+    for (int spins = 0;; ++spins) { er = hipEventQuery(s->ev); if (er == hipSuccess) break; if (er != hipErrorNotReady) return fail("hipEventQuery", er); if (!urgent || spins > 2000) usleep(30); }
     s->generated.fetch_add(m);
   }
   if (left == 0 && n == 0) {           // nothing queued, nothing in flight, nothing new: caught up (a track that finished meanwhile shows up in `done` next cycle)
@@ -992,13 +996,20 @@ extern "C" int mcr_refill_wait(mcr_env* h) {
   if (s->err.load()) { g_err = "the refill service failed: " + s->err_msg; return s->err.load(); }
   if (s->hold.load()) return MCR_OK;
   HIPCHK(hipSetDevice(h->cfg.device));
+  timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+  auto us_since = [&](const timespec& a) { timespec b; clock_gettime(CLOCK_MONOTONIC, &b); return (long long)((b.tv_sec - a.tv_sec) * 1000000ll + (b.tv_nsec - a.tv_nsec) / 1000); };
   std::lock_guard<std::mutex> lk(s->m);
+  { std::lock_guard<std::mutex> q(s->qm); s->dbg[0] = (long long)s->todo.size(); s->dbg[1] = s->inflight; s->dbg[2] = (long long)s->done.size(); }
+  s->dbg[3] = s->dbg[4] = s->dbg[5] = 0; s->dbg[7] = (long long)s->gens.size();
   for (;;) {
-    const int left = refill_cycle(h, s);
+    timespec tc; clock_gettime(CLOCK_MONOTONIC, &tc);
+    const int left = refill_cycle(h, s, true);
+    s->dbg[5] += us_since(tc); ++s->dbg[3];
     if (left < 0) { g_err = "the refill service failed: " + s->err_msg; return left; }
     if (left == 0) break;
-    if (!refill_work_one(h, s)) usleep(20);       // the waiting thread generates too: progress does not depend on how fast a sleeping generator wakes
+    if (refill_work_one(h, s)) ++s->dbg[4]; else usleep(10);       // the waiting thread generates too: progress does not depend on how fast a sleeping generator wakes
   }
+  s->dbg[6] = us_since(t0);
   return MCR_OK;
 }
 // steps launched since the oldest consumption that is not staged yet was noticed (0: nothing pending); < 0: the service failed
@@ -1008,6 +1019,7 @@ extern "C" int mcr_refill_lag(mcr_env* h) {
   if (s->err.load()) { g_err = "the refill service failed: " + s->err_msg; return s->err.load(); }
   return s->pending.load() ? std::max(0, (int32_t)((uint32_t)h->step_count - (uint32_t)s->pending_since.load())) : 0;
 }
+extern "C" int mcr_refill_debug(mcr_env* h, long long* out8) { if (!h || !h->svc || !out8) return MCR_ERR_STATE; for (int i = 0; i < 8; ++i) out8[i] = h->svc->dbg[i]; return MCR_OK; }
 extern "C" int mcr_refill_hold(mcr_env* h, int hold) { if (!h || !h->svc) return MCR_ERR_STATE; h->svc->hold.store(hold != 0); return MCR_OK; }
 extern "C" long long mcr_refill_generated(mcr_env* h) { return (h && h->svc) ? h->svc->generated.load() : 0; }
 
