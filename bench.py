@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--terminal-obs", type=int, default=0, help="1: also hand out the last frame of every episode that ends (info['terminal_observation'], include/mcr.h: mcr_set_terminal_obs)")
     ap.add_argument("--refill", choices=["native", "python"], default="native", help="native (default): the handle's own host thread polls, generates and stages the "
                     "consumed episodes (include/mcr.h: mcr_refill_start); python: rounds 2-5's worker thread in vec_env.py")
+    ap.add_argument("--sync-every", type=int, default=0, help="S > 0: the stepping loop synchronises its stream after every S-th step (S = 1: an RL loop that reads its "
+                    "observations before it picks the next actions) instead of running up to 16 steps ahead of the GPU; not the headline's loop")
     ap.add_argument("--fresh-world", type=int, default=0, help="0 (default): ONE b2World per env across its episodes, as the reference keeps it (csrc/k_world.h); "
                     "1: every episode the first of a fresh world (rounds 1-5's definition)")
     ap.add_argument("--graph", type=int, default=0, help="1: mcr_step replays a hipGraph of the step (bypassed while kernels are timed; measured gain 0.4 %%); 0 (default): plain launches")
@@ -256,6 +258,8 @@ def main():
         if tmask:
             env.timing(tmask if k % TIME_EVERY == 0 else 0)
         env.step(next_actions())
+        if args.sync_every > 0 and k % args.sync_every == args.sync_every - 1:
+            torch.cuda.current_stream().synchronize()
         if k % FENCE == FENCE - 1:
             j = (k // FENCE) % 4
             if k >= LOOKAHEAD:
@@ -331,6 +335,7 @@ def main():
                        "touch_verdict_mismatches_rank0": env.env.verdict_mismatches(),
                        "status_words_rank0": {k: int(v) for k, v in zip(("waits_given_up", "verdict_mismatches", "manifold_overflows", "event_overflows", "envs_frozen"), env.env.status_words()[:5])},
                        "contact_pass_beside_dynamics": bool(env.env.L.mcr_concurrent_collide(env.env.h)),
+                       "stepping_loop": ("synchronised every %d step(s)" % args.sync_every) if args.sync_every > 0 else "free-running, at most 16 steps ahead of the GPU",
                        "world": "fresh world per episode (rounds 1-5)" if args.fresh_world else "one b2World per env across its episodes (the reference; csrc/k_world.h)",
                        "contact_envs_per_step_rank0": float(env.env.debug_counters()[2] - ctr0[2]) / K,
                        "deferred_envs_per_step_rank0": float(env.env.debug_counters()[0] - ctr0[0]) / K},
