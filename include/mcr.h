@@ -155,7 +155,8 @@ int mcr_set_step_graph(mcr_env* h, int enable);
  * synchronisation, `stream` is unused; an install whose kernel has not finished yet shows up in a later poll.
  * Writes up to `cap` env ids; returns the count (>=0) or an error. */
 int mcr_poll_consumed(mcr_env* h, int32_t* env_ids_out, int cap, void* stream);
-/* The refill service: ONE host thread owned by the handle does what a stepping loop would do with the three calls above after every step —
+/* The refill service: host threads owned by the handle (one service thread + up to min(gen_threads, 6) generator threads that stay awake while
+ * there is work) do what a stepping loop would do with the three calls above after every step —
  * poll the consumed-episode counters, generate the next episode of every env that re-spawned from ITS rows of the caller's RNG-state arrays
  * (mt_track / mt_draw [num_envs][MCR_MT_WORDS], advanced in place), write the blob into ITS row of blobs_pinned [num_envs][mcr_episode_bytes()]
  * (page-locked host memory: the staging source) and episode_info [num_envs][12] (T, P, retries, cw, car_order[8]; may be NULL), stage it.

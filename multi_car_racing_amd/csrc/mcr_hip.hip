@@ -851,9 +851,10 @@ extern "C" int mcr_poll_consumed(mcr_env* h, int32_t* env_ids_out, int cap, void
 
 // ---------------------------------------------------------------------------- the refill service
 // What VecMultiCarRacing's Python worker did every step — poll the consumed-episode counters, generate the next episode of every env that
-// re-spawned (its own RNG streams), stage it — as ONE native thread of the handle: no interpreter, no GIL hand-offs, no gather / scatter of
-// RNG states, no bounce buffer (the env's row of the caller's pinned blob array is the staging source).  Host share of a rank: bench.py
-// --emulate-world 8.  The arrays belong to the caller and must outlive the service.
+// re-spawned (its own RNG streams), stage it — as native threads of the handle: a service thread (polls, queues env ids, stages finished
+// tracks) and up to six generator threads (one track at a time off the queue).  No interpreter, no GIL hand-offs, no gather / scatter of RNG
+// states, no bounce buffer (the env's row of the caller's pinned blob array is the staging source), no condition variable or per-batch barrier
+// on the path.  Host share of a rank: bench.py --emulate-world 8.  The arrays belong to the caller and must outlive the service.
 #include <thread>
 #include <deque>
 #include <condition_variable>
@@ -877,7 +878,9 @@ struct RefillSvc {
   hipStream_t st = nullptr; hipEvent_t ev = nullptr;
   std::vector<int32_t> ids;
   std::atomic<long long> generated{0};
-  std::atomic<int32_t> pending_since{0}; std::atomic<bool> pending{false};
+  // the age of the oldest consumption that is not staged yet (mcr_refill_lag): consumptions are served first in, first out — near enough —, so the
+  // oldest unserved one is the `staged`-th to arrive; seen_step[k % size] = the step count when the k-th was noticed
+  std::vector<int32_t> seen_step; std::atomic<long long> arrived{0}, staged{0};
   std::atomic<int> err{0}; std::string err_msg;
   long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // last mcr_refill_wait: queued / in flight / done at entry, cycles, tracks the waiter generated, us staging, us total, generator threads
 };
@@ -923,7 +926,7 @@ static int refill_cycle(mcr_env* h, RefillSvc* s, bool urgent = false) {
     s->done.clear();
     left = (int)s->todo.size() + s->inflight;
   }
-  if (n > 0 && !s->pending.exchange(true)) s->pending_since.store(h->step_count);
+  { const long long a0 = s->arrived.load(); for (int i = 0; i < n; ++i) s->seen_step[(size_t)((a0 + i) % (long long)s->seen_step.size())] = h->step_count; s->arrived.store(a0 + n); }
   if (s->err.load()) return s->err.load();
   if (m > 0) {
     auto fail = [&](const char* what, hipError_t e) { s->err_msg = std::string(what) + ": " + hipGetErrorString(e); s->err.store(MCR_ERR_HIP); return (int)MCR_ERR_HIP; };
@@ -943,11 +946,11 @@ static int refill_cycle(mcr_env* h, RefillSvc* s, bool urgent = false) {
     // (urgent — a caller waits in mcr_refill_wait: poll without sleeping for the first 100 us; the copies are 0.1 MB each)
     for (int spins = 0;; ++spins) { er = hipEventQuery(s->ev); if (er == hipSuccess) break; if (er != hipErrorNotReady) return fail("hipEventQuery", er); if (!urgent || spins > 2000) usleep(30); }
     s->generated.fetch_add(m);
+    s->staged.fetch_add(m);
   }
-  if (left == 0 && n == 0) {           // nothing queued, nothing in flight, nothing new: caught up (a track that finished meanwhile shows up in `done` next cycle)
+  if (left == 0) {                     // nothing queued, nothing in flight — unless a track finished meanwhile (it shows up in `done` next cycle)
     std::lock_guard<std::mutex> lk(s->qm);
-    if (s->todo.empty() && s->inflight == 0 && s->done.empty()) s->pending.store(false);
-    else left = 1;
+    if (!(s->todo.empty() && s->inflight == 0 && s->done.empty())) left = 1;
   }
   return left;
 }
@@ -965,7 +968,7 @@ extern "C" int mcr_refill_start(mcr_env* h, uint32_t* mt_track, uint32_t* mt_dra
   HIPCHK(hipSetDevice(h->cfg.device));
   RefillSvc* s = new RefillSvc();
   s->mt_track = mt_track; s->mt_draw = mt_draw; s->direction_mode = direction_mode; s->gen_threads = std::max(1, gen_threads);
-  s->blobs = (uint8_t*)blobs_pinned; s->info = episode_info; s->ids.resize(h->cfg.num_envs);
+  s->blobs = (uint8_t*)blobs_pinned; s->info = episode_info; s->ids.resize(h->cfg.num_envs); s->seen_step.assign((size_t)h->cfg.num_envs * 2, 0);
   if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) != hipSuccess) { delete s; g_err = "mcr_refill_start: stream / event"; return MCR_ERR_HIP; }
   h->svc = s;
   s->th = std::thread(refill_main, h, s);
@@ -1017,7 +1020,9 @@ extern "C" int mcr_refill_lag(mcr_env* h) {
   if (!h || !h->svc) return 0;
   RefillSvc* s = h->svc;
   if (s->err.load()) { g_err = "the refill service failed: " + s->err_msg; return s->err.load(); }
-  return s->pending.load() ? std::max(0, (int32_t)((uint32_t)h->step_count - (uint32_t)s->pending_since.load())) : 0;
+  const long long st = s->staged.load(), ar = s->arrived.load();
+  if (st >= ar) return 0;
+  return std::max(0, (int32_t)((uint32_t)h->step_count - (uint32_t)s->seen_step[(size_t)(st % (long long)s->seen_step.size())]));
 }
 extern "C" int mcr_refill_debug(mcr_env* h, long long* out8) { if (!h || !h->svc || !out8) return MCR_ERR_STATE; for (int i = 0; i < 8; ++i) out8[i] = h->svc->dbg[i]; return MCR_OK; }
 extern "C" int mcr_refill_hold(mcr_env* h, int hold) { if (!h || !h->svc) return MCR_ERR_STATE; h->svc->hold.store(hold != 0); return MCR_OK; }
