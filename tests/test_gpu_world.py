@@ -135,3 +135,37 @@ def test_masked_reset_and_snapshot_keep_the_world(torch_cuda, oracle, lib):
     assert L.mcr_set_state_blob(env.h, 0, lib.ptr(blob)) == 0
     assert np.array_equal(_device_ids(env, lib, 0), ids_before)
     env.close()
+
+
+def test_fresh_world_switch_is_rounds_1_to_5_definition(torch_cuda, oracle):
+    """mcr_config::fresh_world = 1 (VecMultiCarRacing(fresh_world=True)): every episode the first episode of a fresh world — the oracle's world
+    mode 0 — over three auto-reset episodes with touching cars; the default handle beside it (one world) follows the mode-1 oracle, and the two
+    handles differ from each other from the second episode on."""
+    torch = torch_cuda
+    from multi_car_racing_amd.vec_env import VecMultiCarRacing
+    B, N, seed, L = 12, 2, 1234, 60
+    kw = dict(seed=seed, use_random_direction=True, auto_reset=True, max_episode_steps=L, car_contacts=True, async_refill=False, streams=2, obs=False)
+    fresh, one = VecMultiCarRacing(B, N, fresh_world=True, **kw), VecMultiCarRacing(B, N, **kw)
+    fresh.reset(); one.reset()
+    f0 = [_Follower(oracle, N, seed, g, L) for g in range(B)]
+    for f in f0: f.o.set_world_mode(0)
+    f1 = [_Follower(oracle, N, seed, g, L) for g in range(B)]
+    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+    handles_differ = 0
+    for k in range(3 * L):
+        a = _drive(torch, gen, B, N, k, L)
+        _, r0, d0, _ = fresh.step(a); _, r1, d1, _ = one.step(a)
+        an = a.cpu().numpy()
+        _, _, o0, od0 = oracle.step_batch([f.o for f in f0], an, None, threads=4)
+        _, _, o1, od1 = oracle.step_batch([f.o for f in f1], an, None, threads=4)
+        assert np.array_equal(o0, r0.cpu().numpy()), f"step {k}: fresh-world handle vs the mode-0 oracle"
+        assert np.array_equal(o1, r1.cpu().numpy()), f"step {k}: one-world handle vs the mode-1 oracle"
+        handles_differ += int(not torch.equal(r0, r1))
+        for j in range(B):
+            e0, _ = f0[j].after_step(bool(od0[j])); e1, _ = f1[j].after_step(bool(od1[j]))
+            assert e0 == bool(d0[j].item()) and e1 == bool(d1[j].item())
+            if e0: f0[j].new_episode()
+            if e1: f1[j].new_episode()
+    _cmp_state(fresh, f0, np.arange(B), "fresh-world handle, end"); _cmp_state(one, f1, np.arange(B), "one-world handle, end")
+    assert handles_differ > 0, "the two definitions never disagreed: the rollout did not exercise the ids"
+    fresh.close(); one.close()
