@@ -92,14 +92,17 @@ int mcr_episode_unpack(const void* blob, int32_t* T, int32_t* P, int32_t* cw, do
                        float* quads /*[P*8]*/, uint32_t* quad_meta /*[P]*/, double* spawn /*[8*3]*/,
                        double* track_alpha /*[T]*/);
 
-/* ---- the env's b2World across reset() (NO GPU needed).  The reference keeps ONE world for the life of an env (multi_car_racing.py:138; _destroy
- * :173-181 and reset :341 destroy and re-create its bodies): from the second episode on, the fixtures' broadphase proxy ids come off the dynamic
- * tree's free list, and the ids order the contact callbacks of a step — which of two cars that reach a tile in the same step is its first visitor
- * (:113-120).  A handle's episodes are by default each the first of a fresh world; a caller that wants the reference's behaviour keeps an
- * mcr_world next to its env: mcr_world_reset(w, blob) before staging an episode blob (destroys the old episode's proxies and creates the new
- * one's in the reference's order; writes the ids into the blob, where the contact pass finds them), mcr_world_step(w, bodies) after EVERY step
- * and after the reset's own step, with the bodies of mcr_get_state (b2Body::SynchronizeFixtures -> b2DynamicTree::MoveProxy in b2World::Solve's
- * order).  The single-env facade (env.py) does; the batched envs do not (the tree would have to be advanced on the device every step). */
+/* ---- the env's b2World across reset() as a LITERAL host-side tree (NO GPU needed).  The reference keeps ONE world for the life of an env
+ * (multi_car_racing.py:138; _destroy :173-181 and reset :341 destroy and re-create its bodies): from the second episode on, the fixtures'
+ * broadphase proxy ids come off the dynamic tree's free list, and the ids order the contact callbacks of a step — which of two cars that reach a
+ * tile in the same step is its first visitor (:113-120) — and name fixtureA of a car<->car contact.  Since round 6 every handle carries that world
+ * itself (mcr_config::fresh_world = 0: a per-env stack of free leaf ids on the device, csrc/k_world.h — a proxy's leaf id never depends on the
+ * tree's shape); this host-side dynamic AABB tree with Box2D's insertion / balance / free-list rules (rounds 4-5's facade used it) stays as the
+ * independent twin the tests hold the stack rule against (tests/test_world_ids.py), and for callers of a fresh_world = 1 handle who want to supply
+ * the ids themselves: mcr_world_reset(w, blob) before staging an episode blob (destroys the old episode's proxies and creates the new one's in the
+ * reference's order; writes the ids into the blob, header word pad0 = 1, where the contact pass of a fresh_world = 1 handle finds them),
+ * mcr_world_step(w, bodies) after EVERY step and after the reset's own step, with the bodies of mcr_get_state (b2Body::SynchronizeFixtures ->
+ * b2DynamicTree::MoveProxy in b2World::Solve's order). */
 typedef struct mcr_world mcr_world;
 mcr_world* mcr_world_create(int num_agents);
 void mcr_world_destroy(mcr_world* w);
