@@ -124,8 +124,9 @@ __device__ __forceinline__ void collide_block(const McrParams& p, const int pass
   const int N = p.N, BN = p.BN;
   const uint8_t* slot = p.slots + ((size_t)env * 2 + es.slot) * MCR_SLOT_BYTES;
   const int T = ((const McrSlotHeader*)slot)->T;
-  // broadphase proxy ids: a fresh world's ascend in creation order (tile t -> t, car fixture pf -> TILE_CAP + pf sorts the same way); an episode
-  // slot that carries tables (the facade's world across reset(), mcr_world.cpp) has its own
+  // broadphase proxy ids (k_world.h: mcr_pid_tables): the env's ONE world across its episodes keeps a table (the default); a fresh_world handle's
+  // ids ascend in creation order (tile t -> t, car fixture pf -> TILE_CAP + pf sorts the same way) unless the episode slot brought tables along
+  // (a caller's literal tree, mcr_world.cpp)
   const McrPidTables pidt = mcr_pid_tables(p, env, slot);
   const bool has_pid = pidt.has;
   const uint16_t* TPID = pidt.tile; const uint16_t* FPID = pidt.fix;

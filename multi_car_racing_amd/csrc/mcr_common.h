@@ -75,7 +75,7 @@ struct McrSlotHeader {
 #define MCR_OFF_QBLK (MCR_OFF_TCNT + 4 * MCR_TILE_CAP)        // float4 [QUAD_CAP / QBLK]  lo.xy hi.xy of each run of QBLK road_poly entries (empty: lo > hi)
 #define MCR_TBLK 16                                           // tiles per culling block of the contact pass
 #define MCR_OFF_TBLK (MCR_OFF_QBLK + 16 * (MCR_QUAD_CAP / MCR_QBLK))   // float4 [TILE_CAP / TBLK]  lo.xy hi.xy of each run of TBLK tile sensor AABBs (empty: lo > hi)
-// broadphase proxy ids of the episode's fixtures (header.pad0 != 0: present — the single-env facade's world, mcr_world.cpp; 0: the ids of a
+// broadphase proxy ids of the episode's fixtures (header.pad0 != 0: present — a caller's literal tree, mcr_world.cpp, honoured by fresh_world = 1 handles; 0: the ids of a
 // fresh world, ascending in creation order): what orders the contact callbacks of a step and names fixtureA of a pair (k_collide.h)
 #define MCR_OFF_TPID (MCR_OFF_TBLK + 16 * (MCR_TILE_CAP / MCR_TBLK))  // u16 [TILE_CAP]          tile t
 #define MCR_OFF_FPID (MCR_OFF_TPID + 2 * MCR_TILE_CAP)                // u16 [MAX_AGENTS * 8]    car * 8 + fixture
